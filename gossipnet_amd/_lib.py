@@ -1,0 +1,111 @@
+"""ctypes binding of libgossipnet_hip.so (the C ABI of include/gossipnet_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgossipnet_hip.so")
+GNET_MAX_BLOCKS = 64
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
+_ERR = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported configuration",
+        ERR_WORKSPACE: "workspace too small", ERR_HIP: "HIP runtime error"}
+
+
+class GnetError(RuntimeError):
+    pass
+
+
+class InvalidArgumentError(GnetError, ValueError):
+    """Mirrors tf.errors.InvalidArgumentError raised by the reference ops."""
+
+
+class gnet_config(C.Structure):
+    _fields_ = [("num_classes", C.c_int32), ("num_blocks", C.c_int32), ("neighbor_thresh", C.c_float),
+                ("normalize_loss", C.c_int32), ("loss_multiplyer", C.c_float),
+                ("shortcut_dim", C.c_int32), ("reduced_dim", C.c_int32), ("pairfeat_dim", C.c_int32),
+                ("pwfeat_dim", C.c_int32), ("pwfeat_narrow_dim", C.c_int32),
+                ("num_pwfeat_fc", C.c_int32), ("predict_fc_dim", C.c_int32), ("num_predict_fc", C.c_int32),
+                ("num_block_pw_fc", C.c_int32), ("num_block_fc", C.c_int32)]
+
+
+class gnet_shape(C.Structure):
+    _fields_ = [("n_img", C.c_int32), ("n_det", C.c_int32), ("n_gt", C.c_int32),
+                ("n_edge", C.c_int64), ("n_anno", C.c_int64)]
+
+
+class gnet_inputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dets", "det_scores", "det_classes", "det_off", "gt_boxes",
+                                          "gt_crowd", "gt_classes", "gt_off", "anno_off")]
+
+
+_PB = C.c_void_p * (GNET_MAX_BLOCKS + 1)
+
+
+class gnet_buffers(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "geo", "pw_h1", "pw_h2",
+                                           "pw_feats")] +
+                [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q")] +
+                [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
+                                           "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
+                                           "d_pw", "d_h1", "packed_t", "arena", "scratch_i", "match_ws")] +
+                [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t)])
+
+
+EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_workspace_bytes", "gnet_plan",
+           "gnet_forward", "gnet_loss", "gnet_backward", "det_matching_workspace_bytes", "det_matching_f32",
+           "roi_pool_fwd_f32", "roi_pool_bwd_f32", "gnet_version"]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnetError("libgossipnet_hip.so is missing (%s): build it with "
+                        "`python -m gossipnet_amd.build` -- there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    P = C.POINTER
+    lib.gnet_param_count.restype = i64
+    lib.gnet_param_count.argtypes = [P(gnet_config)]
+    lib.gnet_graph_count.restype = C.c_int
+    lib.gnet_graph_count.argtypes = [vp, i32, vp, i32, f32, vp, vp, vp]
+    lib.gnet_graph_fill.restype = C.c_int
+    lib.gnet_graph_fill.argtypes = [vp, i32, vp, i32, f32, vp, vp, vp, vp, vp]
+    lib.gnet_workspace_bytes.restype = sz
+    lib.gnet_workspace_bytes.argtypes = [P(gnet_config), P(gnet_shape), C.c_int]
+    lib.gnet_plan.restype = C.c_int
+    lib.gnet_plan.argtypes = [P(gnet_config), P(gnet_shape), C.c_int, vp, sz, P(gnet_buffers)]
+    lib.gnet_forward.restype = C.c_int
+    lib.gnet_forward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), C.c_int, vp]
+    lib.gnet_loss.restype = C.c_int
+    lib.gnet_loss.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, f32, P(gnet_buffers), vp]
+    lib.gnet_backward.restype = C.c_int
+    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, vp]
+    lib.det_matching_workspace_bytes.restype = sz
+    lib.det_matching_workspace_bytes.argtypes = [i32, i32]
+    lib.det_matching_f32.restype = C.c_int
+    lib.det_matching_f32.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.roi_pool_fwd_f32.restype = C.c_int
+    lib.roi_pool_fwd_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, i32, f32, vp, vp, vp]
+    lib.roi_pool_bwd_f32.restype = C.c_int
+    lib.roi_pool_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+    lib.gnet_version.restype = C.c_char_p
+    lib.gnet_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status == OK:
+        return
+    msg = "%s failed: %s (%d)" % (what, _ERR.get(status, "unknown"), status)
+    if status == ERR_INVALID:
+        raise InvalidArgumentError(msg)
+    raise GnetError(msg)

@@ -1,0 +1,111 @@
+"""Global `cfg` with the reference's defaults and strict YAML merge.
+
+Mirrors nms_net/config.py:10-121 (values are part of the hot-path contract).
+EasyDict is not installed here; `AttrDict` gives the same attribute access.
+"""
+import yaml
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _defaults():
+    cfg = AttrDict()
+    cfg.random_seed = 42
+    cfg.prefetch_q_size = 20
+    cfg.log_dir = "./log"
+    cfg.imfeat_crop_width = 7
+    cfg.imfeat_crop_height = 7
+    t = cfg.train = AttrDict()
+    t.optimizer = "adam"
+    t.momentum = 0.9
+    t.weight_decay = 0.0005
+    t.num_iter = 100000
+    t.lr_multi_step = [(10000, 0.001), (80000, 0.0001), (200000, 0.0000001)]
+    t.gradient_clipping = -1.0
+    t.pos_weight = 0.1
+    t.max_num_detections = -1
+    t.normalize_loss = False
+    t.loss_multiplyer = 1.0
+    g = cfg.gnet = AttrDict()
+    g.neighbor_thresh = 0.2
+    g.shortcut_dim = 128
+    g.num_blocks = 16
+    g.reduced_dim = 32
+    g.pairfeat_dim = 2 * 32
+    g.gt_match_thresh = 0.5
+    g.num_block_pw_fc = 2
+    g.num_block_fc = 2
+    g.num_predict_fc = 3
+    g.block_dim = 2 * 32
+    g.predict_fc_dim = 128
+    g.imfeats = False
+    g.load_imfeats = False
+    g.imfeat_dim = -1
+    g.neighbor_feats = False
+    # the reference default is num_pwfeat_fc = 0 / pwfeat_narrow_dim = 64 (config.py:73,75); both shipped
+    # experiments override them (experiments/*/conf.yaml) and only that configuration is compiled.
+    g.num_pwfeat_fc = 3
+    g.pwfeat_dim = 256
+    g.pwfeat_narrow_dim = 32
+    g.weight_init = "xavier"
+    g.bias_const_init = 0.01
+    g.pw_feat_multiplyer = 1.0
+    return cfg
+
+
+cfg = _defaults()
+
+
+def _merge_a_into_b(a, b):
+    """config.py:82-112: unknown key -> KeyError, type mismatch -> ValueError."""
+    for k, v in a.items():
+        if k not in b:
+            raise KeyError("{} is not a valid config key".format(k))
+        if isinstance(b[k], dict):
+            if not isinstance(v, dict):
+                raise ValueError("Type mismatch for config key: {}".format(k))
+            _merge_a_into_b(v, b[k])
+            continue
+        old_type = type(b[k])
+        if old_type is not type(v):
+            if isinstance(b[k], (list, tuple)) and isinstance(v, (list, tuple)):
+                pass
+            elif isinstance(b[k], float) and isinstance(v, int) and not isinstance(v, bool):
+                v = float(v)
+            else:
+                raise ValueError("Type mismatch ({} vs. {}) for config key: {}".format(type(b[k]), type(v), k))
+        b[k] = v
+
+
+def cfg_from_file(filename, strict=False):
+    """config.py:115-121.  Keys of the reference's config that only steer out-of-scope
+    subsystems (imdb names, detector, save_iter ...) are ignored unless strict=True."""
+    with open(filename, "r") as f:
+        y = yaml.safe_load(f)
+
+    def prune(a, b):
+        out = {}
+        for k, v in a.items():
+            if k not in b:
+                if strict:
+                    raise KeyError("{} is not a valid config key".format(k))
+                continue
+            out[k] = prune(v, b[k]) if isinstance(v, dict) and isinstance(b[k], dict) else v
+        return out
+
+    _merge_a_into_b(prune(y, cfg), cfg)
+
+
+def reset_cfg():
+    d = _defaults()
+    cfg.clear()
+    cfg.update(d)

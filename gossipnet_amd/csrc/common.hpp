@@ -1,0 +1,193 @@
+// Shared device helpers + host-side parameter layout for libgossipnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gossipnet_hip.h"
+
+// ---- compiled dimensions (the two shipped experiment configs; see gnet_config) ----------
+constexpr int D_S = 128;   // shortcut_dim
+constexpr int D_R = 32;    // reduced_dim
+constexpr int D_P = 64;    // pairfeat_dim
+constexpr int D_H = 256;   // pwfeat_dim
+constexpr int D_E = 32;    // pwfeat_narrow_dim
+constexpr int D_HEAD = 128;
+// partial weight-gradient copies per parameter (upper bound on writer workgroups per kernel)
+constexpr int GNET_ARENA_PARTIALS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HIP_CHECK_RET(expr)                    \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return GNET_ERR_HIP; \
+  } while (0)
+
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? GNET_OK : GNET_ERR_HIP; }
+
+// ---- parameter layout (offsets in floats into the flat buffer; see gossipnet_hip.h) ------
+struct BlockLayout {
+  int64_t wr, br;    // reduce_dim [128,32], [32]
+  int64_t w1, b1;    // pw_fc1 [96,64] rows 0-31 pw, 32-63 centre, 64-95 neighbour; [64]
+  int64_t w2, b2;    // pw_fc2 [64,64]
+  int64_t w3, b3;    // fc1 [64,64]
+  int64_t w4, b4;    // fc2 [64,128]
+};
+struct ParamLayout {
+  int dpw;           // 2*C' + 7
+  int cprime;        // C if multiclass else 1
+  int64_t pw1, pb1, pw2, pb2, pw3, pb3;
+  BlockLayout blk[GNET_MAX_BLOCKS + 1];  // 1-based
+  int64_t hw1, hb1, hw2, hb2, hwl, hbl;
+  int64_t total;
+};
+
+static inline int config_supported(const gnet_config* c) {
+  if (!c) return 0;
+  return c->num_classes >= 1 && c->num_blocks >= 1 && c->num_blocks <= GNET_MAX_BLOCKS &&
+         c->shortcut_dim == D_S && c->reduced_dim == D_R && c->pairfeat_dim == D_P &&
+         c->pwfeat_dim == D_H && c->pwfeat_narrow_dim == D_E && c->num_pwfeat_fc == 3 &&
+         c->predict_fc_dim == D_HEAD && c->num_predict_fc == 3 && c->num_block_pw_fc == 2 &&
+         c->num_block_fc == 2;
+}
+
+static inline ParamLayout make_layout(const gnet_config* c) {
+  ParamLayout L;
+  L.cprime = c->num_classes > 1 ? c->num_classes : 1;
+  L.dpw = 2 * L.cprime + 7;
+  int64_t o = 0;
+  L.pw1 = o; o += (int64_t)L.dpw * D_H;
+  L.pb1 = o; o += D_H;
+  L.pw2 = o; o += D_H * D_H;
+  L.pb2 = o; o += D_H;
+  L.pw3 = o; o += D_H * D_E;
+  L.pb3 = o; o += D_E;
+  for (int b = 1; b <= c->num_blocks; ++b) {
+    BlockLayout& B = L.blk[b];
+    B.wr = o; o += D_S * D_R;
+    B.br = o; o += D_R;
+    B.w1 = o; o += (D_E + 2 * D_R) * D_P;
+    B.b1 = o; o += D_P;
+    B.w2 = o; o += D_P * D_P;
+    B.b2 = o; o += D_P;
+    B.w3 = o; o += D_P * D_P;
+    B.b3 = o; o += D_P;
+    B.w4 = o; o += D_P * D_S;
+    B.b4 = o; o += D_S;
+  }
+  L.hw1 = o; o += D_S * D_HEAD;
+  L.hb1 = o; o += D_HEAD;
+  L.hw2 = o; o += D_HEAD * D_HEAD;
+  L.hb2 = o; o += D_HEAD;
+  L.hwl = o; o += D_HEAD;
+  L.hbl = o; o += 1;
+  L.total = o;
+  return L;
+}
+
+// ---- fp32 MFMA tile primitives ---------------------------------------------------------
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// the 16 accumulator registers hold D[row][col] with col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Exact f32 fma chain.
+__device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// acc += A[32 x K] * Bt[32 x K]^T ; A, Bt row-major with leading dims lda/ldb (floats),
+// both 16-byte aligned at (row*ld + 4*half).  Each lane reads 4 consecutive k per 16-B load:
+// the half-waves pair k = kb+t (half 0) with k = kb+4+t (half 1), a permutation of the k sum.
+template <int K>
+__device__ __forceinline__ void mma_abt(f32x16& acc, const float* A, int lda, const float* Bt, int ldb,
+                                        int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* ap = A + r * lda + 4 * h;
+  const float* bp = Bt + r * ldb + 4 * h;
+#pragma unroll
+  for (int k = 0; k < K; k += 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+
+// Two row tiles (A0, A1) against the same Bt (B fetched once).
+template <int K>
+__device__ __forceinline__ void mma_abt2(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1,
+                                         int lda, const float* Bt, int ldb, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* a0p = A0 + r * lda + 4 * h;
+  const float* a1p = A1 + r * lda + 4 * h;
+  const float* bp = Bt + r * ldb + 4 * h;
+#pragma unroll 4
+  for (int k = 0; k < K; k += 8) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + k);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + k);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + k);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+  }
+}
+
+// acc[m][n] += X[32 rows x (32*MI)]^T * Y[32 rows x (32*NJ)] (weight-gradient shape: the
+// contraction runs over the 32 tile rows).  X, Y row-major; rows that do not exist must be 0 in Y.
+template <int MI, int NJ>
+__device__ __forceinline__ void mma_xty(f32x16 (&acc)[MI][NJ], const float* X, int ldx, const float* Y,
+                                        int ldy, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int row = 2 * kk + h;
+    float a[MI], b[NJ];
+#pragma unroll
+    for (int m = 0; m < MI; ++m) a[m] = X[row * ldx + 32 * m + r];
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) b[n] = Y[row * ldy + 32 * n + r];
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+      for (int n = 0; n < NJ; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// Wave-level LDS hand-off: all earlier LDS accesses of this wave complete before later ones.
+// (LDS operations of one wave execute in order; this pins the compiler and drains lgkmcnt.)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// (segment max, tie count) packed as (float bits << 32) | count; values are >= 0 (post-ReLU)
+// so the float order equals the unsigned order of the bits.  combine() is associative and
+// commutative, so any reduction order gives bit-identical results.
+__device__ __forceinline__ void pm_flush(unsigned long long* addr, float m, unsigned cnt) {
+  const unsigned mb = __float_as_uint(m);
+  unsigned long long old = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    const unsigned ob = (unsigned)(old >> 32);
+    if (ob > mb) return;
+    const unsigned long long neu =
+        (ob == mb) ? (old + cnt) : (((unsigned long long)mb << 32) | (unsigned long long)cnt);
+    if (__hip_atomic_compare_exchange_strong(addr, &old, neu, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT))
+      return;
+  }
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* addr, float v) {
+  __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

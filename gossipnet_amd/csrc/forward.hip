@@ -1,0 +1,517 @@
+// Forward pass of Gnet (network.py:197-273): pairwise geometry features, the pairwise-feature
+// MLP, the stacked _block message passing, and the prediction head.
+//
+// Kernels
+//   pack_transpose   W[in,out] -> Wt[out,in] for every FC (B operands are read 4-along-K)
+//   pw_fwd           _geometry_feats (network.py:411-454) fused with _pw_feats_fc (:324-342):
+//                    the [E,167] feature matrix never exists; fc1 uses the one-hot x score
+//                    structure of its first 2C columns (2 row lookups + 7 geometry FMAs per output).
+//   edge_fwd         per block: build_context + pw_fc1 + pw_fc2 + segment_max (:367-388)
+//   node_fwd         per block: fc1, fc2, shortcut (:390-408) of block b and reduce_dim (:348-354)
+//                    + the per-node halves of pw_fc1 of block b+1; after the last block: head (:258-273)
+// All dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// pack_transpose: matrix id -> (offset, in, out) computed from the flat layout.
+__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, long long* off, int* in, int* out) {
+  const long long pw_sz = (long long)dpw * D_H + D_H + D_H * D_H + D_H + D_H * D_E + D_E;
+  const long long blk_sz = D_S * D_R + D_R + (D_E + 2 * D_R) * D_P + D_P + D_P * D_P + D_P + D_P * D_P + D_P +
+                           D_P * D_S + D_S;
+  if (id == 0) { *off = 0; *in = dpw; *out = D_H; return; }
+  if (id == 1) { *off = (long long)dpw * D_H + D_H; *in = D_H; *out = D_H; return; }
+  if (id == 2) { *off = (long long)dpw * D_H + D_H + D_H * D_H + D_H; *in = D_H; *out = D_E; return; }
+  id -= 3;
+  if (id < 5 * nblocks) {
+    const int b = id / 5, m = id % 5;
+    long long o = pw_sz + (long long)b * blk_sz;
+    if (m == 0) { *off = o; *in = D_S; *out = D_R; return; }
+    o += D_S * D_R + D_R;
+    if (m == 1) { *off = o; *in = D_E + 2 * D_R; *out = D_P; return; }
+    o += (D_E + 2 * D_R) * D_P + D_P;
+    if (m == 2) { *off = o; *in = D_P; *out = D_P; return; }
+    o += D_P * D_P + D_P;
+    if (m == 3) { *off = o; *in = D_P; *out = D_P; return; }
+    o += D_P * D_P + D_P;
+    *off = o; *in = D_P; *out = D_S; return;
+  }
+  id -= 5 * nblocks;
+  long long o = pw_sz + (long long)nblocks * blk_sz;
+  if (id == 0) { *off = o; *in = D_S; *out = D_HEAD; return; }
+  o += D_S * D_HEAD + D_HEAD;
+  *off = o; *in = D_HEAD; *out = D_HEAD;
+}
+
+__global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ params, float* __restrict__ packed,
+                                                      int dpw, int nblocks) {
+  long long off; int in, out;
+  mat_info(blockIdx.y, dpw, nblocks, &off, &in, &out);
+  const int total = in * out;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int o = i / in, k = i - o * in;   // packed[o][k] = W[k][o]
+    packed[off + i] = params[off + (long long)k * out + o];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int PW_T = 64;         // edges per workgroup iteration
+constexpr int PW_LD = D_H + 4;   // padded LDS row (conflict-free 16-B operand reads)
+
+struct PwFwdArgs {
+  int n_edge;
+  const int* edge_c; const int* edge_n; const float* edge_iou;
+  const float4* dets; const float* scores; const int* classes;
+  int cprime, multiclass;
+  const float* w1; const float* b1;     // natural [dpw,256]
+  const float* w2t; const float* b2;    // transposed [256,256]
+  const float* w3t; const float* b3;    // transposed [32,256]
+  float* geo; float* h1; float* h2; float* pw;
+  int training;
+};
+
+__global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sH = smem;                          // [64][260]
+  float* sR = sH + PW_T * PW_LD;             // [4][64][32]
+  float* sGeo = sR + 4 * PW_T * D_E;         // [64][8]
+  float* sSc = sGeo + PW_T * 8;              // [64]
+  float* sSn = sSc + PW_T;                   // [64]
+  int* sRc = reinterpret_cast<int*>(sSn + PW_T);   // [64] fc1 row of the centre score column
+  int* sRn = sRc + PW_T;                     // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = tid & 255, eh = tid >> 8;
+  const int geo_row0 = 2 * a.cprime;
+  float wg[7];
+#pragma unroll
+  for (int g = 0; g < 7; ++g) wg[g] = a.w1[(size_t)(geo_row0 + g) * D_H + f];
+  const float bias1 = a.b1[f];
+  const float log2f_ = 0.69314718f;          // float32(np.log(2.0)) network.py:447
+
+  for (int tile = blockIdx.x; tile * PW_T < a.n_edge; tile += gridDim.x) {
+    const int e0 = tile * PW_T;
+    // ---- phase 0: one thread per edge -> geometry features (network.py:427-450)
+    if (tid < PW_T) {
+      const int e = e0 + tid;
+      float sc = 0.f, sn = 0.f; int rc = 0, rn = 0;
+      float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (e < a.n_edge) {
+        const int c = a.edge_c[e], n = a.edge_n[e];
+        const float4 cb = a.dets[c], nb = a.dets[n];
+        const float c_w = cb.z - cb.x, c_h = cb.w - cb.y;
+        const float n_w = nb.z - nb.x, n_h = nb.w - nb.y;
+        const float c_scale = (c_w + c_h) / 2.0f;
+        const float c_cx = cb.x + c_w / 2.0f, c_cy = cb.y + c_h / 2.0f;
+        const float n_cx = nb.x + n_w / 2.0f, n_cy = nb.y + n_h / 2.0f;
+        float xd = n_cx - c_cx, yd = n_cy - c_cy;
+        const float l2 = sqrtf(xd * xd + yd * yd) / c_scale;
+        xd = xd / c_scale; yd = yd / c_scale;
+        g[0] = a.edge_iou[e];
+        g[1] = xd; g[2] = yd; g[3] = l2;
+        g[4] = logf(n_w / c_w) / log2f_;
+        g[5] = logf(n_h / c_h) / log2f_;
+        g[6] = (logf(n_w / n_h) - logf(c_w / c_h)) / log2f_;
+        sc = a.scores[c]; sn = a.scores[n];
+        if (a.multiclass) {                   // scatter_nd one-hot x score (network.py:413-419)
+          const int cc = a.classes[c] - 1, cn = a.classes[n] - 1;
+          if (cc >= 0 && cc < a.cprime) rc = cc; else sc = 0.f;
+          if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
+        } else { rc = 0; rn = 1; }
+        if (a.training) {
+          float4* gp = reinterpret_cast<float4*>(a.geo + (size_t)e * 8);
+          gp[0] = make_float4(g[0], g[1], g[2], g[3]);
+          gp[1] = make_float4(g[4], g[5], g[6], 0.f);
+        }
+      }
+      sSc[tid] = sc; sSn[tid] = sn; sRc[tid] = rc; sRn[tid] = rn;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sGeo[tid * 8 + k] = g[k];
+    }
+    __syncthreads();
+    // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output)
+    for (int k = 0; k < PW_T / 2; ++k) {
+      const int el = 2 * k + eh;
+      float v = sSc[el] * a.w1[(size_t)sRc[el] * D_H + f];
+      v = fmaf(sSn[el], a.w1[(size_t)sRn[el] * D_H + f], v);
+#pragma unroll
+      for (int g = 0; g < 7; ++g) v = fmaf(sGeo[el * 8 + g], wg[g], v);
+      v = fmaxf(v + bias1, 0.f);
+      sH[el * PW_LD + f] = v;
+      if (a.training && e0 + el < a.n_edge) a.h1[(size_t)(e0 + el) * D_H + f] = v;
+    }
+    __syncthreads();
+    // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
+    f32x16 acc0 = zero16(), acc1 = zero16();
+    mma_abt2<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
+    const int col = lane & 31, half = lane >> 5;
+    const float bias2 = a.b2[32 * wave + col];
+    __syncthreads();   // every wave has finished reading fc1 activations
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      const float v0 = fmaxf(acc0[r] + bias2, 0.f), v1 = fmaxf(acc1[r] + bias2, 0.f);
+      sH[row * PW_LD + 32 * wave + col] = v0;
+      sH[(32 + row) * PW_LD + 32 * wave + col] = v1;
+      if (a.training) {
+        if (e0 + row < a.n_edge) a.h2[(size_t)(e0 + row) * D_H + 32 * wave + col] = v0;
+        if (e0 + 32 + row < a.n_edge) a.h2[(size_t)(e0 + 32 + row) * D_H + 32 * wave + col] = v1;
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: fc3 (256 -> 32): wave = (row tile, K quarter), partial sums through LDS
+    {
+      const int mt = wave & 1, kq = wave >> 1;
+      f32x16 acc = zero16();
+      mma_abt<64>(acc, sH + mt * 32 * PW_LD + 64 * kq, PW_LD, a.w3t + 64 * kq, D_H, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i;
+      const int el = idx >> 5, pf = idx & 31;
+      float v = sR[(0 * PW_T + el) * D_E + pf];
+      v += sR[(1 * PW_T + el) * D_E + pf];
+      v += sR[(2 * PW_T + el) * D_E + pf];
+      v += sR[(3 * PW_T + el) * D_E + pf];
+      v = fmaxf(v + a.b3[pf], 0.f);
+      if (e0 + el < a.n_edge) a.pw[(size_t)(e0 + el) * D_E + pf] = v;
+    }
+  }
+}
+
+constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 4 * PW_T * D_E + PW_T * 8 + 4 * PW_T) * sizeof(float);
+
+// ------------------------------------------------------------------------------------------
+// edge_fwd: one wave = one 32-edge tile at a time, 4 independent waves per workgroup sharing the
+// weights in LDS.  h1 = relu(P.Wp + rc[c] + (c != n) rn[n]);  h2 = relu(h1.W2 + b2);
+// (max, tie count) per (centre, feature) streamed into pm[] (network.py:387-388).
+constexpr int E_LD1 = D_E + 4;   // 36
+constexpr int E_LD2 = D_P + 4;   // 68
+
+struct EdgeFwdArgs {
+  int n_edge;
+  const int* edge_c; const int* edge_n;
+  const float* pw;               // [E,32]
+  const float* rc; const float* rn;   // [N,64]
+  const float* w1t;              // transposed pw_fc1 [64][96]: columns 0-31 = pairwise rows
+  const float* w2t; const float* b2;   // transposed pw_fc2 [64][64]
+  unsigned long long* pm;        // [N,64], zeroed
+};
+
+__device__ __forceinline__ void edge_tile_h1(const EdgeFwdArgs& a, int e0, int lane, int my_c, int my_n,
+                                             const float* sWp, f32x16 (&h1)[2]) {
+  const int col = lane & 31, half = lane >> 5;
+  // accumulator init = per-node halves of pw_fc1 (gathered), then += P . Wp on the matrix core
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = crow(r, half);
+    const int c = __shfl(my_c, row), n = __shfl(my_n, row);
+    float v0 = 0.f, v1 = 0.f;
+    if (c >= 0) {
+      v0 = a.rc[(size_t)c * D_P + col]; v1 = a.rc[(size_t)c * D_P + 32 + col];
+      if (c != n) { v0 += a.rn[(size_t)n * D_P + col]; v1 += a.rn[(size_t)n * D_P + 32 + col]; }  // :371-374
+    }
+    h1[0][r] = v0; h1[1][r] = v1;
+  }
+  const int er = min(e0 + (lane & 31), a.n_edge - 1);
+  const float* ap = a.pw + (size_t)er * D_E + 4 * half;
+  const float* b0 = sWp + (lane & 31) * E_LD1 + 4 * half;
+  const float* b1 = b0 + 32 * E_LD1;
+#pragma unroll
+  for (int k = 0; k < D_E; k += 8) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
+    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
+    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1[0], 0, 0, 0);
+    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1[1], 0, 0, 0);
+    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1[0], 0, 0, 0);
+    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1[1], 0, 0, 0);
+    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1[0], 0, 0, 0);
+    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1[1], 0, 0, 0);
+    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1[0], 0, 0, 0);
+    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { h1[0][r] = fmaxf(h1[0][r], 0.f); h1[1][r] = fmaxf(h1[1][r], 0.f); }
+}
+
+__global__ void __launch_bounds__(256) edge_fwd(const EdgeFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sWp[D_P * E_LD1];      // [64][36]
+  __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]
+  __shared__ __attribute__((aligned(16))) float sH1[4][32 * E_LD2];    // per wave [32][68]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < D_P * D_E; i += 256) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 256) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
+  __syncthreads();
+  const int col = lane & 31, half = lane >> 5;
+  const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
+  const int ntiles = (a.n_edge + 31) / 32;
+  const int nwaves = gridDim.x * 4;
+  const int per = (ntiles + nwaves - 1) / nwaves;
+  const int gw = blockIdx.x * 4 + wave;
+  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  float* sh = sH1[wave];
+  int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned c0 = 0, c1 = 0;   // running (max, count) of this lane
+  for (int t = t0; t < t1; ++t) {
+    const int e0 = t * 32;
+    const int e = e0 + (lane & 31);
+    const int my_c = (e < a.n_edge) ? a.edge_c[e] : -1;
+    const int my_n = (e < a.n_edge) ? a.edge_n[e] : -1;
+    f32x16 h1[2];
+    edge_tile_h1(a, e0, lane, my_c, my_n, sWp, h1);
+    wave_lds_sync();   // previous tile's operand reads are complete
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      sh[row * E_LD2 + col] = h1[0][r];
+      sh[row * E_LD2 + 32 + col] = h1[1][r];
+    }
+    wave_lds_sync();
+    f32x16 h2a = zero16(), h2b = zero16();
+    mma_abt<D_P>(h2a, sh, E_LD2, sW2, E_LD2, lane);
+    mma_abt<D_P>(h2b, sh, E_LD2, sW2 + 32 * E_LD2, E_LD2, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      const int c = __shfl(my_c, row);
+      if (c < 0) continue;
+      const float v0 = fmaxf(h2a[r] + bias0, 0.f), v1 = fmaxf(h2b[r] + bias1, 0.f);
+      if (c != cur) {
+        if (cur >= 0) {
+          pm_flush(a.pm + (size_t)cur * D_P + col, m0, c0);
+          pm_flush(a.pm + (size_t)cur * D_P + 32 + col, m1, c1);
+        }
+        cur = c; m0 = v0; c0 = 1; m1 = v1; c1 = 1;
+      } else {
+        if (v0 > m0) { m0 = v0; c0 = 1; } else if (v0 == m0) { ++c0; }
+        if (v1 > m1) { m1 = v1; c1 = 1; } else if (v1 == m1) { ++c1; }
+      }
+    }
+  }
+  if (cur >= 0) {
+    pm_flush(a.pm + (size_t)cur * D_P + col, m0, c0);
+    pm_flush(a.pm + (size_t)cur * D_P + 32 + col, m1, c1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// node_fwd: one workgroup (4 waves) per 32-detection tile.
+constexpr int N_LD = D_S + 4;    // 132
+
+struct NodeFwdArgs {
+  int n_det;
+  int do_post;                   // finish block b: p -> q -> y -> x_out
+  int do_pre;                    // start block b+1: r, rc, rn
+  int do_head;                   // after the last block: predict/fc1, fc2, logits
+  int training;
+  const unsigned long long* pm;  // [N,64] block b
+  const float* x_prev;           // [N,128] block b input (NULL = zeros)
+  const float* w3t; const float* b3;   // fc1 transposed [64][64]
+  const float* w4t; const float* b4;   // fc2 transposed [128][64]
+  float* q; float* x_out;
+  const float* wrt; const float* br;   // next block reduce_dim transposed [32][128]
+  const float* w1t; const float* b1;   // next block pw_fc1 transposed [64][96]
+  float* r; float* rc; float* rn;
+  const float* hw1t; const float* hb1; const float* hw2t; const float* hb2; const float* hwl; const float* hbl;
+  float* head1; float* head2; float* pred;
+};
+
+__global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sX[32 * N_LD];
+  __shared__ __attribute__((aligned(16))) float sY[32 * N_LD];
+  __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int row0 = blockIdx.x * 32;
+  if (a.do_post) {
+    // p tile (segment max) -> sY[32][68]
+    for (int i = tid; i < 32 * D_P; i += 256) {
+      const int row = i >> 6, ff = i & 63;
+      const int node = min(row0 + row, a.n_det - 1);
+      sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(a.pm[(size_t)node * D_P + ff] >> 32));
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    if (wave < 2) mma_abt<D_P>(acc, sY, E_LD2, a.w3t + (size_t)(32 * wave) * D_P, D_P, lane);
+    __syncthreads();
+    if (wave < 2) {
+      const float bb = a.b3[32 * wave + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const float v = fmaxf(acc[r] + bb, 0.f);
+        sX[row * E_LD2 + 32 * wave + col] = v;       // q staged in sX with leading dim 68
+        if (a.training && row0 + row < a.n_det) a.q[(size_t)(row0 + row) * D_P + 32 * wave + col] = v;
+      }
+    }
+    __syncthreads();
+    acc = zero16();
+    mma_abt<D_P>(acc, sX, E_LD2, a.w4t + (size_t)(32 * wave) * D_P, D_P, lane);
+    __syncthreads();
+    {
+      const float bb = a.b4[32 * wave + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const int node = row0 + row;
+        float xin = 0.f;
+        if (a.x_prev && node < a.n_det) xin = a.x_prev[(size_t)node * D_S + 32 * wave + col];
+        const float v = fmaxf(xin + (acc[r] + bb), 0.f);   // relu(infeats + feats) network.py:408
+        sX[row * N_LD + 32 * wave + col] = v;
+        if (node < a.n_det) a.x_out[(size_t)node * D_S + 32 * wave + col] = v;
+      }
+    }
+    __syncthreads();
+  } else {
+    for (int i = tid; i < 32 * N_LD; i += 256) sX[i] = 0.f;   // start_feat = zeros (network.py:241-246)
+    __syncthreads();
+  }
+  if (a.do_pre) {
+    // r = relu(x . Wr + br): K = 128 split over the 4 waves
+    {
+      f32x16 acc = zero16();
+      mma_abt<32>(acc, sX + 32 * wave, N_LD, a.wrt + 32 * wave, D_S, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[(wave * 32 + crow(r, half)) * 32 + col] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * D_R; i += 256) {
+      const int row = i >> 5, ff = i & 31;
+      float v = sR[(0 * 32 + row) * 32 + ff] + sR[(1 * 32 + row) * 32 + ff];
+      v += sR[(2 * 32 + row) * 32 + ff];
+      v += sR[(3 * 32 + row) * 32 + ff];
+      v = fmaxf(v + a.br[ff], 0.f);
+      sY[row * E_LD1 + ff] = v;
+      if (a.training && row0 + row < a.n_det) a.r[(size_t)(row0 + row) * D_R + ff] = v;
+    }
+    __syncthreads();
+    // rc = r . W1[32:64] + b1 (waves 0,1) ; rn = r . W1[64:96] (waves 2,3)
+    {
+      const int part = wave >> 1, nt = wave & 1;
+      f32x16 acc = zero16();
+      mma_abt<D_R>(acc, sY, E_LD1, a.w1t + (size_t)(32 * nt) * (D_E + 2 * D_R) + D_E + part * D_R, D_E + 2 * D_R, lane);
+      const float bb = part == 0 ? a.b1[32 * nt + col] : 0.f;
+      float* dst = part == 0 ? a.rc : a.rn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int node = row0 + crow(r, half);
+        if (node < a.n_det) dst[(size_t)node * D_P + 32 * nt + col] = acc[r] + bb;
+      }
+    }
+  }
+  if (a.do_head) {
+    __syncthreads();
+    f32x16 acc = zero16();
+    mma_abt<D_S>(acc, sX, N_LD, a.hw1t + (size_t)(32 * wave) * D_S, D_S, lane);
+    {
+      const float bb = a.hb1[32 * wave + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const float v = acc[r] + bb;                 // activation_fn=None (network.py:263)
+        sY[row * N_LD + 32 * wave + col] = v;
+        if (a.training && row0 + row < a.n_det) a.head1[(size_t)(row0 + row) * D_HEAD + 32 * wave + col] = v;
+      }
+    }
+    __syncthreads();
+    acc = zero16();
+    mma_abt<D_HEAD>(acc, sY, N_LD, a.hw2t + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
+    __syncthreads();
+    {
+      const float bb = a.hb2[32 * wave + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const float v = acc[r] + bb;
+        sX[row * N_LD + 32 * wave + col] = v;
+        if (a.training && row0 + row < a.n_det) a.head2[(size_t)(row0 + row) * D_HEAD + 32 * wave + col] = v;
+      }
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 3, part = tid & 7;      // 8 threads per detection
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s = fmaf(sX[row * N_LD + part * 16 + k], a.hwl[part * 16 + k], s);
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      if (part == 0 && row0 + row < a.n_det) a.pred[row0 + row] = s + a.hbl[0];
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                            const float* params, gnet_buffers* buf, int training, gnet_stream_t stream) {
+  if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
+  if (!shape || !in || !params || !buf) return GNET_ERR_INVALID;
+  if (shape->n_det < 0 || shape->n_edge < 0 || shape->n_img < 1) return GNET_ERR_INVALID;
+  if (shape->n_det == 0) return GNET_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const ParamLayout L = make_layout(cfg);
+  const int B = cfg->num_blocks;
+  const int N = shape->n_det;
+  const int E = (int)shape->n_edge;
+  float* pt = buf->packed_t;
+
+  pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B);
+
+  if (E > 0) {
+    PwFwdArgs a;
+    a.n_edge = E; a.edge_c = buf->edge_c; a.edge_n = buf->edge_n; a.edge_iou = buf->edge_iou;
+    a.dets = (const float4*)in->dets; a.scores = in->det_scores; a.classes = in->det_classes;
+    a.cprime = L.cprime; a.multiclass = cfg->num_classes > 1;
+    a.w1 = params + L.pw1; a.b1 = params + L.pb1;
+    a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
+    a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
+    a.geo = buf->geo; a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
+    const int tiles = (E + PW_T - 1) / PW_T;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
+      attr_set = true;
+    }
+    pw_fwd<<<min(tiles, 256), 512, kPwFwdSmem, s>>>(a);
+  }
+
+  const int ntile_n = (N + 31) / 32;
+  const int etiles = (E + 31) / 32;
+  const int egrid = max(1, min(512, (etiles + 3) / 4));
+  for (int b = 0; b <= B; ++b) {
+    // node stage between edge kernels: finish block b (b >= 1), start block b+1 (b < B)
+    NodeFwdArgs n;
+    n.n_det = N; n.do_post = b >= 1; n.do_pre = b < B; n.do_head = b == B; n.training = training;
+    n.pm = b >= 1 ? (const unsigned long long*)buf->blk_pm[b] : nullptr;
+    n.x_prev = b >= 2 ? buf->block_feats[b - 1] : nullptr;
+    if (b >= 1) {
+      n.w3t = pt + L.blk[b].w3; n.b3 = params + L.blk[b].b3;
+      n.w4t = pt + L.blk[b].w4; n.b4 = params + L.blk[b].b4;
+      n.q = buf->blk_q[b]; n.x_out = buf->block_feats[b];
+    } else { n.w3t = n.b3 = n.w4t = n.b4 = nullptr; n.q = n.x_out = nullptr; }
+    if (b < B) {
+      n.wrt = pt + L.blk[b + 1].wr; n.br = params + L.blk[b + 1].br;
+      n.w1t = pt + L.blk[b + 1].w1; n.b1 = params + L.blk[b + 1].b1;
+      n.r = buf->blk_r[b + 1]; n.rc = buf->blk_rc[b + 1]; n.rn = buf->blk_rn[b + 1];
+    } else { n.wrt = n.br = n.w1t = n.b1 = nullptr; n.r = n.rc = n.rn = nullptr; }
+    n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
+    n.hwl = params + L.hwl; n.hbl = params + L.hbl;
+    n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
+    node_fwd<<<ntile_n, 256, 0, s>>>(n);
+    if (b < B) {
+      HIP_CHECK_RET(hipMemsetAsync(buf->blk_pm[b + 1], 0, (size_t)N * D_P * sizeof(unsigned long long), s));
+      if (E > 0) {
+        EdgeFwdArgs e;
+        e.n_edge = E; e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
+        e.rc = buf->blk_rc[b + 1]; e.rn = buf->blk_rn[b + 1];
+        e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
+        e.pm = (unsigned long long*)buf->blk_pm[b + 1];
+        edge_fwd<<<egrid, 256, 0, s>>>(e);
+      }
+    }
+  }
+  return launch_status();
+}

@@ -1,0 +1,162 @@
+// Neighbour-graph construction: N x N box IoU sweep -> ordered CSR edge list.
+// Replaces network.py:170-176 (_xyxy_to_boxdata, _iou of dets with dets) and
+// network.py:192-195 (tf.where(det_det_iou >= neighbor_thresh), row-major order).
+//
+// Bit-exactness contract: iou = inter / ((a_area + b_area) - inter), inter = w*h with
+// w = max(0, min(ax2,bx2) - max(ax1,bx1)); no FMA contraction (-ffp-contract=off) and
+// IEEE-correct division (hipcc default), compared against the fp32 threshold.
+//
+// Two passes (count -> exclusive scan -> fill) so that edges come out in row-major order
+// without materialising the N x N matrix.  HBM-bound in principle (16 B per detection read,
+// 12 B per edge written) but at these sizes the sweep is ALU/latency bound: column boxes are
+// staged through LDS as SoA tiles and every wave tests 4 rows against each 64-column group.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kRowsPerWave = 4;
+constexpr int kWaves = 4;
+constexpr int kRowsPerBlock = kRowsPerWave * kWaves;
+constexpr int kColTile = 1024;
+
+__device__ __forceinline__ int image_of(const int* __restrict__ det_off, int n_img, int row) {
+  int lo = 0, hi = n_img;  // det_off[lo] <= row < det_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (det_off[mid] <= row) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) graph_sweep(const float4* __restrict__ dets, int n,
+                                                   const int* __restrict__ det_off, int n_img, float thr,
+                                                   int* __restrict__ deg, const int* __restrict__ row_ptr,
+                                                   int* __restrict__ edge_c, int* __restrict__ edge_n,
+                                                   float* __restrict__ edge_iou) {
+  __shared__ float sx1[kColTile], sy1[kColTile], sx2[kColTile], sy2[kColTile], sar[kColTile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int brow0 = blockIdx.x * kRowsPerBlock;
+  const int brow1 = min(n, brow0 + kRowsPerBlock) - 1;
+  // column range of the block = images touched by its rows
+  const int cmin = det_off[image_of(det_off, n_img, brow0)];
+  const int cmax = det_off[image_of(det_off, n_img, brow1) + 1];
+
+  float ax1[kRowsPerWave], ay1[kRowsPerWave], ax2[kRowsPerWave], ay2[kRowsPerWave], aar[kRowsPerWave];
+  int lo[kRowsPerWave], hi[kRowsPerWave], pos[kRowsPerWave];
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; ++q) {
+    const int row = brow0 + wave * kRowsPerWave + q;
+    if (row < n) {
+      const float4 b = dets[row];
+      ax1[q] = b.x; ay1[q] = b.y; ax2[q] = b.z; ay2[q] = b.w;
+      aar[q] = (b.z - b.x) * (b.w - b.y);           // network.py:468-471
+      const int img = image_of(det_off, n_img, row);
+      lo[q] = det_off[img]; hi[q] = det_off[img + 1];
+      pos[q] = FILL ? row_ptr[row] : 0;
+    } else {
+      ax1[q] = ay1[q] = ax2[q] = ay2[q] = aar[q] = 0.f;
+      lo[q] = hi[q] = 0; pos[q] = 0;
+    }
+  }
+
+  for (int c0 = cmin; c0 < cmax; c0 += kColTile) {
+    __syncthreads();
+    const int tile_n = min(kColTile, cmax - c0);
+    for (int i = threadIdx.x; i < tile_n; i += 256) {
+      const float4 b = dets[c0 + i];
+      sx1[i] = b.x; sy1[i] = b.y; sx2[i] = b.z; sy2[i] = b.w;
+      sar[i] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < tile_n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool valid = i < tile_n;
+      const int j = c0 + i;
+      const int ii = valid ? i : 0;
+      const float bx1 = sx1[ii], by1 = sy1[ii], bx2 = sx2[ii], by2 = sy2[ii], bar = sar[ii];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; ++q) {
+        // network.py:504-510
+        const float w = fmaxf(0.0f, fminf(ax2[q], bx2) - fmaxf(ax1[q], bx1));
+        const float h = fmaxf(0.0f, fminf(ay2[q], by2) - fmaxf(ay1[q], by1));
+        const float inter = w * h;
+        const bool inrange = valid && j >= lo[q] && j < hi[q];
+        // a pair with zero intersection has iou 0 (or NaN): it can only pass a threshold <= 0
+        const bool cand = inrange && (inter > 0.0f || !(thr > 0.0f));
+        if (__ballot(cand) == 0ull) continue;
+        const float uni = (aar[q] + bar) - inter;    // network.py:480
+        const float iou = inter / uni;               // network.py:481
+        const bool pred = inrange && (iou >= thr);   // network.py:192-193
+        const unsigned long long mask = __ballot(pred);
+        if (FILL) {
+          if (pred) {
+            const int p = pos[q] + __popcll(mask & ((1ull << lane) - 1ull));
+            edge_c[p] = brow0 + wave * kRowsPerWave + q;
+            edge_n[p] = j;
+            edge_iou[p] = iou;
+          }
+        }
+        pos[q] += __popcll(mask);
+      }
+    }
+  }
+  if (!FILL && lane == 0) {
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const int row = brow0 + wave * kRowsPerWave + q;
+      if (row < n) deg[row] = pos[q];
+    }
+  }
+}
+
+// Exclusive scan of deg[0..n) into out[0..n], out[n] = total.  One workgroup.
+__global__ void __launch_bounds__(1024) exclusive_scan(const int* __restrict__ deg, int n, int* __restrict__ out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per, e = min(n, b + per);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += deg[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = b; i < e; ++i) { const int d = deg[i]; out[i] = run; run += d; }
+  if (t == 1023) out[n] = part[1023];
+}
+
+}  // namespace
+
+extern "C" int gnet_graph_count(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
+                                float thresh, int32_t* row_ptr, int32_t* scratch, gnet_stream_t stream) {
+  if (n_det < 0 || n_img < 1 || !row_ptr || !det_off) return GNET_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_det == 0) {
+    HIP_CHECK_RET(hipMemsetAsync(row_ptr, 0, sizeof(int32_t), s));
+    return GNET_OK;
+  }
+  if (!dets || !scratch) return GNET_ERR_INVALID;
+  const int grid = (n_det + kRowsPerBlock - 1) / kRowsPerBlock;
+  graph_sweep<false><<<grid, 256, 0, s>>>((const float4*)dets, n_det, det_off, n_img, thresh, scratch,
+                                          nullptr, nullptr, nullptr, nullptr);
+  exclusive_scan<<<1, 1024, 0, s>>>(scratch, n_det, row_ptr);
+  return launch_status();
+}
+
+extern "C" int gnet_graph_fill(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
+                               float thresh, const int32_t* row_ptr, int32_t* edge_c, int32_t* edge_n,
+                               float* edge_iou, gnet_stream_t stream) {
+  if (n_det < 0 || n_img < 1 || !row_ptr || !det_off) return GNET_ERR_INVALID;
+  if (n_det == 0) return GNET_OK;
+  if (!dets || !edge_c || !edge_n || !edge_iou) return GNET_ERR_INVALID;
+  const int grid = (n_det + kRowsPerBlock - 1) / kRowsPerBlock;
+  graph_sweep<true><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)dets, n_det, det_off, n_img, thresh,
+                                                          nullptr, row_ptr, edge_c, edge_n, edge_iou);
+  return launch_status();
+}

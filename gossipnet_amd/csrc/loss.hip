@@ -1,0 +1,310 @@
+// Loss side of Gnet (network.py:174-187, 275-313) and the DetectionMatching op
+// (matching_module/det_matching.cc:72-160), all on device (the reference op is CPU-only and
+// forces a D->H->D round trip per step).
+//
+//   anno_iou      det_anno_iou = _iou(dets, gt, crowd) with IoA on crowd columns, class-masked
+//   match_cand    per detection: best two non-crowd candidates (iou >= 0.5) and first crowd hit
+//   match_rank    score order: rank = #{j : s_j > s_i or (s_j == s_i and j > i)}
+//                 (std::sort ascending + reverse with ties resolved "higher index first")
+//   match_greedy  one wave per image walks the detections in score order; only detections with a
+//                 non-crowd candidate touch the sequential state (a GT bitmask held in registers)
+//   loss_kernel   class weighting, sigmoid cross-entropy, per-image sums, d loss / d logit
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ int image_of(const int* __restrict__ off, int n_img, int row) {
+  int lo = 0, hi = n_img;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= row) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) anno_iou(const float4* __restrict__ dets, const int* __restrict__ det_classes,
+                                                const int* __restrict__ det_off, const float4* __restrict__ gts,
+                                                const unsigned char* __restrict__ gt_crowd,
+                                                const int* __restrict__ gt_classes, const int* __restrict__ gt_off,
+                                                const long long* __restrict__ anno_off, int n_det, int n_img,
+                                                int multiclass, float* __restrict__ out) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= n_det) return;
+  const int img = image_of(det_off, n_img, d);
+  const int g0 = gt_off[img], g1 = gt_off[img + 1];
+  const int m = g1 - g0;
+  float* row = out + anno_off[img] + (long long)(d - det_off[img]) * m;
+  const float4 a = dets[d];
+  const float a_area = (a.z - a.x) * (a.w - a.y);
+  const int dc = det_classes[d];
+  for (int g = g0; g < g1; ++g) {
+    const float4 b = gts[g];
+    const float b_area = (b.z - b.x) * (b.w - b.y);
+    const float w = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+    const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+    const float inter = w * h;
+    float v;
+    if (gt_crowd[g]) v = inter / a_area;                     // network.py:485-488
+    else v = inter / ((a_area + b_area) - inter);            // network.py:480-481
+    if (multiclass && dc != gt_classes[g]) v = 0.0f;         // network.py:182-187
+    row[g - g0] = v;
+  }
+}
+
+// Per detection: the two best non-crowd candidates as keys (iou bits << 32 | gt index): the
+// reference's inner loop keeps the maximum iou >= 0.5 and lets a later equal iou win
+// (det_matching.cc:142-148), i.e. the maximum key.  cfirst = first crowd GT with iou >= 0.5
+// (det_matching.cc:138 breaks at the next crowd once one matched).
+__global__ void __launch_bounds__(256) match_cand(const float* __restrict__ iou, const long long* __restrict__ anno_off,
+                                                  const int* __restrict__ det_off, const int* __restrict__ gt_off,
+                                                  const unsigned char* __restrict__ ignore, int n_det, int n_img,
+                                                  unsigned long long* __restrict__ k1, unsigned long long* __restrict__ k2,
+                                                  int* __restrict__ ncand, int* __restrict__ cfirst) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= n_det) return;
+  const int img = image_of(det_off, n_img, d);
+  const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
+  const float* row = iou + anno_off[img] + (long long)(d - det_off[img]) * m;
+  unsigned long long b1 = 0, b2 = 0;
+  int nc = 0, cf = -1;
+  for (int g = 0; g < m; ++g) {
+    const float v = row[g];
+    if (!(v >= 0.5f)) continue;
+    if (ignore[g0 + g]) { if (cf < 0) cf = g; continue; }
+    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)g;
+    ++nc;
+    if (key > b1) { b2 = b1; b1 = key; } else if (key > b2) { b2 = key; }
+  }
+  k1[d] = b1; k2[d] = b2; ncand[d] = nc; cfirst[d] = cf;
+}
+
+__global__ void __launch_bounds__(256) match_rank(const float* __restrict__ score, const int* __restrict__ det_off,
+                                                  int n_det, int n_img, int* __restrict__ order) {
+  __shared__ float ss[1024];
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  const int dd = min(d, n_det - 1);
+  const int b0 = blockIdx.x * 256, b1 = min(n_det, b0 + 256) - 1;
+  const int cmin = det_off[image_of(det_off, n_img, b0)];
+  const int cmax = det_off[image_of(det_off, n_img, b1) + 1];
+  const int img = image_of(det_off, n_img, dd);
+  const int lo = det_off[img], hi = det_off[img + 1];
+  const float s = score[dd];
+  int rank = 0;
+  for (int c0 = cmin; c0 < cmax; c0 += 1024) {
+    __syncthreads();
+    const int tn = min(1024, cmax - c0);
+    for (int i = threadIdx.x; i < tn; i += 256) ss[i] = score[c0 + i];
+    __syncthreads();
+    const int jlo = max(lo, c0), jhi = min(hi, c0 + tn);
+    for (int j = jlo; j < jhi; ++j) {
+      const float t = ss[j - c0];
+      rank += (t > s || (t == s && j > dd)) ? 1 : 0;
+    }
+  }
+  if (d < n_det) order[lo + rank] = d;
+}
+
+// One wave per image.  matched GT flags live in a per-lane bitmask: GT g -> lane g & 63, bit g >> 6
+// (up to 2048 GT per image; larger images take the LDS-free slow path below too, via global flags).
+__global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou, const long long* __restrict__ anno_off,
+                                                   const int* __restrict__ det_off, const int* __restrict__ gt_off,
+                                                   const unsigned char* __restrict__ ignore,
+                                                   const int* __restrict__ order, const unsigned long long* __restrict__ k1,
+                                                   const unsigned long long* __restrict__ k2,
+                                                   const int* __restrict__ ncand, const int* __restrict__ cfirst,
+                                                   float* __restrict__ labels, float* __restrict__ weights,
+                                                   int* __restrict__ assign) {
+  const int img = blockIdx.x, lane = threadIdx.x;
+  const int d0 = det_off[img], d1 = det_off[img + 1];
+  const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
+  const float* ibase = iou + anno_off[img];
+  unsigned matched = 0;   // bit b of lane l: GT (b*64 + l) is taken
+  for (int p0 = d0; p0 < d1; p0 += 64) {
+    const int p = p0 + lane;
+    const bool act = p < d1;
+    const int det = act ? order[p] : -1;
+    const unsigned long long c1 = act ? k1[det] : 0ull, c2 = act ? k2[det] : 0ull;
+    const int nc = act ? ncand[det] : 0;
+    const int cf = act ? cfirst[det] : -1;
+    int res = (act && nc == 0) ? cf : -1;     // no regular candidate: state-independent
+    unsigned long long todo = __ballot(act && nc > 0);
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int ga = (int)(unsigned)__shfl(c1, l);
+      const int nl = __shfl(nc, l);
+      int mt = -1;
+      if (!((__shfl(matched, ga & 63) >> (ga >> 6)) & 1u)) {
+        mt = ga;
+      } else if (nl >= 2) {
+        const int gb = (int)(unsigned)__shfl(c2, l);
+        if (!((__shfl(matched, gb & 63) >> (gb >> 6)) & 1u)) mt = gb;
+        else if (nl > 2) {
+          // rare: more than two candidates and the best two are taken -> scan the row
+          const int dl = __shfl(det, l);
+          const float* row = ibase + (long long)(dl - d0) * m;
+          unsigned long long best = 0;
+          for (int gbase = 0; gbase < m; gbase += 64) {
+            const int g = gbase + lane;
+            if (g < m) {
+              const float v = row[g];
+              const bool taken = (matched >> (gbase >> 6)) & 1u;
+              if (v >= 0.5f && !ignore[g0 + g] && !taken) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)g;
+                best = key > best ? key : best;
+              }
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            best = other > best ? other : best;
+          }
+          if (best) mt = (int)(unsigned)best;
+        }
+      }
+      if (mt >= 0) {
+        if (lane == (mt & 63)) matched |= 1u << (mt >> 6);
+      } else {
+        mt = __shfl(cf, l);    // fall through to the crowd GTs (det_matching.cc:134-148)
+      }
+      if (lane == l) res = mt;
+    }
+    if (act) {
+      assign[det] = res;
+      labels[det] = res >= 0 ? 1.0f : 0.0f;
+      weights[det] = (res >= 0 && ignore[g0 + res]) ? 0.0f : 1.0f;
+    }
+  }
+}
+
+// network.py:282-313.  One workgroup per image.
+__global__ void __launch_bounds__(256) loss_kernel(const float* __restrict__ pred, const float* __restrict__ labels,
+                                                   float* __restrict__ weights, const int* __restrict__ assign,
+                                                   const int* __restrict__ det_off, const int* __restrict__ gt_off,
+                                                   const unsigned char* __restrict__ gt_crowd,
+                                                   const int* __restrict__ gt_classes,
+                                                   const float* __restrict__ class_weights, int num_classes,
+                                                   int normalize, float loss_mult, float grad_scale,
+                                                   float* __restrict__ loss, float* __restrict__ d_logits) {
+  __shared__ float red[256];
+  const int img = blockIdx.x;
+  const int d0 = det_off[img], d1 = det_off[img + 1], g0 = gt_off[img];
+  const int n = d1 - d0;
+  const float gscale = grad_scale * loss_mult * (normalize ? (n > 0 ? 1.0f / (float)n : 0.f) : 1.0f);
+  float acc = 0.f;
+  for (int d = d0 + threadIdx.x; d < d1; d += 256) {
+    const int a = assign[d];
+    int cls = 0;
+    if (a >= 0 && !gt_crowd[g0 + a]) cls = gt_classes[g0 + a];        // :286-297
+    float cw = 1.0f;
+    if (class_weights) cw = (cls >= 0 && cls <= num_classes) ? class_weights[cls] : 0.f;
+    const float w = weights[d] * cw;                                    // :298-299
+    weights[d] = w;
+    const float x = pred[d], z = labels[d];
+    // sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))  (:301-302)
+    const float l = fmaxf(x, 0.f) - x * z + logf(1.0f + expf(-fabsf(x)));
+    acc += w * l;
+    const float sig = 1.0f / (1.0f + expf(-x));
+    d_logits[d] = gscale * w * (sig - z);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[2 * img] = red[0];                                  // cls_loss_unnormed (:304-305)
+    loss[2 * img + 1] = n > 0 ? red[0] / (float)n : 0.f;     // cls_loss_normed   (:307-308)
+  }
+}
+
+struct MatchWs {
+  int* order; unsigned long long* k1; unsigned long long* k2; int* ncand; int* cfirst;
+};
+size_t match_ws_bytes(int n_det) {
+  const size_t n = (size_t)n_det + 64;
+  return ((n * 4 + 255) & ~(size_t)255) * 3 + ((n * 8 + 255) & ~(size_t)255) * 2;
+}
+MatchWs carve_match(void* ws, int n_det) {
+  const size_t n = (size_t)n_det + 64;
+  const size_t s4 = (n * 4 + 255) & ~(size_t)255, s8 = (n * 8 + 255) & ~(size_t)255;
+  char* p = (char*)ws;
+  MatchWs w;
+  w.k1 = (unsigned long long*)p; p += s8;
+  w.k2 = (unsigned long long*)p; p += s8;
+  w.order = (int*)p; p += s4;
+  w.ncand = (int*)p; p += s4;
+  w.cfirst = (int*)p;
+  return w;
+}
+
+int run_matching(const float* iou, const long long* anno_off, const int* det_off, const int* gt_off,
+                 const unsigned char* ignore, const float* score, int n_det, int n_img, void* ws, float* labels,
+                 float* weights, int* assign, hipStream_t s) {
+  const MatchWs w = carve_match(ws, n_det);
+  const int grid = (n_det + 255) / 256;
+  match_cand<<<grid, 256, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, n_det, n_img, w.k1, w.k2, w.ncand, w.cfirst);
+  match_rank<<<grid, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
+  match_greedy<<<n_img, 64, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
+                                    labels, weights, assign);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t det_matching_workspace_bytes(int32_t n_det, int32_t n_gt) {
+  (void)n_gt;
+  if (n_det < 0) return 0;
+  return match_ws_bytes(n_det) + 1024;   // + the single-image offset tables
+}
+
+extern "C" int det_matching_f32(const float* iou, const float* score, const uint8_t* ignore, int32_t n_det,
+                                int32_t n_gt, float* labels, float* weights, int32_t* assignment, void* workspace,
+                                size_t workspace_bytes, gnet_stream_t stream) {
+  // shape checks of det_matching.cc:76-93 are the caller's tensor ranks; sizes must be consistent
+  if (n_det < 0 || n_gt < 0) return GNET_ERR_INVALID;
+  if (n_det == 0) return GNET_OK;
+  if (!score || !labels || !weights || !assignment || !workspace) return GNET_ERR_INVALID;
+  if (n_gt > 0 && (!iou || !ignore)) return GNET_ERR_INVALID;
+  if (n_gt > 2048) return GNET_ERR_UNSUPPORTED;
+  if (workspace_bytes < det_matching_workspace_bytes(n_det, n_gt)) return GNET_ERR_WORKSPACE;
+  if (((uintptr_t)workspace & 255) != 0) return GNET_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  // single image: offset tables live at the head of the workspace
+  struct { long long anno[2]; int det[2]; int gt[2]; } h;
+  h.anno[0] = 0; h.anno[1] = (long long)n_det * n_gt; h.det[0] = 0; h.det[1] = n_det; h.gt[0] = 0; h.gt[1] = n_gt;
+  HIP_CHECK_RET(hipMemcpyAsync(workspace, &h, sizeof(h), hipMemcpyHostToDevice, s));
+  HIP_CHECK_RET(hipStreamSynchronize(s));   // h is a stack object
+  const long long* anno_off = (const long long*)workspace;
+  const int* det_off = (const int*)((char*)workspace + 16);
+  const int* gt_off = (const int*)((char*)workspace + 24);
+  return run_matching(iou, anno_off, det_off, gt_off, ignore, score, n_det, 1, (char*)workspace + 1024, labels, weights,
+                      assignment, s);
+}
+
+extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                         const float* class_weights, float grad_scale, gnet_buffers* buf, gnet_stream_t stream) {
+  if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
+  if (!shape || !in || !buf || !buf->labels || !buf->match_ws) return GNET_ERR_INVALID;
+  if (shape->n_det == 0) return GNET_OK;
+  if (!in->gt_off || !in->anno_off || !in->det_off) return GNET_ERR_INVALID;
+  if (shape->n_gt > 0 && (!in->gt_boxes || !in->gt_crowd || !in->gt_classes)) return GNET_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = shape->n_det;
+  const int grid = (N + 255) / 256;
+  if (shape->n_gt > 0)
+    anno_iou<<<grid, 256, 0, s>>>((const float4*)in->dets, in->det_classes, in->det_off, (const float4*)in->gt_boxes,
+                                  in->gt_crowd, in->gt_classes, in->gt_off, (const long long*)in->anno_off, N,
+                                  shape->n_img, cfg->num_classes > 1, buf->det_anno_iou);
+  int st = run_matching(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
+                        buf->prediction, N, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
+                        buf->det_gt_matching, s);
+  if (st != GNET_OK) return st;
+  loss_kernel<<<shape->n_img, 256, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,
+                                           in->det_off, in->gt_off, in->gt_crowd, in->gt_classes, class_weights,
+                                           cfg->num_classes, cfg->normalize_loss, cfg->loss_multiplyer, grad_scale,
+                                           buf->loss, buf->d_logits);
+  return launch_status();
+}

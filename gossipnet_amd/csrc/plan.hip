@@ -1,0 +1,112 @@
+// Workspace carving (host code): gnet_param_count / gnet_workspace_bytes / gnet_plan.
+#include <string.h>
+#include "common.hpp"
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* b) : base((char*)b), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+// Upper bounds on the number of workgroups that write partial weight gradients (see backward.hip).
+size_t arena_floats(const gnet_config* cfg, const gnet_shape* sh) {
+  const ParamLayout L = make_layout(cfg);
+  (void)sh;
+  // every backward kernel writes at most kMaxPartials partial copies of the parameters it owns
+  return (size_t)GNET_ARENA_PARTIALS * (size_t)L.total;
+}
+
+size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* ws, gnet_buffers* out) {
+  const ParamLayout L = make_layout(cfg);
+  const size_t N = (size_t)sh->n_det, E = (size_t)sh->n_edge, B = (size_t)cfg->num_blocks;
+  const size_t Np = N + 32, Ep = E + 64;   // slack for tile tails
+  gnet_buffers b;
+  memset(&b, 0, sizeof(b));
+  Carver c(ws);
+  b.row_ptr = c.take<int32_t>(N + 1);
+  b.edge_c = c.take<int32_t>(Ep);
+  b.edge_n = c.take<int32_t>(Ep);
+  b.edge_iou = c.take<float>(Ep);
+  b.pw_feats = c.take<float>(Ep * D_E);
+  b.packed_t = c.take<float>((size_t)L.total);
+  b.prediction = c.take<float>(Np);
+  b.scratch_i = c.take<int32_t>(N + 1024);
+  if (training) {
+    b.geo = c.take<float>(Ep * 8);
+    b.pw_h1 = c.take<float>(Ep * D_H);
+    b.pw_h2 = c.take<float>(Ep * D_H);
+    b.block_feats[0] = nullptr;
+    for (size_t k = 1; k <= B; ++k) {
+      b.block_feats[k] = c.take<float>(Np * D_S);
+      b.blk_r[k] = c.take<float>(Np * D_R);
+      b.blk_rc[k] = c.take<float>(Np * D_P);
+      b.blk_rn[k] = c.take<float>(Np * D_P);
+      b.blk_pm[k] = c.take<uint64_t>(Np * D_P);
+      b.blk_q[k] = c.take<float>(Np * D_P);
+    }
+    b.head1 = c.take<float>(Np * D_HEAD);
+    b.head2 = c.take<float>(Np * D_HEAD);
+    b.det_anno_iou = c.take<float>((size_t)sh->n_anno + 64);
+    b.labels = c.take<float>(Np);
+    b.weights = c.take<float>(Np);
+    b.det_gt_matching = c.take<int32_t>(Np);
+    b.loss = c.take<float>((size_t)sh->n_img * 2 + 2);
+    b.match_ws_bytes = det_matching_workspace_bytes(sh->n_det, sh->n_gt);
+    b.match_ws = c.take<char>(b.match_ws_bytes);
+    b.d_logits = c.take<float>(Np);
+    b.d_x = c.take<float>(Np * D_S);
+    b.d_pc = c.take<float>(Np * D_P);
+    b.d_rc = c.take<float>(Np * D_P);
+    b.d_rn = c.take<float>(Np * D_P);
+    b.d_pw = c.take<float>(Ep * D_E);
+    b.d_h1 = c.take<float>(Ep * D_H);
+    b.arena_floats = arena_floats(cfg, sh);
+    b.arena = c.take<float>(b.arena_floats);
+  } else {
+    // inference: per-block tensors are transient -> two alternating sets
+    float* xf[2] = {c.take<float>(Np * D_S), c.take<float>(Np * D_S)};
+    float* rc = c.take<float>(Np * D_P);
+    float* rn = c.take<float>(Np * D_P);
+    uint64_t* pm = c.take<uint64_t>(Np * D_P);
+    for (size_t k = 1; k <= B; ++k) {
+      b.block_feats[k] = xf[k & 1];
+      b.blk_rc[k] = rc; b.blk_rn[k] = rn; b.blk_pm[k] = pm;
+    }
+  }
+  if (out) *out = b;
+  return (c.off + 255) & ~(size_t)255;
+}
+
+}  // namespace
+
+extern "C" int64_t gnet_param_count(const gnet_config* cfg) {
+  if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
+  return make_layout(cfg).total;
+}
+
+extern "C" size_t gnet_workspace_bytes(const gnet_config* cfg, const gnet_shape* shape, int training) {
+  if (!config_supported(cfg) || !shape || shape->n_det < 0 || shape->n_edge < 0 || shape->n_img < 1) return 0;
+  return carve(cfg, shape, training, nullptr, nullptr);
+}
+
+extern "C" int gnet_plan(const gnet_config* cfg, const gnet_shape* shape, int training, void* workspace,
+                         size_t workspace_bytes, gnet_buffers* out) {
+  if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
+  if (!shape || !workspace || !out || shape->n_det < 0 || shape->n_edge < 0 || shape->n_img < 1) return GNET_ERR_INVALID;
+  if (((uintptr_t)workspace & 255) != 0) return GNET_ERR_INVALID;
+  const size_t need = carve(cfg, shape, training, nullptr, nullptr);
+  if (workspace_bytes < need) return GNET_ERR_WORKSPACE;
+  carve(cfg, shape, training, workspace, out);
+  return GNET_OK;
+}
+
+extern "C" const char* gnet_version(void) { return "gossipnet_hip 0.1 (gfx950, fp32 MFMA)"; }

@@ -1,0 +1,381 @@
+"""Gnet -- host-side mirror of the reference's nms_net/network.py:121-322 class `Gnet`.
+
+Same constructor, same input names (`get_batch_spec`), same output attribute names
+(`prediction`, `labels`, `weights`, `det_gt_matching`, `det_anno_iou`, `loss`, `loss_normed`,
+`loss_unnormed`, `pw_feats`, `block_feats`, `neighbor_pair_idxs`, `num_dets`, `class_weights`,
+`trainable_variables`), and hyper-parameters taken from the global `cfg` at construction
+(reference: nms_net/config.py).  There is no TF graph: `net.run(batch)` plays the role of
+`sess.run(...)` and fills the attributes.  All arithmetic happens in libgossipnet_hip.so
+(hand-written HIP for gfx950) through the C ABI of include/gossipnet_hip.h; PyTorch only owns
+device memory and streams.  There is no CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import cfg
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def param_spec(num_classes, num_blocks):
+    """TF variable names + shapes in flat-buffer order (include/gossipnet_hip.h)."""
+    cp = num_classes if num_classes > 1 else 1
+    d = 2 * cp + 7
+    g = cfg.gnet
+    spec = []
+    dims = [d, g.pwfeat_dim, g.pwfeat_dim, g.pwfeat_narrow_dim]
+    for i in range(3):
+        spec.append(("gnet/pw_feats/fc%d/weights" % (i + 1), (dims[i], dims[i + 1])))
+        spec.append(("gnet/pw_feats/fc%d/biases" % (i + 1), (dims[i + 1],)))
+    for b in range(1, num_blocks + 1):
+        p = "gnet/block%d/" % b
+        spec += [
+            (p + "reduce_dim/weights", (g.shortcut_dim, g.reduced_dim)), (p + "reduce_dim/biases", (g.reduced_dim,)),
+            (p + "pw_fc1/weights", (g.pwfeat_narrow_dim + 2 * g.reduced_dim, g.pairfeat_dim)),
+            (p + "pw_fc1/biases", (g.pairfeat_dim,)),
+            (p + "pw_fc2/weights", (g.pairfeat_dim, g.pairfeat_dim)), (p + "pw_fc2/biases", (g.pairfeat_dim,)),
+            (p + "fc1/weights", (g.pairfeat_dim, g.pairfeat_dim)), (p + "fc1/biases", (g.pairfeat_dim,)),
+            (p + "fc2/weights", (g.pairfeat_dim, g.shortcut_dim)), (p + "fc2/biases", (g.shortcut_dim,)),
+        ]
+    for i in (1, 2):
+        p = "gnet/predict/fc%d/fully_connected/" % i
+        spec += [(p + "weights", (g.predict_fc_dim, g.predict_fc_dim)), (p + "biases", (g.predict_fc_dim,))]
+    p = "gnet/predict/logits/fully_connected/"
+    spec += [(p + "weights", (g.predict_fc_dim, 1)), (p + "biases", (1,))]
+    return spec
+
+
+class DeviceBatch(object):
+    """One or more images concatenated and resident on the device (block-diagonal batch)."""
+
+    def __init__(self, images, device):
+        if isinstance(images, dict):
+            images = [images]
+        self.n_img = len(images)
+        f32, i32 = np.float32, np.int32
+
+        def cat(key, dtype, shape_tail):
+            parts = [np.asarray(im[key], dtype=dtype).reshape((-1,) + shape_tail) for im in images if key in im]
+            if len(parts) != len(images):
+                return None
+            return np.concatenate(parts, 0) if parts else np.zeros((0,) + shape_tail, dtype)
+
+        dets = cat("dets", f32, (4,))
+        scores = cat("det_scores", f32, ())
+        classes = cat("det_classes", i32, ())
+        if dets is None or scores is None or classes is None:
+            raise _lib.InvalidArgumentError("batch needs dets, det_scores, det_classes")
+        n_per = [np.asarray(im["dets"]).reshape(-1, 4).shape[0] for im in images]
+        if scores.shape[0] != dets.shape[0] or classes.shape[0] != dets.shape[0]:
+            raise _lib.InvalidArgumentError("dets / det_scores / det_classes disagree on the number of detections")
+        self.det_off_h = np.concatenate([[0], np.cumsum(n_per)]).astype(i32)
+        gtb = cat("gt_boxes", f32, (4,))
+        self.has_gt = gtb is not None
+        if self.has_gt:
+            crowd = cat("gt_crowd", np.uint8, ())
+            gcls = cat("gt_classes", i32, ())
+            m_per = [np.asarray(im["gt_boxes"]).reshape(-1, 4).shape[0] for im in images]
+            if crowd is None or gcls is None or crowd.shape[0] != gtb.shape[0] or gcls.shape[0] != gtb.shape[0]:
+                raise _lib.InvalidArgumentError("gt_boxes / gt_crowd / gt_classes disagree")
+        else:
+            gtb = np.zeros((0, 4), f32); crowd = np.zeros(0, np.uint8); gcls = np.zeros(0, i32)
+            m_per = [0] * self.n_img
+        self.gt_off_h = np.concatenate([[0], np.cumsum(m_per)]).astype(i32)
+        self.anno_off_h = np.concatenate([[0], np.cumsum(np.asarray(n_per, np.int64) * np.asarray(m_per, np.int64))]).astype(np.int64)
+        self.n_det, self.n_gt = int(dets.shape[0]), int(gtb.shape[0])
+        self.n_anno = int(self.anno_off_h[-1])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.dets, self.det_scores, self.det_classes = t(dets), t(scores), t(classes)
+        self.gt_boxes, self.gt_crowd, self.gt_classes = t(gtb), t(crowd), t(gcls)
+        self.det_off, self.gt_off, self.anno_off = t(self.det_off_h), t(self.gt_off_h), t(self.anno_off_h)
+
+    def c_inputs(self):
+        a = _lib.gnet_inputs()
+        a.dets, a.det_scores, a.det_classes, a.det_off = _vp(self.dets), _vp(self.det_scores), _vp(self.det_classes), _vp(self.det_off)
+        a.gt_boxes, a.gt_crowd, a.gt_classes = _vp(self.gt_boxes), _vp(self.gt_crowd), _vp(self.gt_classes)
+        a.gt_off, a.anno_off = _vp(self.gt_off), _vp(self.anno_off)
+        return a
+
+
+class Gnet(object):
+    name = 'gnet'
+    dets = None
+    det_scores = None
+    det_classes = None
+    gt_boxes = None
+    gt_crowd = None
+    gt_classes = None
+    image = None
+
+    _scopes = {}   # variable scope 'gnet' -> shared parameter storage (tf.variable_scope(reuse=True))
+
+    @staticmethod
+    def get_batch_spec(num_classes, is_training=True):
+        """network.py:131-146."""
+        spec = {
+            'dets': (torch.float32, [None, 4]),
+            'det_scores': (torch.float32, [None]),
+            'det_classes': (torch.int32, [None]),
+        }
+        if is_training:
+            spec.update({
+                'gt_boxes': (torch.float32, [None, 4]),
+                'gt_crowd': (torch.bool, [None]),
+                'gt_classes': (torch.int32, [None]),
+            })
+        if cfg.gnet.imfeats or cfg.gnet.load_imfeats:
+            spec['image'] = (torch.float32, [None, None, None, 3])
+        return spec
+
+    def __init__(self, num_classes, class_weights=None, batch=None, weight_reg=None, reuse=False,
+                 device=None):
+        self.num_classes = num_classes
+        self.multiclass = num_classes > 1
+        if cfg.gnet.imfeats:
+            raise _lib.GnetError("cfg.gnet.imfeats=True needs the ResNet trunk (out of scope, SURVEY §2 row 12); "
+                                 "the roi_pool op itself is available in gossipnet_amd.roi_pooling_layer")
+        if cfg.gnet.neighbor_feats:
+            raise _lib.GnetError("cfg.gnet.neighbor_feats=True is not compiled")
+        if cfg.gnet.weight_init != 'xavier':
+            raise ValueError('unknown weight init {}'.format(cfg.gnet.weight_init))
+        self._lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:0")
+        g = cfg.gnet
+        self._cfg = _lib.gnet_config(
+            num_classes, g.num_blocks, g.neighbor_thresh, int(bool(cfg.train.normalize_loss)),
+            float(cfg.train.loss_multiplyer), g.shortcut_dim, g.reduced_dim, g.pairfeat_dim, g.pwfeat_dim,
+            g.pwfeat_narrow_dim, g.num_pwfeat_fc, g.predict_fc_dim, g.num_predict_fc, g.num_block_pw_fc,
+            g.num_block_fc)
+        n = self._lib.gnet_param_count(C.byref(self._cfg))
+        if n < 0:
+            _lib.check(int(n), "gnet_param_count")
+        self.num_blocks = g.num_blocks
+        self._spec = param_spec(num_classes, g.num_blocks)
+        assert sum(int(np.prod(s)) for _, s in self._spec) == n
+        key = (self.name, num_classes, g.num_blocks, str(self.device))
+        if reuse:
+            if key not in Gnet._scopes:
+                raise ValueError("Variable scope gnet does not exist, cannot reuse")
+            self.params = Gnet._scopes[key]
+        else:
+            self.params = self._init_params(n)
+            Gnet._scopes[key] = self.params
+        self.grads = torch.zeros_like(self.params)
+        self.variables = {}
+        self.gradients = {}
+        reg = torch.zeros(n, dtype=torch.float32)
+        off = 0
+        for nm, shape in self._spec:
+            k = int(np.prod(shape))
+            self.variables[nm] = self.params[off:off + k].view(*shape)
+            self.gradients[nm] = self.grads[off:off + k].view(*shape)
+            # l2 regulariser sites: every `weights_regularizer=weight_reg` (network.py:332-403), not predict/*
+            if nm.endswith("weights") and "/predict/" not in nm:
+                reg[off:off + k] = 1.0
+            off += k
+        self._reg_mask = reg.to(self.device)
+        self.trainable_variables = [self.variables[nm] for nm, _ in self._spec]   # network.py:317-322
+        self.weight_reg = weight_reg                       # l2 scale (tf l2_regularizer(scale): scale*sum(w^2)/2)
+        if class_weights is None:
+            class_weights = np.ones((num_classes + 1), dtype=np.float32)           # network.py:282-284
+        self.class_weights = torch.as_tensor(np.asarray(class_weights, dtype=np.float32)).to(self.device)
+        if self.class_weights.numel() != num_classes + 1:
+            raise _lib.InvalidArgumentError("class_weights must have num_classes + 1 entries")
+        self._ws = None
+        self._buf = None
+        self._shape = None
+        self._row_ptr_tmp = None
+        self._scratch_tmp = None
+        self.grad_scale = 1.0
+        self._batch = batch
+        if batch is not None:
+            self.feed(batch)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_params(self, n):
+        """xavier-uniform, seed cfg.random_seed (network.py:203-205); biases const (network.py:215)."""
+        gen = torch.Generator().manual_seed(int(cfg.random_seed))
+        flat = torch.empty(n, dtype=torch.float32)
+        off = 0
+        for nm, shape in self._spec:
+            k = int(np.prod(shape))
+            if nm.endswith("weights"):
+                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                flat[off:off + k] = ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).reshape(-1)
+            else:
+                flat[off:off + k] = float(cfg.gnet.bias_const_init)
+            off += k
+        return flat.to(self.device)
+
+    def load_params(self, named):
+        """Assign variables by TF name (e.g. from a converted checkpoint)."""
+        for nm, _ in self._spec:
+            if nm in named:
+                self.variables[nm].copy_(torch.as_tensor(np.asarray(named[nm], dtype=np.float32)).to(self.device))
+
+    def state_dict(self):
+        return {nm: self.variables[nm].detach().cpu().numpy().copy() for nm, _ in self._spec}
+
+    # ------------------------------------------------------------------ feeding / running
+    def feed(self, batch):
+        """Plays the role of feed_dict / the preloaded batch (network.py:154-160)."""
+        db = batch if isinstance(batch, DeviceBatch) else DeviceBatch(batch, self.device)
+        self._dbatch = db
+        self.dets, self.det_scores, self.det_classes = db.dets, db.det_scores, db.det_classes
+        self.gt_boxes, self.gt_crowd, self.gt_classes = db.gt_boxes, db.gt_crowd.bool(), db.gt_classes
+        self.num_dets = db.n_det
+        return db
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _view(self, ptr, count, dtype):
+        if not ptr:
+            return None
+        esz = torch.empty(0, dtype=dtype).element_size()
+        off = ptr - self._ws.data_ptr()
+        return self._ws[off:off + count * esz].view(dtype)
+
+    def _build_graph(self, db, training):
+        lib, s = self._lib, self._stream()
+        N = db.n_det
+        if self._row_ptr_tmp is None or self._row_ptr_tmp.numel() < N + 1:
+            self._row_ptr_tmp = torch.empty(N + 1, dtype=torch.int32, device=self.device)
+            self._scratch_tmp = torch.empty(N + 1024, dtype=torch.int32, device=self.device)
+        thr = float(cfg.gnet.neighbor_thresh)
+        _lib.check(lib.gnet_graph_count(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, _vp(self._row_ptr_tmp),
+                                        _vp(self._scratch_tmp), s), "gnet_graph_count")
+        E = int(self._row_ptr_tmp[N].item()) if N > 0 else 0     # the one host sync of a step
+        shape = _lib.gnet_shape(db.n_img, N, db.n_gt, E, db.n_anno)
+        need = lib.gnet_workspace_bytes(C.byref(self._cfg), C.byref(shape), int(training))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+        buf = _lib.gnet_buffers()
+        _lib.check(lib.gnet_plan(C.byref(self._cfg), C.byref(shape), int(training), _vp(self._ws), self._ws.numel(),
+                                 C.byref(buf)), "gnet_plan")
+        self._buf, self._shape, self._training = buf, shape, training
+        self._view(buf.row_ptr, N + 1, torch.int32).copy_(self._row_ptr_tmp[:N + 1])
+        _lib.check(lib.gnet_graph_fill(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr, buf.edge_c,
+                                       buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
+        self.num_edges = E
+        return shape, buf
+
+    def run(self, batch=None, training=None, backward=None):
+        """One evaluation of the graph = the reference's sess.run.  training=None -> GT present."""
+        db = self.feed(batch) if batch is not None else self._dbatch
+        if training is None:
+            training = db.has_gt
+        if backward is None:
+            backward = training
+        if training and not db.has_gt:
+            raise _lib.InvalidArgumentError("training needs gt_boxes / gt_crowd / gt_classes")
+        lib, s = self._lib, self._stream()
+        shape, buf = self._build_graph(db, training)
+        inp = db.c_inputs()
+        self._inputs = inp
+        _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
+                                    C.byref(buf), int(training), s), "gnet_forward")
+        if training:
+            _lib.check(lib.gnet_loss(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.class_weights),
+                                     float(self.grad_scale), C.byref(buf), s), "gnet_loss")
+            if backward:
+                _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
+                                             C.byref(buf), _vp(self.grads), s), "gnet_backward")
+                if self.weight_reg:
+                    # slim get_total_loss adds sum(l2_regularizer(scale)(w)) -> d/dw = scale * w (train.py:231-238)
+                    self.grads.addcmul_(self.params, self._reg_mask, value=float(self.weight_reg) * float(self.grad_scale))
+        return self
+
+    # ------------------------------------------------------------------ outputs (Gnet attributes)
+    @property
+    def prediction(self):
+        return self._view(self._buf.prediction, self._shape.n_det, torch.float32)
+
+    @property
+    def labels(self):
+        return self._view(self._buf.labels, self._shape.n_det, torch.float32)
+
+    @property
+    def weights(self):
+        return self._view(self._buf.weights, self._shape.n_det, torch.float32)
+
+    @property
+    def det_gt_matching(self):
+        return self._view(self._buf.det_gt_matching, self._shape.n_det, torch.int32)
+
+    @property
+    def det_anno_iou(self):
+        db = self._dbatch
+        flat = self._view(self._buf.det_anno_iou, max(self._shape.n_anno, 0), torch.float32)
+        outs = []
+        for i in range(db.n_img):
+            n = int(db.det_off_h[i + 1] - db.det_off_h[i]); m = int(db.gt_off_h[i + 1] - db.gt_off_h[i])
+            outs.append(flat[int(db.anno_off_h[i]):int(db.anno_off_h[i + 1])].view(n, m))
+        return outs[0] if db.n_img == 1 else outs
+
+    @property
+    def image_losses(self):
+        """[n_img, 2]: (loss_unnormed, loss_normed) of every image of the batch."""
+        return self._view(self._buf.loss, 2 * self._shape.n_img, torch.float32).view(-1, 2)
+
+    @property
+    def loss_unnormed(self):
+        return self.image_losses[:, 0].sum()
+
+    @property
+    def loss_normed(self):
+        return self.image_losses[:, 1].sum()
+
+    @property
+    def loss(self):
+        l = self.loss_normed if cfg.train.normalize_loss else self.loss_unnormed
+        return l * float(cfg.train.loss_multiplyer)
+
+    def regularization_loss(self):
+        if not self.weight_reg:
+            return torch.zeros((), device=self.device)
+        return 0.5 * float(self.weight_reg) * (self.params * self.params * self._reg_mask).sum()
+
+    @property
+    def pw_feats(self):
+        return self._view(self._buf.pw_feats, self._shape.n_edge * 32, torch.float32).view(-1, 32)
+
+    @property
+    def block_feats(self):
+        N = self._shape.n_det
+        out = [torch.zeros(N, 128, device=self.device)]
+        if not self._training:
+            out += [None] * (self.num_blocks - 1)
+            out.append(self._view(self._buf.block_feats[self.num_blocks], N * 128, torch.float32).view(N, 128))
+            return out
+        for k in range(1, self.num_blocks + 1):
+            out.append(self._view(self._buf.block_feats[k], N * 128, torch.float32).view(N, 128))
+        return out
+
+    @property
+    def neighbor_pair_idxs(self):
+        E = self._shape.n_edge
+        c = self._view(self._buf.edge_c, E, torch.int32)
+        n = self._view(self._buf.edge_n, E, torch.int32)
+        return torch.stack([c, n], 1).long()
+
+    @property
+    def edge_iou(self):
+        return self._view(self._buf.edge_iou, self._shape.n_edge, torch.float32)
+
+    @property
+    def row_ptr(self):
+        return self._view(self._buf.row_ptr, self._shape.n_det + 1, torch.int32)
+
+    def debug_view(self, name, count, dtype=torch.float32, index=None):
+        p = getattr(self._buf, name)
+        if index is not None:
+            p = p[index]
+        return self._view(p, count, dtype)

@@ -1,0 +1,188 @@
+/* gossipnet_hip.h -- C ABI of libgossipnet_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the GossipNet hot path.  Every entry point replaces a
+ * reference interface (paths relative to the reference repo root):
+ *
+ *   gnet_*                 nms_net/network.py:121-322  class Gnet (graph build,
+ *                          pairwise features, pw-MLP, _block stack, head, loss,
+ *                          and TF autodiff of those = gnet_backward)
+ *   det_matching_f32       nms_net/matching_module/det_matching.cc:16-33,72-165
+ *                          (op "DetectionMatching", loaded at matching_module/__init__.py:9-13)
+ *   roi_pool_fwd_f32       nms_net/roi_pooling_layer/roi_pooling_op.cc:35-43,79-195
+ *                          (op "RoiPool";  GPU twin roi_pooling_op_gpu.cu:19-110)
+ *   roi_pool_bwd_f32       nms_net/roi_pooling_layer/roi_pooling_op.cc:45-54,324-457
+ *                          (op "RoiPoolGrad"; GPU twin roi_pooling_op_gpu.cu:113-215)
+ *
+ * Conventions: plain C, raw DEVICE pointers + explicit sizes, caller-owned
+ * buffers and workspace (query the size first), the HIP stream is passed in as
+ * an opaque pointer (hipStream_t), every call returns an int status (0 = ok)
+ * and never exits the process (unlike roi_pooling_op_gpu.cu:102-107), no global
+ * mutable state, re-entrant per stream.  All tensors are dense row-major fp32
+ * unless stated.  Indices are int32.
+ */
+#ifndef GOSSIPNET_HIP_H
+#define GOSSIPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNET_OK 0
+#define GNET_ERR_INVALID (-1)     /* bad argument (the TF ops raise InvalidArgument)      */
+#define GNET_ERR_UNSUPPORTED (-2) /* a hyper-parameter outside the compiled configuration */
+#define GNET_ERR_WORKSPACE (-3)   /* workspace too small                                  */
+#define GNET_ERR_HIP (-4)         /* a HIP runtime call or launch failed                  */
+
+typedef void* gnet_stream_t; /* hipStream_t */
+
+/* Hyper-parameters: the cfg.gnet.* / cfg.train.* values Gnet reads at construction
+ * (nms_net/config.py:46-79, experiments/<exp>/conf.yaml).  Only the configuration of the two
+ * shipped experiments is compiled: shortcut 128, reduced 32, pairfeat 64,
+ * pwfeat 256, pwfeat_narrow 32, num_pwfeat_fc 3, predict_fc 128, num_predict_fc 3,
+ * num_block_pw_fc 2, num_block_fc 2, neighbor_feats False, imfeats False. */
+typedef struct gnet_config {
+  int32_t num_classes;     /* C; multiclass = C > 1 (network.py:151)            */
+  int32_t num_blocks;      /* cfg.gnet.num_blocks                                */
+  float neighbor_thresh;   /* cfg.gnet.neighbor_thresh (0.2)                     */
+  int32_t normalize_loss;  /* cfg.train.normalize_loss                           */
+  float loss_multiplyer;   /* cfg.train.loss_multiplyer                          */
+  int32_t shortcut_dim, reduced_dim, pairfeat_dim, pwfeat_dim, pwfeat_narrow_dim;
+  int32_t num_pwfeat_fc, predict_fc_dim, num_predict_fc, num_block_pw_fc, num_block_fc;
+} gnet_config;
+
+/* Sizes of one batch: n_img images concatenated (the reference runs n_img = 1,
+ * train.py:115; a batch is a block-diagonal graph, images never interact).
+ * n_anno = sum_i n_det_i * n_gt_i (ragged det_anno_iou). */
+typedef struct gnet_shape {
+  int32_t n_img, n_det, n_gt;
+  int64_t n_edge;
+  int64_t n_anno;
+} gnet_shape;
+
+/* Inputs = Gnet.get_batch_spec (network.py:131-146), concatenated over images. */
+typedef struct gnet_inputs {
+  const float* dets;          /* [n_det,4] xyxy                        */
+  const float* det_scores;    /* [n_det]                               */
+  const int32_t* det_classes; /* [n_det] 1-based                       */
+  const int32_t* det_off;     /* [n_img+1] first detection of image i  */
+  const float* gt_boxes;      /* [n_gt,4]   (training; may be NULL)    */
+  const uint8_t* gt_crowd;    /* [n_gt] bool                           */
+  const int32_t* gt_classes;  /* [n_gt]                                */
+  const int32_t* gt_off;      /* [n_img+1]                             */
+  const int64_t* anno_off;    /* [n_img+1] offset of image i in det_anno_iou */
+} gnet_inputs;
+
+#define GNET_MAX_BLOCKS 64
+
+/* Device pointers carved out of the caller's workspace by gnet_plan().  These are
+ * the tensors the reference exposes as Gnet attributes (network.py:170-313) plus
+ * what the backward pass re-reads. */
+typedef struct gnet_buffers {
+  /* graph (network.py:192-195): CSR of neighbor_pair_idxs, row-major order */
+  int32_t* row_ptr;   /* [n_det+1]                     */
+  int32_t* edge_c;    /* [n_edge] pair_c_idxs          */
+  int32_t* edge_n;    /* [n_edge] pair_n_idxs          */
+  float* edge_iou;    /* [n_edge] det_det_iou at pairs */
+  float* geo;         /* [n_edge,8] 7 geometry columns of _geometry_feats (+pad) */
+  float* pw_h1;       /* [n_edge,256]  pw_feats/fc1 output (training)            */
+  float* pw_h2;       /* [n_edge,256]  pw_feats/fc2 output (training)            */
+  float* pw_feats;    /* [n_edge,32]   Gnet.pw_feats                             */
+  float* block_feats[GNET_MAX_BLOCKS + 1]; /* [n_det,128] each; [0] = zeros      */
+  float* blk_r[GNET_MAX_BLOCKS + 1];       /* [n_det,32]  relu(reduce_dim)        */
+  float* blk_rc[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[32:64] + b1        */
+  float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[64:96]             */
+  uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count */
+  float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
+  float* head1;       /* [n_det,128] predict/fc1 */
+  float* head2;       /* [n_det,128] predict/fc2 */
+  float* prediction;  /* [n_det] logits (Gnet.prediction) */
+  /* loss (network.py:275-313) */
+  float* det_anno_iou;      /* [n_anno] ragged [n_det_i, n_gt_i] per image */
+  float* labels;            /* [n_det] */
+  float* weights;           /* [n_det] after class weighting */
+  int32_t* det_gt_matching; /* [n_det] */
+  float* loss;              /* [n_img,2]: (loss_unnormed, loss_normed) per image */
+  /* backward scratch */
+  float* d_logits;    /* [n_det] */
+  float* d_x;         /* [n_det,128] */
+  float* d_pc;        /* [n_det,64]  dp / tie count */
+  float* d_rc;        /* [n_det,64] */
+  float* d_rn;        /* [n_det,64] */
+  float* d_pw;        /* [n_edge,32] grad wrt pw_feats */
+  float* d_h1;        /* [n_edge,256] grad wrt pre-activation of pw_feats/fc1 */
+  float* packed_t;    /* [param_count] transposed copies of the weight matrices */
+  float* arena;       /* per-workgroup partial weight gradients */
+  int32_t* scratch_i; /* [n_det + 1024] */
+  void* match_ws;     /* det_matching_workspace_bytes(n_det, n_gt) */
+  size_t match_ws_bytes;
+  size_t arena_floats;
+} gnet_buffers;
+
+/* ---- parameters ------------------------------------------------------------
+ * One flat fp32 buffer in TF-variable order, weights [in,out]:
+ *   gnet/pw_feats/fc{1,2,3}/{weights,biases}
+ *   gnet/block{k}/{reduce_dim,pw_fc1,pw_fc2,fc1,fc2}/{weights,biases}   k = 1..B
+ *   gnet/predict/fc{1,2}/fully_connected/{weights,biases}
+ *   gnet/predict/logits/fully_connected/{weights,biases}
+ * gnet_param_count returns <0 on an unsupported config. */
+int64_t gnet_param_count(const gnet_config* cfg);
+
+/* ---- graph build (network.py:170-176,192-195) --------------------------------
+ * Pass 1: per-row neighbour counts + exclusive scan -> row_ptr[n_det+1]
+ * (row_ptr[n_det] = n_edge, read it back to size the edge buffers).
+ * scratch: at least (n_det + 1024) int32. */
+int gnet_graph_count(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
+                     float thresh, int32_t* row_ptr, int32_t* scratch, gnet_stream_t stream);
+/* Pass 2: ordered fill of edge_c / edge_n / edge_iou (row-major = tf.where order). */
+int gnet_graph_fill(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
+                    float thresh, const int32_t* row_ptr, int32_t* edge_c, int32_t* edge_n,
+                    float* edge_iou, gnet_stream_t stream);
+
+/* ---- workspace ----------------------------------------------------------------- */
+size_t gnet_workspace_bytes(const gnet_config* cfg, const gnet_shape* shape, int training);
+int gnet_plan(const gnet_config* cfg, const gnet_shape* shape, int training, void* workspace,
+              size_t workspace_bytes, gnet_buffers* out);
+
+/* ---- forward: features + pw-MLP + blocks + head -> buf->prediction
+ * (network.py:197-273).  buf->row_ptr/edge_* must have been filled. */
+int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                 const float* params, gnet_buffers* buf, int training, gnet_stream_t stream);
+
+/* ---- loss: det_anno_iou, detection_matching, class weighting, sigmoid x-ent
+ * (network.py:174-187,275-313); also seeds d_logits = grad_scale * dloss/dlogit.
+ * class_weights: [num_classes+1] device, or NULL for ones (network.py:282-284). */
+int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+              const float* class_weights, float grad_scale, gnet_buffers* buf, gnet_stream_t stream);
+
+/* ---- backward: d loss / d params -> grads[param_count] (overwritten). */
+int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                  const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream);
+
+/* ---- DetectionMatching (det_matching.cc:72-160).  iou [n_det,n_gt], score [n_det],
+ * ignore [n_gt] (bool as u8) -> labels, weights (f32 [n_det]), assignment (i32 [n_det]).
+ * Ties in score: higher index first; equal ignore flags: lower index first.
+ * workspace: det_matching_workspace_bytes(n_det, n_gt). */
+size_t det_matching_workspace_bytes(int32_t n_det, int32_t n_gt);
+int det_matching_f32(const float* iou, const float* score, const uint8_t* ignore, int32_t n_det,
+                     int32_t n_gt, float* labels, float* weights, int32_t* assignment,
+                     void* workspace, size_t workspace_bytes, gnet_stream_t stream);
+
+/* ---- RoiPool / RoiPoolGrad, NHWC, argmax = index within the image
+ * (roi_pooling_op.cc:128-187, 374-449).  rois [R,5] = (batch, x1, y1, x2, y2). */
+int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, int32_t W, int32_t C,
+                     const float* bottom_rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
+                     float spatial_scale, float* top_data, int32_t* argmax, gnet_stream_t stream);
+int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, const float* bottom_rois,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h,
+                     int32_t pooled_w, float spatial_scale, float* bottom_diff, gnet_stream_t stream);
+
+/* Version / build info string (static storage). */
+const char* gnet_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOSSIPNET_HIP_H */

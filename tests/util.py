@@ -1,0 +1,26 @@
+import numpy as np
+import torch
+
+from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.synthetic import make_image
+from oracle import gnet_oracle as go
+
+
+def make_pair(num_classes, num_blocks, seed_params=42, class_weights=None, normalize_loss=False, bias=0.01):
+    """(Gnet on cuda:0, GnetOracle) sharing the same parameters."""
+    from gossipnet_amd.network import Gnet
+    reset_cfg()
+    cfg.gnet.num_blocks = num_blocks
+    cfg.gnet.bias_const_init = bias
+    cfg.train.normalize_loss = normalize_loss
+    params = go.init_params(num_classes, num_blocks, seed=seed_params, bias_init=bias)
+    net = Gnet(num_classes, class_weights=class_weights)
+    net.load_params(params)
+    orc = go.GnetOracle(num_classes, num_blocks, params=params, class_weights=class_weights,
+                        normalize_loss=normalize_loss)
+    return net, orc
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b))))) if a.size else 0.0
