@@ -45,18 +45,22 @@ _PB = C.c_void_p * (GNET_MAX_BLOCKS + 1)
 
 
 class gnet_buffers(C.Structure):
-    _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "geo", "pw_h1", "pw_h2",
+    _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "edge_t", "geo", "pw_h1", "pw_h2",
                                            "pw_feats")] +
                 [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q")] +
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
                                            "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
-                                           "d_pw", "d_h1", "packed_t", "arena", "scratch_i", "match_ws")] +
-                [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t)])
+                                           "d_pw", "d_h1", "d_g1", "packed_t", "arena", "scratch_i", "match_ws")] +
+                [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t), ("profiler", C.c_void_p)])
 
 
-EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_workspace_bytes", "gnet_plan",
+EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_graph_transpose", "gnet_workspace_bytes", "gnet_plan",
            "gnet_forward", "gnet_loss", "gnet_backward", "det_matching_workspace_bytes", "det_matching_f32",
-           "roi_pool_fwd_f32", "roi_pool_bwd_f32", "gnet_version"]
+           "roi_pool_fwd_f32", "roi_pool_bwd_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
+           "gnet_profiler_destroy"]
+
+KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "blk_bwd_post", "edge_bwd", "blk_bwd_pre",
+            "pw_bwd_main", "pw_bwd_w1", "reduce_partials"]
 
 _lib = None
 
@@ -69,6 +73,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GnetError("libgossipnet_hip.so is missing (%s): build it with "
                         "`python -m gossipnet_amd.build` -- there is no CPU fallback" % LIB_PATH)
+    # torch bundles its own HIP runtime: it must be mapped first so that this library binds to the
+    # same libamdhip64 as the streams/allocations it is handed (loading /opt/rocm's copy first breaks launches)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     P = C.POINTER
@@ -78,6 +85,8 @@ def load():
     lib.gnet_graph_count.argtypes = [vp, i32, vp, i32, f32, vp, vp, vp]
     lib.gnet_graph_fill.restype = C.c_int
     lib.gnet_graph_fill.argtypes = [vp, i32, vp, i32, f32, vp, vp, vp, vp, vp]
+    lib.gnet_graph_transpose.restype = C.c_int
+    lib.gnet_graph_transpose.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.gnet_workspace_bytes.restype = sz
     lib.gnet_workspace_bytes.argtypes = [P(gnet_config), P(gnet_shape), C.c_int]
     lib.gnet_plan.restype = C.c_int
@@ -96,6 +105,12 @@ def load():
     lib.roi_pool_fwd_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, i32, f32, vp, vp, vp]
     lib.roi_pool_bwd_f32.restype = C.c_int
     lib.roi_pool_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+    lib.gnet_profiler_create.restype = C.c_int
+    lib.gnet_profiler_create.argtypes = [i32, C.c_uint32, P(vp)]
+    lib.gnet_profiler_read.restype = C.c_int
+    lib.gnet_profiler_read.argtypes = [vp, P(C.c_double), P(i32)]
+    lib.gnet_profiler_destroy.restype = C.c_int
+    lib.gnet_profiler_destroy.argtypes = [vp]
     lib.gnet_version.restype = C.c_char_p
     lib.gnet_version.argtypes = []
     _lib = lib

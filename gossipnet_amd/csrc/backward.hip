@@ -1,7 +1,827 @@
-// placeholder until the backward kernels land
+// Backward pass of Gnet: the gradient of network.py:197-313 w.r.t. every trainable variable
+// (what TF autodiff produces for train.py:64-77), hand-written for gfx950.
+//
+// Semantics restated from TensorFlow: ReLU grad = g * (out > 0);
+// SegmentMax grad splits evenly among ties: sel = (h2 == p[c]), dh2 = sel ? (dp / cnt)[c] : 0;
+// gather grads are segment sums (centre, sorted) and scatter-adds (neighbour).  No gradient flows
+// into the geometry features (stop_gradient, network.py:454), the matching, or the boxes.
+//
+// Kernels (launch order):
+//   head_bwd       predict/logits, fc2, fc1                       -> d_x (grad wrt block_feats[B])
+//   per block b = B..1:
+//     blk_bwd_post  shortcut ReLU, fc2, fc1                       -> d_x := dz, d_pc = dp / tie count
+//     edge_bwd      recompute h1,h2; pw_fc2, pw_fc1               -> d_pw (+=), d_g1
+//     gather_sums   centre segment sums / neighbour reversed-edge sums of d_g1 -> d_rc, d_rn
+//     blk_bwd_pre   per-node halves of pw_fc1, reduce_dim         -> d_x := dz + drpre . Wr^T
+//   pw_bwd_main    pw_feats fc3, fc2 (+ d_h1 = grad wrt fc1 pre-activation)
+//   pw_bwd_w1      pw_feats fc1 (one-hot x score structure + 7 geometry rows)
+//   reduce_partials  sums the per-workgroup partial weight gradients in a fixed order
+// Weight gradients are accumulated in MFMA accumulators across a workgroup's tiles and written once
+// per workgroup to an arena; reduce_partials adds them in index order.  There are no float atomics:
+// every sum has a fixed order, so gradients are reproducible run to run.
 #include "common.hpp"
+
+namespace {
+
+constexpr int LD32 = D_E + 4;    // 36
+constexpr int LD64 = D_P + 4;    // 68
+constexpr int LD128 = D_S + 4;   // 132
+constexpr int LD256 = D_H + 4;   // 260
+
+template <int W, int LD>
+__device__ __forceinline__ void load_tile(float* s, const float* __restrict__ g, long long row0, long long nrows,
+                                          int tid, int nthreads) {
+  constexpr int W4 = W / 4;
+  for (int i = tid; i < 32 * W4; i += nthreads) {
+    const int row = i / W4, c4 = i - row * W4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows) v = *reinterpret_cast<const float4*>(g + (size_t)(row0 + row) * W + 4 * c4);
+    *reinterpret_cast<float4*>(s + row * LD + 4 * c4) = v;
+  }
+}
+
+__device__ __forceinline__ float col_sum32(const float* s, int ld, int col) {
+  float v = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < 32; ++r) v += s[r * ld + col];
+  return v;
+}
+
+// write one 32x32 accumulator tile (C layout) to a row-major destination
+__device__ __forceinline__ void store_acc(float* dst, int ld, const f32x16& acc, int lane) {
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[(size_t)crow(r, half) * ld + col] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------
+struct HeadBwdArgs {
+  int n_det;
+  const float* d_logits; const float* head2; const float* head1; const float* xb;
+  const float* hw1; const float* hw2; const float* hwl;   // natural layouts
+  float* d_x;
+  float* arena; long long stride;                          // arena row stride = total params
+  long long o_hw1, o_hb1, o_hw2, o_hb2, o_hwl, o_hbl;
+};
+
+__global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sH2[32 * LD128];
+  __shared__ __attribute__((aligned(16))) float sH1[32 * LD128];
+  __shared__ __attribute__((aligned(16))) float sX[32 * LD128];
+  __shared__ __attribute__((aligned(16))) float sD2[32 * LD128];
+  __shared__ __attribute__((aligned(16))) float sD1[32 * LD128];
+  __shared__ float sDl[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 aW2[1][4], aW1[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { aW2[0][j] = zero16(); aW1[0][j] = zero16(); }
+  float gwl = 0.f, gb2 = 0.f, gb1 = 0.f, gbl = 0.f;
+  const int ntiles = (a.n_det + 31) / 32;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int row0 = t * 32;
+    __syncthreads();
+    load_tile<D_HEAD, LD128>(sH2, a.head2, row0, a.n_det, tid, 256);
+    load_tile<D_HEAD, LD128>(sH1, a.head1, row0, a.n_det, tid, 256);
+    load_tile<D_S, LD128>(sX, a.xb, row0, a.n_det, tid, 256);
+    if (tid < 32) sDl[tid] = (row0 + tid < a.n_det) ? a.d_logits[row0 + tid] : 0.f;
+    __syncthreads();
+    // d head2 = dl (outer) wl
+    for (int i = tid; i < 32 * D_HEAD; i += 256) {
+      const int row = i >> 7, j = i & 127;
+      sD2[row * LD128 + j] = sDl[row] * a.hwl[j];
+    }
+    if (tid < D_HEAD) {
+      float v = 0.f;
+      for (int r = 0; r < 32; ++r) v = fmaf(sH2[r * LD128 + tid], sDl[r], v);
+      gwl += v;
+    }
+    if (tid == 0) { float v = 0.f; for (int r = 0; r < 32; ++r) v += sDl[r]; gbl += v; }
+    __syncthreads();
+    mma_xty<1, 4>(aW2, sH1 + 32 * wave, LD128, sD2, LD128, lane);           // d W(fc2) += head1^T . d head2
+    if (tid < D_HEAD) gb2 += col_sum32(sD2, LD128, tid);
+    {
+      f32x16 acc = zero16();                                                // d head1 = d head2 . W2^T
+      mma_abt<D_HEAD>(acc, sD2, LD128, a.hw2 + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sD1[crow(r, half) * LD128 + 32 * wave + col] = acc[r];
+    }
+    __syncthreads();
+    mma_xty<1, 4>(aW1, sX + 32 * wave, LD128, sD1, LD128, lane);            // d W(fc1) += x^T . d head1
+    if (tid < D_HEAD) gb1 += col_sum32(sD1, LD128, tid);
+    {
+      f32x16 acc = zero16();                                                // d x = d head1 . W1^T
+      mma_abt<D_HEAD>(acc, sD1, LD128, a.hw1 + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int node = row0 + crow(r, half);
+        if (node < a.n_det) a.d_x[(size_t)node * D_S + 32 * wave + col] = acc[r];
+      }
+    }
+  }
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    store_acc(ar + a.o_hw2 + (size_t)(32 * wave) * D_HEAD + 32 * j, D_HEAD, aW2[0][j], lane);
+    store_acc(ar + a.o_hw1 + (size_t)(32 * wave) * D_HEAD + 32 * j, D_HEAD, aW1[0][j], lane);
+  }
+  if (tid < D_HEAD) { ar[a.o_hwl + tid] = gwl; ar[a.o_hb2 + tid] = gb2; ar[a.o_hb1 + tid] = gb1; }
+  if (tid == 0) ar[a.o_hbl] = gbl;
+}
+
+// ------------------------------------------------------------------------------------------
+struct BlkPostArgs {
+  int n_det;
+  float* d_x;                       // in: grad wrt block output; out: dz = d_x * (x_out > 0)
+  const float* x_out; const float* q; const unsigned long long* pm;
+  const float* w4; const float* w3; // natural [64,128], [64,64]
+  float* d_pc;
+  float* arena; long long stride;
+  long long o_w4, o_b4, o_w3, o_b3;
+};
+
+__global__ void __launch_bounds__(256) blk_bwd_post(const BlkPostArgs a) {
+  __shared__ __attribute__((aligned(16))) float sDz[32 * LD128];
+  __shared__ __attribute__((aligned(16))) float sQ[32 * LD64];
+  __shared__ __attribute__((aligned(16))) float sP[32 * LD64];
+  __shared__ __attribute__((aligned(16))) float sDq[32 * LD64];
+  __shared__ __attribute__((aligned(16))) float sR[2 * 32 * D_P];   // K-half partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 aW4[2][1], aW3[1][1];
+  aW4[0][0] = zero16(); aW4[1][0] = zero16(); aW3[0][0] = zero16();
+  float gb4 = 0.f, gb3 = 0.f;
+  const int ntiles = (a.n_det + 31) / 32;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int row0 = t * 32;
+    __syncthreads();
+    for (int i = tid; i < 32 * (D_S / 4); i += 256) {
+      const int row = i >> 5, c4 = i & 31;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + row < a.n_det) {
+        const size_t o = (size_t)(row0 + row) * D_S + 4 * c4;
+        const float4 g = *reinterpret_cast<const float4*>(a.d_x + o);
+        const float4 x = *reinterpret_cast<const float4*>(a.x_out + o);
+        v = make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f);
+        *reinterpret_cast<float4*>(a.d_x + o) = v;      // dz: also the shortcut gradient
+      }
+      *reinterpret_cast<float4*>(sDz + row * LD128 + 4 * c4) = v;
+    }
+    load_tile<D_P, LD64>(sQ, a.q, row0, a.n_det, tid, 256);
+    for (int i = tid; i < 32 * D_P; i += 256) {
+      const int row = i >> 6, ff = i & 63;
+      float v = 0.f;
+      if (row0 + row < a.n_det) {
+        const size_t o = (size_t)(row0 + row) * D_P + ff;
+        v = __uint_as_float((unsigned)(a.pm[o] >> 32));
+      }
+      sP[row * LD64 + ff] = v;
+    }
+    __syncthreads();
+    // d W4 += q^T . dz : wave w owns output column tile w
+    {
+      f32x16 (&acc)[2][1] = aW4;
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + h;
+        const float x0 = sQ[row * LD64 + r], x1 = sQ[row * LD64 + 32 + r];
+        const float y = sDz[row * LD128 + 32 * wave + r];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, acc[1][0], 0, 0, 0);
+      }
+    }
+    if (tid < D_S) gb4 += col_sum32(sDz, LD128, tid);
+    // dq = (dz . W4^T) * (q > 0): wave = (column tile, K half)
+    {
+      const int nt = wave & 1, kh = wave >> 1;
+      f32x16 acc = zero16();
+      mma_abt<64>(acc, sDz + 64 * kh, LD128, a.w4 + (size_t)(32 * nt) * D_S + 64 * kh, D_S, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * D_P; i += 256) {
+      const int row = i >> 6, ff = i & 63;
+      const float v = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
+      sDq[row * LD64 + ff] = sQ[row * LD64 + ff] > 0.f ? v : 0.f;
+    }
+    __syncthreads();
+    // d W3 += p^T . dq : wave = (mi, nj)
+    {
+      const int mi = wave >> 1, nj = wave & 1;
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + h;
+        aW3[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[row * LD64 + 32 * mi + r], sDq[row * LD64 + 32 * nj + r],
+                                                         aW3[0][0], 0, 0, 0);
+      }
+    }
+    if (tid < D_P) gb3 += col_sum32(sDq, LD64, tid);
+    // dp = dq . W3^T : wave = (column tile, K half)
+    {
+      const int nt = wave & 1, kh = wave >> 1;
+      f32x16 acc = zero16();
+      mma_abt<32>(acc, sDq + 32 * kh, LD64, a.w3 + (size_t)(32 * nt) * D_P + 32 * kh, D_P, lane);
+      __syncthreads();   // sR of the dq step fully consumed
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * D_P; i += 256) {
+      const int row = i >> 6, ff = i & 63;
+      if (row0 + row < a.n_det) {
+        const size_t o = (size_t)(row0 + row) * D_P + ff;
+        const float dp = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
+        const unsigned cnt = (unsigned)(a.pm[o] & 0xffffffffull);
+        a.d_pc[o] = dp / (float)cnt;                     // weighted_grads = grad / num_selected
+      }
+    }
+  }
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  store_acc(ar + a.o_w4 + 32 * wave, D_S, aW4[0][0], lane);
+  store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * wave, D_S, aW4[1][0], lane);
+  store_acc(ar + a.o_w3 + (size_t)(32 * (wave >> 1)) * D_P + 32 * (wave & 1), D_P, aW3[0][0], lane);
+  if (tid < D_S) ar[a.o_b4 + tid] = gb4;
+  if (tid < D_P) ar[a.o_b3 + tid] = gb3;
+}
+
+// ------------------------------------------------------------------------------------------
+// Gather gradients (TF: segment sum for the sorted centre gather, scatter-add for the neighbour
+// gather) without atomics:  d_rc[i] = sum_{e in row i} g1[e];  d_rn[i] = sum_{e in row i, n != i}
+// g1[reverse(e)] (the graph is symmetric).  One wave per detection; a wave-instruction reads four
+// 256-byte edge rows (16 lanes x float4 each); fixed summation order.  HBM/L2-bound: 2 x 256 B per edge.
+__global__ void __launch_bounds__(256) gather_sums(const float* __restrict__ g1, const int* __restrict__ row_ptr,
+                                                   const int* __restrict__ edge_n, const int* __restrict__ edge_t,
+                                                   int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n_det) return;
+  const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
+  const int eb = row_ptr[node], ee = row_ptr[node + 1];
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
+  for (int e = eb + sub; e < ee; e += 4) {
+    const float4 c = *reinterpret_cast<const float4*>(g1 + (size_t)e * D_P + 4 * f4);
+    sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+    const int t = edge_n[e] != node ? edge_t[e] : -1;     // self pair: n_feats zeroed (network.py:371-374)
+    if (t >= 0) {
+      const float4 v = *reinterpret_cast<const float4*>(g1 + (size_t)t * D_P + 4 * f4);
+      sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    sc.x += __shfl_xor(sc.x, o); sc.y += __shfl_xor(sc.y, o); sc.z += __shfl_xor(sc.z, o); sc.w += __shfl_xor(sc.w, o);
+    sn.x += __shfl_xor(sn.x, o); sn.y += __shfl_xor(sn.y, o); sn.z += __shfl_xor(sn.z, o); sn.w += __shfl_xor(sn.w, o);
+  }
+  if (sub == 0) {
+    *reinterpret_cast<float4*>(d_rc + (size_t)node * D_P + 4 * f4) = sc;
+    *reinterpret_cast<float4*>(d_rn + (size_t)node * D_P + 4 * f4) = sn;
+  }
+}
+
+struct BlkPreArgs {
+  int n_det;
+  int write_dx;                     // block > 1: d_x += drpre . Wr^T
+  const float* d_rc; const float* d_rn; const float* r; const float* x_prev;   // x_prev NULL = zeros
+  const float* w1;                  // natural [96,64]; rows 32-63 centre, 64-95 neighbour
+  const float* wr;                  // natural [128,32]
+  float* d_x;
+  float* arena; long long stride;
+  long long o_w1, o_b1, o_wr, o_br;
+};
+
+__global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
+  __shared__ __attribute__((aligned(16))) float sRc[32 * LD64];
+  __shared__ __attribute__((aligned(16))) float sRn[32 * LD64];
+  __shared__ __attribute__((aligned(16))) float sRr[32 * LD32];
+  __shared__ __attribute__((aligned(16))) float sDr[32 * LD32];
+  __shared__ __attribute__((aligned(16))) float sX[32 * LD128];
+  __shared__ __attribute__((aligned(16))) float sPart[4 * 32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 aWcn = zero16(), aWr = zero16();
+  float gb1 = 0.f, gbr = 0.f;
+  const int ntiles = (a.n_det + 31) / 32;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int row0 = t * 32;
+    __syncthreads();
+    load_tile<D_P, LD64>(sRc, a.d_rc, row0, a.n_det, tid, 256);
+    load_tile<D_P, LD64>(sRn, a.d_rn, row0, a.n_det, tid, 256);
+    load_tile<D_R, LD32>(sRr, a.r, row0, a.n_det, tid, 256);
+    if (a.x_prev) load_tile<D_S, LD128>(sX, a.x_prev, row0, a.n_det, tid, 256);
+    else for (int i = tid; i < 32 * LD128; i += 256) sX[i] = 0.f;
+    __syncthreads();
+    // dr = drc . Wc^T + drn . Wn^T : wave = (term, K half)
+    {
+      const int term = wave & 1, kh = wave >> 1;
+      f32x16 acc = zero16();
+      mma_abt<32>(acc, (term ? sRn : sRc) + 32 * kh, LD64, a.w1 + (size_t)(32 + 32 * term) * D_P + 32 * kh, D_P, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sPart[(wave * 32 + crow(r, half)) * 32 + col] = acc[r];
+    }
+    // d Wc += r^T . drc ; d Wn += r^T . drn : wave = (term, column tile)
+    {
+      const int term = wave >> 1, nj = wave & 1;
+      const float* Y = term ? sRn : sRc;
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + h;
+        aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(sRr[row * LD32 + r], Y[row * LD64 + 32 * nj + r], aWcn, 0, 0, 0);
+      }
+    }
+    if (tid < D_P) gb1 += col_sum32(sRc, LD64, tid);
+    __syncthreads();
+    for (int i = tid; i < 32 * D_R; i += 256) {
+      const int row = i >> 5, ff = i & 31;
+      float v = sPart[(0 * 32 + row) * 32 + ff] + sPart[(1 * 32 + row) * 32 + ff];
+      v += sPart[(2 * 32 + row) * 32 + ff];
+      v += sPart[(3 * 32 + row) * 32 + ff];
+      sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? v : 0.f;    // ReLU of reduce_dim
+    }
+    __syncthreads();
+    // d Wr += x_prev^T . drpre : wave w owns rows [32w, 32w+32) of Wr
+    {
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + h;
+        aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * wave + r], sDr[row * LD32 + r], aWr, 0, 0, 0);
+      }
+    }
+    if (tid < D_R) gbr += col_sum32(sDr, LD32, tid);
+    if (a.write_dx) {
+      f32x16 acc = zero16();
+      mma_abt<D_R>(acc, sDr, LD32, a.wr + (size_t)(32 * wave) * D_R, D_R, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int node = row0 + crow(r, half);
+        if (node < a.n_det) a.d_x[(size_t)node * D_S + 32 * wave + col] += acc[r];
+      }
+    }
+  }
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (wave >> 1)) * D_P + 32 * (wave & 1), D_P, aWcn, lane);
+  store_acc(ar + a.o_wr + (size_t)(32 * wave) * D_R, D_R, aWr, lane);
+  if (tid < D_P) ar[a.o_b1 + tid] = gb1;
+  if (tid < D_R) ar[a.o_br + tid] = gbr;
+}
+
+// ------------------------------------------------------------------------------------------
+struct EdgeBwdArgs {
+  int n_edge;
+  int accumulate_dpw;               // 0 for the first block processed (writes), 1 afterwards (adds)
+  const int* edge_c; const int* edge_n;
+  const float* pw; const float* rc; const float* rn;
+  const unsigned long long* pm; const float* d_pc;
+  const float* w1t; const float* w2t; const float* b2;   // transposed copies (forward recompute)
+  const float* w1; const float* w2;                       // natural layouts (input gradients)
+  float* d_pw; float* d_g1;
+  float* arena; long long stride;
+  long long o_w1, o_w2, o_b2;
+};
+
+__global__ void __launch_bounds__(256) edge_bwd(const EdgeBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sWpT = smem;                     // [64][36]  Wp^T   (forward)
+  float* sW2T = sWpT + D_P * LD32;        // [64][68]  W2^T   (forward)
+  float* sW2 = sW2T + D_P * LD64;         // [64][68]  W2     (d h1 = d h2 . W2^T)
+  float* sWp = sW2 + D_P * LD64;          // [32][68]  Wp     (d P  = g1 . Wp^T)
+  float* sTiles = sWp + D_E * LD64;       // per wave: h1 [32][68], d2/g1 [32][68]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < D_P * D_E; i += 256) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 256) {
+    sW2T[(i >> 6) * LD64 + (i & 63)] = a.w2t[i];
+    sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
+  }
+  for (int i = tid; i < D_E * D_P; i += 256) sWp[(i >> 6) * LD64 + (i & 63)] = a.w1[i];
+  __syncthreads();
+  float* sh1 = sTiles + wave * (2 * 32 * LD64);
+  float* sd2 = sh1 + 32 * LD64;
+  const int col = lane & 31, half = lane >> 5;
+  const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
+  f32x16 aW2[2][2], aWp[1][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { aW2[i][0] = zero16(); aW2[i][1] = zero16(); }
+  aWp[0][0] = zero16(); aWp[0][1] = zero16();
+  float gb2a = 0.f, gb2b = 0.f;
+  const int ntiles = (a.n_edge + 31) / 32;
+  const int nwaves = gridDim.x * 4;
+  const int per = (ntiles + nwaves - 1) / nwaves;
+  const int gw = blockIdx.x * 4 + wave;
+  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  for (int t = t0; t < t1; ++t) {
+    const int e0 = t * 32;
+    const int e = e0 + (lane & 31);
+    const int my_c = (e < a.n_edge) ? a.edge_c[e] : -1;
+    const int my_n = (e < a.n_edge) ? a.edge_n[e] : -1;
+    // ---- recompute h1 (kept in registers for its ReLU mask) and h2
+    f32x16 h1[2];
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const int c = __shfl(my_c, row), n = __shfl(my_n, row);
+        float v0 = 0.f, v1 = 0.f;
+        if (c >= 0) {
+          v0 = a.rc[(size_t)c * D_P + col]; v1 = a.rc[(size_t)c * D_P + 32 + col];
+          if (c != n) { v0 += a.rn[(size_t)n * D_P + col]; v1 += a.rn[(size_t)n * D_P + 32 + col]; }
+        }
+        h1[0][r] = v0; h1[1][r] = v1;
+      }
+      const int er = min(e, a.n_edge - 1);
+      const float* ap = a.pw + (size_t)er * D_E + 4 * half;
+      const float* b0 = sWpT + col * LD32 + 4 * half;
+      const float* b1 = b0 + 32 * LD32;
+#pragma unroll
+      for (int k = 0; k < D_E; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
+        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1[0], 0, 0, 0);
+        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1[1], 0, 0, 0);
+        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1[0], 0, 0, 0);
+        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1[1], 0, 0, 0);
+        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1[0], 0, 0, 0);
+        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1[1], 0, 0, 0);
+        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1[0], 0, 0, 0);
+        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1[1], 0, 0, 0);
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      h1[0][r] = fmaxf(h1[0][r], 0.f); h1[1][r] = fmaxf(h1[1][r], 0.f);
+      sh1[row * LD64 + col] = h1[0][r];
+      sh1[row * LD64 + 32 + col] = h1[1][r];
+    }
+    wave_lds_sync();
+    f32x16 h2a = zero16(), h2b = zero16();
+    mma_abt<D_P>(h2a, sh1, LD64, sW2T, LD64, lane);
+    mma_abt<D_P>(h2b, sh1, LD64, sW2T + 32 * LD64, LD64, lane);
+    // ---- d h2 (pre-activation): SegmentMax tie split, then ReLU mask
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      const int c = __shfl(my_c, row);
+      float d0 = 0.f, d1 = 0.f;
+      if (c >= 0) {
+        const float v0 = fmaxf(h2a[r] + bias0, 0.f), v1 = fmaxf(h2b[r] + bias1, 0.f);
+        const size_t o = (size_t)c * D_P + col;
+        const float p0 = __uint_as_float((unsigned)(a.pm[o] >> 32));
+        const float p1 = __uint_as_float((unsigned)(a.pm[o + 32] >> 32));
+        if (v0 > 0.f && v0 == p0) d0 = a.d_pc[o];
+        if (v1 > 0.f && v1 == p1) d1 = a.d_pc[o + 32];
+      }
+      sd2[row * LD64 + col] = d0;
+      sd2[row * LD64 + 32 + col] = d1;
+      gb2a += d0; gb2b += d1;
+    }
+    wave_lds_sync();
+    mma_xty<2, 2>(aW2, sh1, LD64, sd2, LD64, lane);                 // d W2 += h1^T . d h2
+    f32x16 g1a = zero16(), g1b = zero16();                           // g1 = (d h2 . W2^T) * (h1 > 0)
+    mma_abt<D_P>(g1a, sd2, LD64, sW2, LD64, lane);
+    mma_abt<D_P>(g1b, sd2, LD64, sW2 + 32 * LD64, LD64, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      const float v0 = h1[0][r] > 0.f ? g1a[r] : 0.f, v1 = h1[1][r] > 0.f ? g1b[r] : 0.f;
+      sd2[row * LD64 + col] = v0;                                    // g1 staged over d h2
+      sd2[row * LD64 + 32 + col] = v1;
+      // g1 goes to HBM: blk_bwd_pre turns it into the centre (segment) and neighbour (reversed-edge
+      // gather) sums in a fixed order -- no float atomics
+      const int ee = e0 + row;
+      if (ee < a.n_edge) {
+        a.d_g1[(size_t)ee * D_P + col] = v0;
+        a.d_g1[(size_t)ee * D_P + 32 + col] = v1;
+      }
+    }
+    wave_lds_sync();
+    // ---- d Wp += P^T . g1 (P read straight from global: rows of the tile are contiguous)
+    {
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + h;
+        const int er = min(e0 + row, a.n_edge - 1);
+        const float x = a.pw[(size_t)er * D_E + r];
+        const float y0 = sd2[row * LD64 + r], y1 = sd2[row * LD64 + 32 + r];
+        aWp[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y0, aWp[0][0], 0, 0, 0);
+        aWp[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y1, aWp[0][1], 0, 0, 0);
+      }
+    }
+    // ---- d P = g1 . Wp^T
+    {
+      f32x16 acc = zero16();
+      mma_abt<D_P>(acc, sd2, LD64, sWp, LD64, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ee = e0 + crow(r, half);
+        if (ee < a.n_edge) {
+          float* dst = a.d_pw + (size_t)ee * D_E + col;
+          *dst = a.accumulate_dpw ? (*dst + acc[r]) : acc[r];
+        }
+      }
+    }
+  }
+  // ---- workgroup reduction of the weight-gradient accumulators (waves 1..3 -> wave 0 through LDS)
+  __syncthreads();
+  float* red = sTiles;    // >= 3 * 1024 floats
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    f32x16& acc = (k < 4) ? aW2[k >> 1][k & 1] : aWp[0][k - 4];
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane] + red[1024 + r * 64 + lane] + red[2048 + r * 64 + lane];
+      if (k < 4) store_acc(ar + a.o_w2 + (size_t)(32 * (k >> 1)) * D_P + 32 * (k & 1), D_P, acc, lane);
+      else store_acc(ar + a.o_w1 + 32 * (k - 4), D_P, acc, lane);     // rows 0-31 of pw_fc1
+    }
+    __syncthreads();
+  }
+  // bias gradient of pw_fc2: every lane holds the sum over its rows; fold halves and waves
+  red[wave * 128 + half * 64 + col] = gb2a;
+  red[wave * 128 + half * 64 + 32 + col] = gb2b;
+  __syncthreads();
+  if (tid < D_P) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[w * 128 + tid] + red[w * 128 + 64 + tid];
+    ar[a.o_b2 + tid] = v;
+  }
+}
+
+constexpr size_t kEdgeBwdSmem =
+    (size_t)(D_P * LD32 + 2 * D_P * LD64 + D_E * LD64 + 4 * 2 * 32 * LD64) * sizeof(float);
+
+// ------------------------------------------------------------------------------------------
+struct PwBwdArgs {
+  int n_edge;
+  const float* pw; const float* d_pw; const float* h1; const float* h2;
+  const float* w2; const float* w3;          // natural [256,256], [256,32]
+  float* d_h1;
+  float* arena; long long stride;
+  long long o_w2, o_b2, o_w3, o_b3;
+};
+
+__global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sH1 = smem;                    // [32][260]
+  float* sH2 = sH1 + 32 * LD256;        // [32][260]  fc2 output, then d(fc2 pre-activation)
+  float* sD3 = sH2 + 32 * LD256;        // [32][36]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 aW2[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) aW2[0][j] = zero16();
+  f32x16 aW3 = zero16();
+  float gb2 = 0.f, gb3 = 0.f;
+  const int ntiles = (a.n_edge + 31) / 32;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long e0 = (long long)t * 32;
+    __syncthreads();
+    load_tile<D_H, LD256>(sH1, a.h1, e0, a.n_edge, tid, 512);
+    load_tile<D_H, LD256>(sH2, a.h2, e0, a.n_edge, tid, 512);
+    for (int i = tid; i < 32 * D_E; i += 512) {
+      const int row = i >> 5, j = i & 31;
+      float v = 0.f;
+      if (e0 + row < a.n_edge) {
+        const size_t o = (size_t)(e0 + row) * D_E + j;
+        v = a.pw[o] > 0.f ? a.d_pw[o] : 0.f;              // ReLU of fc3
+      }
+      sD3[row * LD32 + j] = v;
+    }
+    __syncthreads();
+    // d(fc2 pre) tile w = (d3 . W3^T) * (h2 > 0)
+    f32x16 d2 = zero16();
+    mma_abt<D_E>(d2, sD3, LD32, a.w3 + (size_t)(32 * wave) * D_E, D_E, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[r] = sH2[crow(r, half) * LD256 + 32 * wave + col] > 0.f ? d2[r] : 0.f;
+    // d W3 += h2^T . d3 (rows [32w, 32w+32) of W3)
+    {
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + h;
+        aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sH2[row * LD256 + 32 * wave + r], sD3[row * LD32 + r], aW3, 0, 0, 0);
+      }
+    }
+    if (tid < D_E) gb3 += col_sum32(sD3, LD32, tid);
+    __syncthreads();      // every wave is done with the fc2 outputs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sH2[crow(r, half) * LD256 + 32 * wave + col] = d2[r];
+    __syncthreads();
+    if (tid < D_H) gb2 += col_sum32(sH2, LD256, tid);
+    // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
+    mma_xty<1, 8>(aW2, sH1 + 32 * wave, LD256, sH2, LD256, lane);
+    // d(fc1 pre) tile w = (d2 . W2^T) * (h1 > 0)
+    {
+      f32x16 acc = zero16();
+      mma_abt<D_H>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        if (e0 + row < a.n_edge)
+          a.d_h1[(size_t)(e0 + row) * D_H + 32 * wave + col] = sH1[row * LD256 + 32 * wave + col] > 0.f ? acc[r] : 0.f;
+      }
+    }
+  }
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) store_acc(ar + a.o_w2 + (size_t)(32 * wave) * D_H + 32 * j, D_H, aW2[0][j], lane);
+  store_acc(ar + a.o_w3 + (size_t)(32 * wave) * D_E, D_E, aW3, lane);
+  if (tid < D_H) ar[a.o_b2 + tid] = gb2;
+  if (tid < D_E) ar[a.o_b3 + tid] = gb3;
+}
+
+constexpr size_t kPwBwdSmem = (size_t)(2 * 32 * LD256 + 32 * LD32) * sizeof(float);
+
+// fc1 of the pw-MLP: d W1 = X^T . d_h1 with X = [one-hot(c) * s_c | one-hot(n) * s_n | geo(7)].
+// One wave per (edge chunk, 64-column slice); the class rows accumulate in LDS (single wave ->
+// plain read-modify-write, deterministic), the 7 geometry rows and the bias in registers.
+struct PwW1Args {
+  int n_edge; int cprime; int multiclass;
+  const int* edge_c; const int* edge_n; const float* scores; const int* classes; const float* geo;
+  const float* d_h1;
+  float* arena; long long stride;
+  long long o_w1, o_b1;
+};
+
+__global__ void __launch_bounds__(64) pw_bwd_w1(const PwW1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float sAcc[];   // [2*cprime][64]
+  const int lane = threadIdx.x;
+  const int fcol = blockIdx.y * 64 + lane;
+  const int nrow = 2 * a.cprime;
+  for (int i = lane; i < nrow * 64; i += 64) sAcc[i] = 0.f;
+  float g[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float gb = 0.f;
+  const int per = (a.n_edge + gridDim.x - 1) / gridDim.x;
+  const int eb = blockIdx.x * per, ee = min(a.n_edge, eb + per);
+  for (int e = eb; e < ee; ++e) {
+    const float d = a.d_h1[(size_t)e * D_H + fcol];
+    const int c = a.edge_c[e], n = a.edge_n[e];
+    float sc = a.scores[c], sn = a.scores[n];
+    int rc = 0, rn = 1;
+    if (a.multiclass) {
+      const int cc = a.classes[c] - 1, cn = a.classes[n] - 1;
+      if (cc >= 0 && cc < a.cprime) rc = cc; else sc = 0.f;
+      if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
+    }
+    sAcc[rc * 64 + lane] = fmaf(sc, d, sAcc[rc * 64 + lane]);
+    sAcc[rn * 64 + lane] = fmaf(sn, d, sAcc[rn * 64 + lane]);
+    const float4 g0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
+    const float4 g1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
+    g[0] = fmaf(g0.x, d, g[0]); g[1] = fmaf(g0.y, d, g[1]); g[2] = fmaf(g0.z, d, g[2]); g[3] = fmaf(g0.w, d, g[3]);
+    g[4] = fmaf(g1.x, d, g[4]); g[5] = fmaf(g1.y, d, g[5]); g[6] = fmaf(g1.z, d, g[6]);
+    gb += d;
+  }
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  for (int r = 0; r < nrow; ++r) ar[a.o_w1 + (size_t)r * D_H + fcol] = sAcc[r * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) ar[a.o_w1 + (size_t)(nrow + k) * D_H + fcol] = g[k];
+  ar[a.o_b1 + fcol] = gb;
+}
+
+// ------------------------------------------------------------------------------------------
+// grads[p] = sum over the n(p) partial copies arena[k][p], k ascending.
+struct ReduceArgs {
+  const float* arena; long long stride; long long total;
+  long long pw1_end;      // end of pw fc1 weights+bias
+  long long pw_end;       // end of the pw-MLP parameters
+  long long blk_sz; int nblocks;
+  int n_w1, n_pw, n_edge, n_node, n_head;
+  float* grads;
+};
+
+__global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.total) return;
+  int n;
+  if (p < a.pw1_end) n = a.n_w1;
+  else if (p < a.pw_end) n = a.n_pw;
+  else if (p < a.pw_end + a.blk_sz * a.nblocks) {
+    const long long q = (p - a.pw_end) % a.blk_sz;
+    const long long w1 = D_S * D_R + D_R;                       // start of pw_fc1 weights
+    const long long w2 = w1 + (D_E + 2 * D_R) * D_P + D_P;      // start of pw_fc2 weights
+    const bool edge = (q >= w1 && q < w1 + D_E * D_P) || (q >= w2 && q < w2 + D_P * D_P + D_P);
+    n = edge ? a.n_edge : a.n_node;
+  } else n = a.n_head;
+  float v = 0.f;
+  const float* src = a.arena + p;
+  for (int k = 0; k < n; ++k) v += src[(size_t)k * a.stride];
+  a.grads[p] = v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
 extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                              const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream) {
-  (void)cfg; (void)shape; (void)in; (void)params; (void)buf; (void)grads; (void)stream;
-  return GNET_ERR_UNSUPPORTED;
+  clear_hip_error();
+  if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
+  if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1) return GNET_ERR_INVALID;   // plan(training=1)
+  hipStream_t s = (hipStream_t)stream;
+  const ParamLayout L = make_layout(cfg);
+  const int B = cfg->num_blocks;
+  const int N = shape->n_det;
+  const int E = (int)shape->n_edge;
+  if (N == 0) {
+    HIP_CHECK_RET(hipMemsetAsync(grads, 0, (size_t)L.total * sizeof(float), s));
+    return GNET_OK;
+  }
+  if ((size_t)GNET_ARENA_PARTIALS * (size_t)L.total > buf->arena_floats) return GNET_ERR_WORKSPACE;
+  const float* pt = buf->packed_t;
+  void* prof = buf->profiler;
+  const long long stride = L.total;
+  const int ntile_n = (N + 31) / 32;
+  const int g_node = min(ntile_n, 128);
+  const int etiles = (E + 31) / 32;
+  const int g_edge = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (etiles + 3) / 4)) : 0;
+  const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
+  const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + 255) / 256)) : 0;
+
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+
+  {
+    HeadBwdArgs h;
+    h.n_det = N; h.d_logits = buf->d_logits; h.head2 = buf->head2; h.head1 = buf->head1; h.xb = buf->block_feats[B];
+    h.hw1 = params + L.hw1; h.hw2 = params + L.hw2; h.hwl = params + L.hwl;
+    h.d_x = buf->d_x; h.arena = buf->arena; h.stride = stride;
+    h.o_hw1 = L.hw1; h.o_hb1 = L.hb1; h.o_hw2 = L.hw2; h.o_hb2 = L.hb2; h.o_hwl = L.hwl; h.o_hbl = L.hbl;
+    GNET_LAUNCH(prof, GNET_K_HEAD_BWD, s, head_bwd<<<g_node, 256, 0, s>>>(h));
+  }
+  for (int b = B; b >= 1; --b) {
+    const BlockLayout& K = L.blk[b];
+    {
+      BlkPostArgs p;
+      p.n_det = N; p.d_x = buf->d_x; p.x_out = buf->block_feats[b]; p.q = buf->blk_q[b];
+      p.pm = (const unsigned long long*)buf->blk_pm[b];
+      p.w4 = params + K.w4; p.w3 = params + K.w3;
+      p.d_pc = buf->d_pc;
+      p.arena = buf->arena; p.stride = stride; p.o_w4 = K.w4; p.o_b4 = K.b4; p.o_w3 = K.w3; p.o_b3 = K.b3;
+      GNET_LAUNCH(prof, GNET_K_BLK_POST, s, blk_bwd_post<<<g_node, 256, 0, s>>>(p));
+    }
+    if (E > 0) {
+      EdgeBwdArgs e;
+      e.n_edge = E; e.accumulate_dpw = b != B;
+      e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
+      e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b];
+      e.pm = (const unsigned long long*)buf->blk_pm[b]; e.d_pc = buf->d_pc;
+      e.w1t = pt + K.w1; e.w2t = pt + K.w2; e.b2 = params + K.b2; e.w1 = params + K.w1; e.w2 = params + K.w2;
+      e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
+      e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
+      GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<<<g_edge, 256, kEdgeBwdSmem, s>>>(e));
+    }
+    GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sums<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, N,
+                                                                              buf->d_rc, buf->d_rn));
+    {
+      BlkPreArgs p;
+      p.n_det = N; p.write_dx = b > 1;
+      p.d_rc = buf->d_rc; p.d_rn = buf->d_rn; p.r = buf->blk_r[b];
+      p.x_prev = b > 1 ? buf->block_feats[b - 1] : nullptr;
+      p.w1 = params + K.w1; p.wr = params + K.wr; p.d_x = buf->d_x;
+      p.arena = buf->arena; p.stride = stride; p.o_w1 = K.w1; p.o_b1 = K.b1; p.o_wr = K.wr; p.o_br = K.br;
+      GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, blk_bwd_pre<<<g_node, 256, 0, s>>>(p));
+    }
+  }
+  if (E > 0) {
+    PwBwdArgs p;
+    p.n_edge = E; p.pw = buf->pw_feats; p.d_pw = buf->d_pw; p.h1 = buf->pw_h1; p.h2 = buf->pw_h2;
+    p.w2 = params + L.pw2; p.w3 = params + L.pw3; p.d_h1 = buf->d_h1;
+    p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
+    GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<<<g_pw, 512, kPwBwdSmem, s>>>(p));
+    PwW1Args w;
+    w.n_edge = E; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;
+    w.edge_c = buf->edge_c; w.edge_n = buf->edge_n; w.scores = in->det_scores; w.classes = in->det_classes;
+    w.geo = buf->geo; w.d_h1 = buf->d_h1; w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1;
+    const size_t smem = (size_t)2 * L.cprime * 64 * sizeof(float);
+    if (smem > 160 * 1024) return GNET_ERR_UNSUPPORTED;
+    GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_bwd_w1<<<dim3(g_w1, 4), 64, smem, s>>>(w));
+  }
+  {
+    ReduceArgs r;
+    r.arena = buf->arena; r.stride = stride; r.total = L.total;
+    r.pw1_end = L.pw2; r.pw_end = L.blk[1].wr;
+    r.blk_sz = (B > 1) ? (L.blk[2].wr - L.blk[1].wr) : (L.hw1 - L.blk[1].wr);
+    r.nblocks = B;
+    r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_node;
+    r.grads = grads;
+    GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 255) / 256), 256, 0, s>>>(r));
+  }
+  return launch_status();
 }

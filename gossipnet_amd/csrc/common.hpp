@@ -23,6 +23,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (_e != hipSuccess) return GNET_ERR_HIP; \
   } while (0)
 
+// ---- optional event profiler (see gnet_profiler_* in gossipnet_hip.h) ------------------------
+struct GnetProfiler {
+  uint32_t mask;
+  int cap, n;
+  hipEvent_t* ev0;
+  hipEvent_t* ev1;
+  int* cls;
+};
+struct ProfScope {
+  GnetProfiler* p; int idx; hipStream_t s;
+  ProfScope(void* prof, int cls, hipStream_t stream) : p((GnetProfiler*)prof), idx(-1), s(stream) {
+    if (p && ((p->mask >> cls) & 1u) && p->n < p->cap) {
+      idx = p->n++;
+      p->cls[idx] = cls;
+      (void)hipEventRecord(p->ev0[idx], s);
+    }
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(p->ev1[idx], s); }
+};
+#define GNET_LAUNCH(prof, cls, stream, ...) \
+  do { ProfScope _ps((prof), (cls), (stream)); __VA_ARGS__; } while (0)
+
+// HIP keeps the last error of ANY runtime call of the thread (torch's included): clear it on entry.
+static inline void clear_hip_error() { (void)hipGetLastError(); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? GNET_OK : GNET_ERR_HIP; }
 
 // ---- parameter layout (offsets in floats into the flat buffer; see gossipnet_hip.h) ------

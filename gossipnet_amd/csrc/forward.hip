@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
 // ------------------------------------------------------------------------------------------
 extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                             const float* params, gnet_buffers* buf, int training, gnet_stream_t stream) {
+  clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf) return GNET_ERR_INVALID;
   if (shape->n_det < 0 || shape->n_edge < 0 || shape->n_img < 1) return GNET_ERR_INVALID;
@@ -458,7 +459,8 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   const int E = (int)shape->n_edge;
   float* pt = buf->packed_t;
 
-  pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B);
+  void* prof = buf->profiler;
+  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B));
 
   if (E > 0) {
     PwFwdArgs a;
@@ -475,7 +477,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
       HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
       attr_set = true;
     }
-    pw_fwd<<<min(tiles, 256), 512, kPwFwdSmem, s>>>(a);
+    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<min(tiles, 256), 512, kPwFwdSmem, s>>>(a));
   }
 
   const int ntile_n = (N + 31) / 32;
@@ -500,7 +502,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
     n.hwl = params + L.hwl; n.hbl = params + L.hbl;
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
-    node_fwd<<<ntile_n, 256, 0, s>>>(n);
+    GNET_LAUNCH(prof, GNET_K_NODE_FWD, s, node_fwd<<<ntile_n, 256, 0, s>>>(n));
     if (b < B) {
       HIP_CHECK_RET(hipMemsetAsync(buf->blk_pm[b + 1], 0, (size_t)N * D_P * sizeof(unsigned long long), s));
       if (E > 0) {
@@ -509,7 +511,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.rc = buf->blk_rc[b + 1]; e.rn = buf->blk_rn[b + 1];
         e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
         e.pm = (unsigned long long*)buf->blk_pm[b + 1];
-        edge_fwd<<<egrid, 256, 0, s>>>(e);
+        GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd<<<egrid, 256, 0, s>>>(e));
       }
     }
   }

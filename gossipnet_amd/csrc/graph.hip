@@ -131,10 +131,28 @@ __global__ void __launch_bounds__(1024) exclusive_scan(const int* __restrict__ d
   if (t == 1023) out[n] = part[1023];
 }
 
+// edge_t[e] = position of the reversed pair: for e = (c, n) find c in row n (columns ascending).
+__global__ void __launch_bounds__(256) graph_transpose(const int* __restrict__ row_ptr, const int* __restrict__ edge_c,
+                                                       const int* __restrict__ edge_n, long long n_edge,
+                                                       int* __restrict__ edge_t) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_edge) return;
+  const int c = edge_c[e], n = edge_n[e];
+  int lo = row_ptr[n], hi = row_ptr[n + 1] - 1, pos = -1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int v = edge_n[mid];
+    if (v == c) { pos = mid; break; }
+    if (v < c) lo = mid + 1; else hi = mid - 1;
+  }
+  edge_t[e] = pos;
+}
+
 }  // namespace
 
 extern "C" int gnet_graph_count(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
                                 float thresh, int32_t* row_ptr, int32_t* scratch, gnet_stream_t stream) {
+  clear_hip_error();
   if (n_det < 0 || n_img < 1 || !row_ptr || !det_off) return GNET_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   if (n_det == 0) {
@@ -152,11 +170,22 @@ extern "C" int gnet_graph_count(const float* dets, int32_t n_det, const int32_t*
 extern "C" int gnet_graph_fill(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
                                float thresh, const int32_t* row_ptr, int32_t* edge_c, int32_t* edge_n,
                                float* edge_iou, gnet_stream_t stream) {
+  clear_hip_error();
   if (n_det < 0 || n_img < 1 || !row_ptr || !det_off) return GNET_ERR_INVALID;
   if (n_det == 0) return GNET_OK;
   if (!dets || !edge_c || !edge_n || !edge_iou) return GNET_ERR_INVALID;
   const int grid = (n_det + kRowsPerBlock - 1) / kRowsPerBlock;
   graph_sweep<true><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)dets, n_det, det_off, n_img, thresh,
                                                           nullptr, row_ptr, edge_c, edge_n, edge_iou);
+  return launch_status();
+}
+
+extern "C" int gnet_graph_transpose(const int32_t* row_ptr, const int32_t* edge_c, const int32_t* edge_n, int64_t n_edge,
+                                    int32_t* edge_t, gnet_stream_t stream) {
+  clear_hip_error();
+  if (n_edge < 0) return GNET_ERR_INVALID;
+  if (n_edge == 0) return GNET_OK;
+  if (!row_ptr || !edge_c || !edge_n || !edge_t) return GNET_ERR_INVALID;
+  graph_transpose<<<(int)((n_edge + 255) / 256), 256, 0, (hipStream_t)stream>>>(row_ptr, edge_c, edge_n, n_edge, edge_t);
   return launch_status();
 }

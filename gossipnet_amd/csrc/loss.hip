@@ -263,6 +263,7 @@ extern "C" size_t det_matching_workspace_bytes(int32_t n_det, int32_t n_gt) {
 extern "C" int det_matching_f32(const float* iou, const float* score, const uint8_t* ignore, int32_t n_det,
                                 int32_t n_gt, float* labels, float* weights, int32_t* assignment, void* workspace,
                                 size_t workspace_bytes, gnet_stream_t stream) {
+  clear_hip_error();
   // shape checks of det_matching.cc:76-93 are the caller's tensor ranks; sizes must be consistent
   if (n_det < 0 || n_gt < 0) return GNET_ERR_INVALID;
   if (n_det == 0) return GNET_OK;
@@ -286,6 +287,7 @@ extern "C" int det_matching_f32(const float* iou, const float* score, const uint
 
 extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                          const float* class_weights, float grad_scale, gnet_buffers* buf, gnet_stream_t stream) {
+  clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !buf || !buf->labels || !buf->match_ws) return GNET_ERR_INVALID;
   if (shape->n_det == 0) return GNET_OK;

@@ -36,6 +36,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
   b.edge_c = c.take<int32_t>(Ep);
   b.edge_n = c.take<int32_t>(Ep);
   b.edge_iou = c.take<float>(Ep);
+  b.edge_t = c.take<int32_t>(Ep);
   b.pw_feats = c.take<float>(Ep * D_E);
   b.packed_t = c.take<float>((size_t)L.total);
   b.prediction = c.take<float>(Np);
@@ -69,6 +70,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_rn = c.take<float>(Np * D_P);
     b.d_pw = c.take<float>(Ep * D_E);
     b.d_h1 = c.take<float>(Ep * D_H);
+    b.d_g1 = c.take<float>(Ep * D_P);
     b.arena_floats = arena_floats(cfg, sh);
     b.arena = c.take<float>(b.arena_floats);
   } else {
@@ -106,6 +108,41 @@ extern "C" int gnet_plan(const gnet_config* cfg, const gnet_shape* shape, int tr
   const size_t need = carve(cfg, shape, training, nullptr, nullptr);
   if (workspace_bytes < need) return GNET_ERR_WORKSPACE;
   carve(cfg, shape, training, workspace, out);
+  return GNET_OK;
+}
+
+extern "C" int gnet_profiler_create(int32_t capacity, uint32_t class_mask, void** out) {
+  if (capacity <= 0 || !out) return GNET_ERR_INVALID;
+  GnetProfiler* p = new GnetProfiler();
+  p->mask = class_mask; p->cap = capacity; p->n = 0;
+  p->ev0 = new hipEvent_t[capacity]; p->ev1 = new hipEvent_t[capacity]; p->cls = new int[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&p->ev0[i]) != hipSuccess || hipEventCreate(&p->ev1[i]) != hipSuccess) return GNET_ERR_HIP;
+  }
+  *out = p;
+  return GNET_OK;
+}
+
+extern "C" int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count) {
+  GnetProfiler* p = (GnetProfiler*)profiler;
+  if (!p || !ms_sum || !count) return GNET_ERR_INVALID;
+  for (int i = 0; i < p->n; ++i) {
+    if (hipEventSynchronize(p->ev1[i]) != hipSuccess) return GNET_ERR_HIP;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p->ev0[i], p->ev1[i]) != hipSuccess) return GNET_ERR_HIP;
+    ms_sum[p->cls[i]] += ms;
+    count[p->cls[i]] += 1;
+  }
+  p->n = 0;
+  return GNET_OK;
+}
+
+extern "C" int gnet_profiler_destroy(void* profiler) {
+  GnetProfiler* p = (GnetProfiler*)profiler;
+  if (!p) return GNET_OK;
+  for (int i = 0; i < p->cap; ++i) { (void)hipEventDestroy(p->ev0[i]); (void)hipEventDestroy(p->ev1[i]); }
+  delete[] p->ev0; delete[] p->ev1; delete[] p->cls;
+  delete p;
   return GNET_OK;
 }
 

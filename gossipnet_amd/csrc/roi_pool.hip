@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256) roi_pool_bwd(const float* __restrict__ to
 extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, int32_t W, int32_t C,
                                 const float* bottom_rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
                                 float spatial_scale, float* top_data, int32_t* argmax, gnet_stream_t stream) {
+  clear_hip_error();
   if (pooled_h < 0 || pooled_w < 0 || B < 0 || H < 0 || W < 0 || C < 0 || R < 0) return GNET_ERR_INVALID;  // :59-77
   const long long total = (long long)R * pooled_h * pooled_w * C;
   if (total == 0) return GNET_OK;
@@ -87,6 +88,7 @@ extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, 
 extern "C" int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, const float* bottom_rois, int32_t B,
                                 int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h, int32_t pooled_w,
                                 float spatial_scale, float* bottom_diff, gnet_stream_t stream) {
+  clear_hip_error();
   (void)spatial_scale;
   if (pooled_h < 0 || pooled_w < 0 || B < 0 || H < 0 || W < 0 || C < 0 || R < 0) return GNET_ERR_INVALID;
   const long long image_elems = (long long)H * W * C;

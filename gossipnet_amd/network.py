@@ -193,6 +193,7 @@ class Gnet(object):
         self._row_ptr_tmp = None
         self._scratch_tmp = None
         self.grad_scale = 1.0
+        self._profiler = None
         self._batch = batch
         if batch is not None:
             self.feed(batch)
@@ -260,10 +261,13 @@ class Gnet(object):
         buf = _lib.gnet_buffers()
         _lib.check(lib.gnet_plan(C.byref(self._cfg), C.byref(shape), int(training), _vp(self._ws), self._ws.numel(),
                                  C.byref(buf)), "gnet_plan")
+        buf.profiler = self._profiler
         self._buf, self._shape, self._training = buf, shape, training
         self._view(buf.row_ptr, N + 1, torch.int32).copy_(self._row_ptr_tmp[:N + 1])
         _lib.check(lib.gnet_graph_fill(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr, buf.edge_c,
                                        buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
+        if training and E > 0:
+            _lib.check(lib.gnet_graph_transpose(buf.row_ptr, buf.edge_c, buf.edge_n, E, buf.edge_t, s), "gnet_graph_transpose")
         self.num_edges = E
         return shape, buf
 
@@ -292,6 +296,25 @@ class Gnet(object):
                     # slim get_total_loss adds sum(l2_regularizer(scale)(w)) -> d/dw = scale * w (train.py:231-238)
                     self.grads.addcmul_(self.params, self._reg_mask, value=float(self.weight_reg) * float(self.grad_scale))
         return self
+
+    # ------------------------------------------------------------------ measurement
+    def enable_kernel_timing(self, classes=None, capacity=4096):
+        """HIP-event timing of the selected kernel classes (names in _lib.KCLASSES) on the launch stream."""
+        mask = 0
+        for i, nm in enumerate(_lib.KCLASSES):
+            if classes is None or nm in classes:
+                mask |= 1 << i
+        if self._profiler:
+            self._lib.gnet_profiler_destroy(self._profiler)
+        out = C.c_void_p()
+        _lib.check(self._lib.gnet_profiler_create(capacity, mask, C.byref(out)), "gnet_profiler_create")
+        self._profiler = out.value
+
+    def read_kernel_timing(self):
+        ms = (C.c_double * len(_lib.KCLASSES))()
+        cnt = (C.c_int32 * len(_lib.KCLASSES))()
+        _lib.check(self._lib.gnet_profiler_read(self._profiler, ms, cnt), "gnet_profiler_read")
+        return {nm: (ms[i], cnt[i]) for i, nm in enumerate(_lib.KCLASSES) if cnt[i]}
 
     # ------------------------------------------------------------------ outputs (Gnet attributes)
     @property

@@ -86,6 +86,7 @@ typedef struct gnet_buffers {
   int32_t* edge_c;    /* [n_edge] pair_c_idxs          */
   int32_t* edge_n;    /* [n_edge] pair_n_idxs          */
   float* edge_iou;    /* [n_edge] det_det_iou at pairs */
+  int32_t* edge_t;    /* [n_edge] index of the reversed pair (n,c); the graph is symmetric */
   float* geo;         /* [n_edge,8] 7 geometry columns of _geometry_feats (+pad) */
   float* pw_h1;       /* [n_edge,256]  pw_feats/fc1 output (training)            */
   float* pw_h2;       /* [n_edge,256]  pw_feats/fc2 output (training)            */
@@ -113,12 +114,14 @@ typedef struct gnet_buffers {
   float* d_rn;        /* [n_det,64] */
   float* d_pw;        /* [n_edge,32] grad wrt pw_feats */
   float* d_h1;        /* [n_edge,256] grad wrt pre-activation of pw_feats/fc1 */
+  float* d_g1;        /* [n_edge,64]  grad wrt pre-activation of block pw_fc1 (per block, transient) */
   float* packed_t;    /* [param_count] transposed copies of the weight matrices */
   float* arena;       /* per-workgroup partial weight gradients */
   int32_t* scratch_i; /* [n_det + 1024] */
   void* match_ws;     /* det_matching_workspace_bytes(n_det, n_gt) */
   size_t match_ws_bytes;
   size_t arena_floats;
+  void* profiler;     /* optional gnet_profiler (NULL = off); set by the caller after gnet_plan */
 } gnet_buffers;
 
 /* ---- parameters ------------------------------------------------------------
@@ -140,6 +143,10 @@ int gnet_graph_count(const float* dets, int32_t n_det, const int32_t* det_off, i
 int gnet_graph_fill(const float* dets, int32_t n_det, const int32_t* det_off, int32_t n_img,
                     float thresh, const int32_t* row_ptr, int32_t* edge_c, int32_t* edge_n,
                     float* edge_iou, gnet_stream_t stream);
+
+/* Reverse-edge permutation: edge_t[e] = position of (n,c) for e = (c,n) (binary search in row n). */
+int gnet_graph_transpose(const int32_t* row_ptr, const int32_t* edge_c, const int32_t* edge_n, int64_t n_edge,
+                         int32_t* edge_t, gnet_stream_t stream);
 
 /* ---- workspace ----------------------------------------------------------------- */
 size_t gnet_workspace_bytes(const gnet_config* cfg, const gnet_shape* shape, int training);
@@ -178,6 +185,19 @@ int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, int32_t W, 
 int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, const float* bottom_rois,
                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h,
                      int32_t pooled_w, float spatial_scale, float* bottom_diff, gnet_stream_t stream);
+
+/* ---- optional per-kernel timing (measurement only; no reference counterpart) -------------
+ * A caller-owned pool of HIP event pairs recorded on the launch stream around every kernel of the
+ * selected classes.  gnet_profiler_read synchronises the recorded events, adds the elapsed
+ * milliseconds and launch counts per class into ms_sum[GNET_KCLASS_COUNT] / count[...], and resets. */
+enum {
+  GNET_K_GRAPH = 0, GNET_K_PACK, GNET_K_PW_FWD, GNET_K_NODE_FWD, GNET_K_EDGE_FWD, GNET_K_LOSS,
+  GNET_K_HEAD_BWD, GNET_K_BLK_POST, GNET_K_EDGE_BWD, GNET_K_BLK_PRE, GNET_K_PW_BWD, GNET_K_PW_W1,
+  GNET_K_REDUCE, GNET_KCLASS_COUNT
+};
+int gnet_profiler_create(int32_t capacity, uint32_t class_mask, void** out);
+int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count);
+int gnet_profiler_destroy(void* profiler);
 
 /* Version / build info string (static storage). */
 const char* gnet_version(void);

@@ -195,9 +195,23 @@ class _SegmentMax(torch.autograd.Function):
         return torch.where(sel, weighted[ids], torch.zeros_like(x)), None, None
 
 
-def _fc(x, params, scope, relu):
+def _fc(x, params, scope, relu, stats=None):
     y = x @ params[scope + "/weights"] + params[scope + "/biases"]
+    if relu and stats is not None and y.numel():
+        stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float(y.detach().abs().min()))
     return torch.relu(y) if relu else y
+
+
+def _segmax_gap(h, ids, n_seg):
+    """Smallest positive gap between the largest and the second largest value of a segment
+    (conditioning of the arg-max; exact ties are handled identically by every implementation)."""
+    h = h.detach()
+    idx = ids.view(-1, 1).expand_as(h)
+    top = torch.zeros(n_seg, h.shape[1], dtype=h.dtype).scatter_reduce(0, idx, h, reduce="amax", include_self=False)
+    rest = torch.where(h == top[ids], torch.full_like(h, -1.0), h)
+    second = torch.full((n_seg, h.shape[1]), -1.0, dtype=h.dtype).scatter_reduce(0, idx, rest, reduce="amax", include_self=True)
+    gap = (top - second)[(top > 0) & (second >= 0)]
+    return float(gap.min()) if gap.numel() else float("inf")
 
 
 def sigmoid_xent(x, z):
@@ -266,7 +280,9 @@ class GnetOracle:
         self.class_weights = torch.tensor(np.asarray(class_weights), dtype=dtype)
         self.matching_fn = matching_fn or detection_matching_py
 
-    def forward(self, batch, with_loss=True, keep=False):
+    def forward(self, batch, with_loss=True, keep=False, stats=None):
+        """stats (optional dict) collects the conditioning of the non-smooth points:
+        relu_margin = min |pre-activation| over every ReLU, max_gap = min top-2 gap of segment_max."""
         P = self.params
         npd = self.npdtype
         C = self.num_classes
@@ -287,7 +303,7 @@ class GnetOracle:
         f = torch.from_numpy(raw).to(self.dtype)          # stop_gradient (:454), multiplyer 1.0 (:199-200)
         # _pw_feats_fc network.py:324-342
         for i in range(1, NUM_PWFEAT_FC + 1):
-            f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True)
+            f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats)
         pw = f
         out["pw_feats"] = pw
         x = torch.zeros(N, SHORTCUT_DIM, dtype=self.dtype)   # network.py:241-246
@@ -295,15 +311,19 @@ class GnetOracle:
         is_id = (c_idx == n_idx).view(-1, 1)
         for b in range(1, self.num_blocks + 1):             # _block network.py:344-409
             s = "gnet/block%d/" % b
-            r = _fc(x, P, s + "reduce_dim", True)
+            r = _fc(x, P, s + "reduce_dim", True, stats if b > 1 else None)
             cf = r[c_idx]
             nf = torch.where(is_id, torch.zeros((), dtype=self.dtype), r[n_idx])
             h = torch.cat([pw, cf, nf], 1)
-            h = _fc(h, P, s + "pw_fc1", True)
-            h = _fc(h, P, s + "pw_fc2", True)
+            h = _fc(h, P, s + "pw_fc1", True, stats)
+            h = _fc(h, P, s + "pw_fc2", True, stats)
+            if stats is not None:
+                stats["max_gap"] = min(stats.get("max_gap", float("inf")), _segmax_gap(h, c_idx, N))
             p = _SegmentMax.apply(h, c_idx, N)
-            q = _fc(p, P, s + "fc1", True)
+            q = _fc(p, P, s + "fc1", True, stats)
             y = _fc(q, P, s + "fc2", False)
+            if stats is not None and N:
+                stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float((x + y).detach().abs().min()))
             x = torch.relu(x + y)
             block_feats.append(x)
         out["block_feats"] = block_feats
@@ -335,10 +355,10 @@ class GnetOracle:
         out["loss"] = (out["loss_normed"] if self.normalize_loss else out["loss_unnormed"]) * self.loss_multiplyer
         return out
 
-    def forward_backward(self, batch):
+    def forward_backward(self, batch, stats=None):
         for p in self.params.values():
             p.grad = None
-        out = self.forward(batch)
+        out = self.forward(batch, stats=stats)
         out["loss"].backward()
         grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()
                  for k, p in self.params.items()}

@@ -1,0 +1,135 @@
+"""GPU parity of the two custom ops through their reference-named wrappers (bit-exact integer outputs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import native
+from oracle import gnet_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def _match(iou, score, ign):
+    from gossipnet_amd.matching_module import detection_matching
+    d = "cuda:0"
+    l, w, a = detection_matching(torch.tensor(iou, dtype=torch.float32, device=d).reshape(len(score), len(ign)),
+                                 torch.tensor(score, dtype=torch.float32, device=d),
+                                 torch.tensor(np.asarray(ign, bool), device=d))
+    return l.cpu().numpy(), w.cpu().numpy(), a.cpu().numpy()
+
+
+def test_matching_kats():
+    l, w, a = _match([[.6, .7], [.8, .0], [.55, .9]], [.1, .9, .5], [False, False])
+    assert l.tolist() == [0, 1, 1] and w.tolist() == [1, 1, 1] and a.tolist() == [-1, 0, 1]
+    l, w, a = _match([[.6, .7], [.9, .8]], [2, 1], [False, True])
+    assert l.tolist() == [1, 1] and w.tolist() == [1, 0] and a.tolist() == [0, 1]
+    l, w, a = _match([[.6, .7], [.9, .8], [.0, .6]], [3, 2, 1], [False, True])
+    assert a.tolist() == [0, 1, 1] and w.tolist() == [1, 0, 0]
+    l, w, a = _match([[.5]], [1], [False])
+    assert a.tolist() == [0]
+    l, w, a = _match(np.zeros((3, 0)), [1, 2, 3], [])
+    assert l.tolist() == [0, 0, 0] and w.tolist() == [1, 1, 1] and a.tolist() == [-1, -1, -1]
+    l, w, a = _match([[.7, .7]], [1], [False, False])
+    assert a.tolist() == [1]
+
+
+@pytest.mark.parametrize("n,m,seed", [(1, 1, 0), (17, 5, 1), (200, 40, 2), (64, 0, 3), (2000, 80, 4), (500, 300, 5),
+                                      (3000, 7, 6)])
+def test_matching_random_vs_oracle(n, m, seed):
+    rng = np.random.default_rng(seed)
+    iou = rng.uniform(0, 1, (n, m)).astype(np.float32)
+    iou[rng.uniform(size=(n, m)) < 0.7] = 0
+    # force contention: many detections compete for the same few GTs, 3+ candidates per detection
+    if m >= 4:
+        iou[:, :4] = rng.uniform(0.5, 1, (n, 4)).astype(np.float32)
+    score = (rng.permutation(n) + 0.5).astype(np.float32)
+    ign = rng.uniform(size=m) < 0.3
+    ref = native.det_matching(iou, score, ign)
+    got = _match(iou, score, ign)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g)
+
+
+def test_matching_score_ties_follow_documented_rule():
+    # equal scores: higher index first (stable ascending sort reversed, det_matching.cc:95-96)
+    iou = np.array([[.9], [.9], [.9]], np.float32)
+    l, w, a = _match(iou, [1, 1, 1], [False])
+    assert a.tolist() == [-1, -1, 0]
+
+
+def test_matching_shape_errors():
+    from gossipnet_amd.matching_module import detection_matching
+    from gossipnet_amd._lib import InvalidArgumentError
+    d = "cuda:0"
+    with pytest.raises(InvalidArgumentError):
+        detection_matching(torch.zeros(3, device=d), torch.zeros(3, device=d), torch.zeros(1, device=d, dtype=torch.bool))
+    with pytest.raises(InvalidArgumentError):
+        detection_matching(torch.zeros(3, 2, device=d), torch.zeros(4, device=d), torch.zeros(2, device=d, dtype=torch.bool))
+    with pytest.raises(InvalidArgumentError):
+        detection_matching(torch.zeros(3, 2, device=d), torch.zeros(3, device=d), torch.zeros(3, device=d, dtype=torch.bool))
+
+
+def test_roi_pool_kat():
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    d = "cuda:0"
+    data = torch.arange(16, dtype=torch.float32, device=d).reshape(1, 4, 4, 1)
+    rois = torch.tensor([[0, 0, 0, 3, 3]], dtype=torch.float32, device=d)
+    top, am = roi_pool(data, rois, 2, 2, 1.0)
+    assert top.flatten().tolist() == [5, 7, 13, 15] and am.flatten().tolist() == [5, 7, 13, 15]
+    g = roi_pool_grad(data, rois, am, torch.tensor([1., 2, 3, 4], device=d).reshape(1, 2, 2, 1), 2, 2, 1.0)
+    exp = np.zeros(16, np.float32); exp[[5, 7, 13, 15]] = [1, 2, 3, 4]
+    assert g.flatten().tolist() == exp.tolist()
+    top, am = roi_pool(data, torch.tensor([[0, 100, 100, 120, 120]], dtype=torch.float32, device=d), 2, 2, 1.0)
+    assert bool((top == 0).all()) and bool((am == -1).all())
+
+
+@pytest.mark.parametrize("B,H,W,C,R,ph,pw,scale,seed", [(1, 38, 63, 64, 50, 7, 7, 1 / 16., 0), (2, 20, 30, 16, 40, 6, 6, 1 / 3., 1),
+                                                        (1, 10, 10, 3, 8, 7, 7, 1.0, 2), (1, 38, 63, 1024, 300, 7, 7, 1 / 16., 3)])
+def test_roi_pool_random_vs_oracle(B, H, W, C, R, ph, pw, scale, seed):
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool
+    rng = np.random.default_rng(seed)
+    data = rng.normal(size=(B, H, W, C)).astype(np.float32)
+    xy = rng.uniform(-20, max(H, W) / scale + 20, (R, 2)).astype(np.float32)
+    wh = rng.uniform(1, max(H, W) / scale / 2, (R, 2)).astype(np.float32)
+    rois = np.concatenate([rng.integers(0, B, (R, 1)).astype(np.float32), xy, xy + wh], 1)
+    rtop, ram = native.roi_pool(data, rois, ph, pw, scale)
+    dd = torch.tensor(data, device="cuda:0", requires_grad=True)
+    top, am = roi_pool(dd, torch.tensor(rois, device="cuda:0"), ph, pw, scale)
+    assert np.array_equal(am.cpu().numpy(), ram), "argmax must be bit-exact"
+    assert np.array_equal(top.detach().cpu().numpy(), rtop)
+    gtop = rng.normal(size=rtop.shape).astype(np.float32)
+    rgrad = native.roi_pool_grad((B, H, W, C), rois, ram, gtop, ph, pw, scale)
+    top.backward(torch.tensor(gtop, device="cuda:0"))     # gradient registration: [data_grad, None]
+    got = dd.grad.cpu().numpy()
+    assert np.abs(got - rgrad).max() <= 1e-5 * max(1.0, np.abs(rgrad).max())
+
+
+def test_roi_pool_attr_errors():
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool
+    from gossipnet_amd._lib import InvalidArgumentError
+    d = "cuda:0"
+    with pytest.raises(InvalidArgumentError):
+        roi_pool(torch.zeros(1, 4, 4, 1, device=d), torch.zeros(1, 5, device=d), -1, 2, 1.0)
+    with pytest.raises(InvalidArgumentError):
+        roi_pool(torch.zeros(4, 4, 1, device=d), torch.zeros(1, 5, device=d), 2, 2, 1.0)
+
+
+def test_graph_build_dense_10000():
+    """BASELINE config 4: N = 10000 synthetic dense image: edge list against the oracle, bit-exact."""
+    from tests.util import make_pair, make_image
+    net, orc = make_pair(80, 1)
+    batch = make_image(10000, 80, seed=0)
+    db = go.xyxy_to_boxdata(batch["dets"])
+    infer = {k: batch[k] for k in ("dets", "det_scores", "det_classes")}
+    net.run(infer)
+    pairs = net.neighbor_pair_idxs.cpu().numpy()
+    cnt = 0
+    for s in range(0, 10000, 1000):   # the oracle's dense N x N matrix, in row slabs
+        sl = tuple(x[s:s + 1000] for x in db)
+        m = go.iou(sl, db)
+        ref = np.argwhere(m >= np.float32(0.2))
+        ref[:, 0] += s
+        assert np.array_equal(pairs[cnt:cnt + len(ref)], ref)
+        cnt += len(ref)
+    assert cnt == len(pairs)
+    assert np.isfinite(net.prediction.cpu().numpy()).all()
