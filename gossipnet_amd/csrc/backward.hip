@@ -382,185 +382,217 @@ struct EdgeBwdArgs {
   long long o_w1, o_w2, o_b2;
 };
 
-__global__ void __launch_bounds__(256) edge_bwd(const EdgeBwdArgs a) {
+// edge_bwd: one workgroup (4 waves) per 64-edge tile; wave (mt, nt) owns edge rows [32mt, 32mt+32)
+// and feature columns [32nt, 32nt+32) of every 64-wide tensor (h1, h2, d h2, g1).  Per tile and wave:
+// 144 MFMAs (16 L1 + 32 L2 + 32 dW2 + 32 g1 + 16 dWp + 16 dP), two LDS tiles shared by the workgroup.
+// Memory discipline (the L1 stalls on repeated requests to a line that is still in flight):
+//   * centre-side gathers (rc, segment max, tie-split gradient) are issued once per DISTINCT centre --
+//     a detection's ~E/N consecutive edges share them;
+//   * the P tile is fetched once per workgroup (register prefetch one tile ahead -> LDS), not per wave;
+//   * the old d_pw values of the read-modify-write are prefetched at the top of the tile.
+// 70.6 KB of LDS -> 2 independent workgroups per CU.
+constexpr int EB_T = 64;
+
+__global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sWpT = smem;                     // [64][36]  Wp^T   (forward)
-  float* sW2T = sWpT + D_P * LD32;        // [64][68]  W2^T   (forward)
-  float* sW2 = sW2T + D_P * LD64;         // [64][68]  W2     (d h1 = d h2 . W2^T)
-  float* sWp = sW2 + D_P * LD64;          // [32][68]  Wp     (d P  = g1 . Wp^T)
-  float* sTiles = sWp + D_E * LD64;       // per wave: h1 [32][68], d2/g1 [32][68]
+  float* sWpT = smem;                     // [64][36]  Wp^T  (layer 1; also the B operand of d P)
+  float* sW2T = sWpT + D_P * LD32;        // [64][68]  W2^T  (layer 2; also the B operand of g1, strided)
+  float* sA = sW2T + D_P * LD64;          // [64][68]  h1, later g1
+  float* sB = sA + EB_T * LD64;           // [64][68]  d h2, later the K-split partials of d P
+  float* sP = sB + EB_T * LD64;           // [64][36]  P tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < D_P * D_E; i += 256) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
-  for (int i = tid; i < D_P * D_P; i += 256) {
-    sW2T[(i >> 6) * LD64 + (i & 63)] = a.w2t[i];
-    sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
-  }
-  for (int i = tid; i < D_E * D_P; i += 256) sWp[(i >> 6) * LD64 + (i & 63)] = a.w1[i];
-  __syncthreads();
-  float* sh1 = sTiles + wave * (2 * 32 * LD64);
-  float* sd2 = sh1 + 32 * LD64;
+  for (int i = tid; i < D_P * D_P; i += 256) sW2T[(i >> 6) * LD64 + (i & 63)] = a.w2t[i];
   const int col = lane & 31, half = lane >> 5;
-  const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
-  f32x16 aW2[2][2], aWp[1][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { aW2[i][0] = zero16(); aW2[i][1] = zero16(); }
-  aWp[0][0] = zero16(); aWp[0][1] = zero16();
-  float gb2a = 0.f, gb2b = 0.f;
-  const int ntiles = (a.n_edge + 31) / 32;
-  const int nwaves = gridDim.x * 4;
-  const int per = (ntiles + nwaves - 1) / nwaves;
-  const int gw = blockIdx.x * 4 + wave;
-  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  const int mt = wave >> 1, nt = wave & 1;
+  const float bias = a.b2[32 * nt + col];
+  const unsigned* pmw = reinterpret_cast<const unsigned*>(a.pm);   // [N][64] x {count, max bits}
+  f32x16 aW2 = zero16(), aWp = zero16();    // dW2 tile (mt, nt); dWp columns nt, edge half mt
+  float gb2 = 0.f;
+  const int ntiles = (a.n_edge + EB_T - 1) / EB_T;
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
+  // one-tile-ahead prefetch: indices of this wave's rows and this thread's two float4 of the P tile
+  int nx_c = -1, nx_n = -1;
+  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
+  const int prow0 = tid >> 3, pc4 = tid & 7;                        // P tile: thread -> (row, float4) x 2
+  if (t0 < t1) {
+    const int e = t0 * EB_T + 32 * mt + col;
+    if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
+    const int last = a.n_edge - 1;
+    pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + prow0, last) * D_E + 4 * pc4);
+    pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
+  }
+  __syncthreads();
   for (int t = t0; t < t1; ++t) {
-    const int e0 = t * 32;
-    const int e = e0 + (lane & 31);
-    const int my_c = (e < a.n_edge) ? a.edge_c[e] : -1;
-    const int my_n = (e < a.n_edge) ? a.edge_n[e] : -1;
-    // ---- recompute h1 (kept in registers for its ReLU mask) and h2
-    f32x16 h1[2];
+    const int e0 = t * EB_T + 32 * mt;                              // first edge of this wave's rows
+    const int my_c = nx_c, my_n = nx_n;
+    const int nrows = min(32, a.n_edge - e0);                       // may be <= 0 for the last tile
+    const int tvalid = min(EB_T, a.n_edge - t * EB_T) * D_E;        // valid floats of the d_pw tile
+    float* dpw_tile = a.d_pw + (size_t)(t * EB_T) * D_E;
+    *reinterpret_cast<float4*>(sP + prow0 * LD32 + 4 * pc4) = pf0;
+    *reinterpret_cast<float4*>(sP + (32 + prow0) * LD32 + 4 * pc4) = pf1;
+    nx_c = -1; nx_n = -1;
+    if (t + 1 < t1) {
+      const int e = e0 + EB_T + col;
+      if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
+      const int last = a.n_edge - 1;
+      pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + prow0, last) * D_E + 4 * pc4);
+      pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
+    }
+    float dold[8];                                                  // old d_pw values of the final RMW
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      dold[i] = (a.accumulate_dpw && idx < tvalid) ? dpw_tile[idx] : 0.f;
+    }
+    // ---- S1: h1 = relu(P . Wp + rc[c] + (c != n) rn[n]) for this wave's quadrant
+    f32x16 h1;
+    float pmv[16], dpv[16];
     {
+      int cprev = -2;
+      float rcv = 0.f, pmq = 0.f, dpq = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, half);
-        const int c = __shfl(my_c, row), n = __shfl(my_n, row);
-        float v0 = 0.f, v1 = 0.f;
-        if (c >= 0) {
-          v0 = a.rc[(size_t)c * D_P + col]; v1 = a.rc[(size_t)c * D_P + 32 + col];
-          if (c != n) { v0 += a.rn[(size_t)n * D_P + col]; v1 += a.rn[(size_t)n * D_P + 32 + col]; }
+        const int c = __shfl(my_c, crow(r, half)), n = __shfl(my_n, crow(r, half));
+        if (c != cprev) {                                            // once per distinct centre
+          const unsigned oc = (unsigned)max(c, 0) * D_P + 32 * nt + col;
+          rcv = a.rc[oc];
+          pmq = __uint_as_float(pmw[2 * oc + 1]);                    // segment max
+          dpq = a.d_pc[oc];                                          // tie-split gradient of the centre
+          cprev = c;
         }
-        h1[0][r] = v0; h1[1][r] = v1;
+        const float u = a.rn[(unsigned)max(n, 0) * D_P + 32 * nt + col];
+        h1[r] = (c != n) ? rcv + u : rcv;                            // self pair: n_feats zeroed (:371-374)
+        pmv[r] = pmq; dpv[r] = dpq;
       }
-      const int er = min(e, a.n_edge - 1);
-      const float* ap = a.pw + (size_t)er * D_E + 4 * half;
-      const float* b0 = sWpT + col * LD32 + 4 * half;
-      const float* b1 = b0 + 32 * LD32;
+    }
+    __syncthreads();                                                // B0: P tile in LDS
+    {
+      const float* ap = sP + (32 * mt + col) * LD32 + 4 * half;
+      const float* bp = sWpT + (32 * nt + col) * LD32 + 4 * half;
 #pragma unroll
       for (int k = 0; k < D_E; k += 8) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
-        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1[0], 0, 0, 0);
-        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1[1], 0, 0, 0);
-        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1[0], 0, 0, 0);
-        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1[1], 0, 0, 0);
-        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1[0], 0, 0, 0);
-        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1[1], 0, 0, 0);
-        h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1[0], 0, 0, 0);
-        h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1[1], 0, 0, 0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + k);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, h1, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, h1, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, h1, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, h1, 0, 0, 0);
       }
     }
-    wave_lds_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      h1[0][r] = fmaxf(h1[0][r], 0.f); h1[1][r] = fmaxf(h1[1][r], 0.f);
-      sh1[row * LD64 + col] = h1[0][r];
-      sh1[row * LD64 + 32 + col] = h1[1][r];
+      h1[r] = fmaxf(h1[r], 0.f);
+      sA[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = h1[r];
     }
-    wave_lds_sync();
-    f32x16 h2a = zero16(), h2b = zero16();
-    mma_abt<D_P>(h2a, sh1, LD64, sW2T, LD64, lane);
-    mma_abt<D_P>(h2b, sh1, LD64, sW2T + 32 * LD64, LD64, lane);
-    // ---- d h2 (pre-activation): SegmentMax tie split, then ReLU mask
+    __syncthreads();                                                // B1: h1 tile complete
+    // ---- S2: h2 = relu(h1 . W2 + b2); d h2 = SegmentMax tie split + ReLU mask
+    f32x16 d2 = zero16();
+    mma_abt<D_P>(d2, sA + 32 * mt * LD64, LD64, sW2T + 32 * nt * LD64, LD64, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      const int c = __shfl(my_c, row);
-      float d0 = 0.f, d1 = 0.f;
-      if (c >= 0) {
-        const float v0 = fmaxf(h2a[r] + bias0, 0.f), v1 = fmaxf(h2b[r] + bias1, 0.f);
-        const size_t o = (size_t)c * D_P + col;
-        const float p0 = __uint_as_float((unsigned)(a.pm[o] >> 32));
-        const float p1 = __uint_as_float((unsigned)(a.pm[o + 32] >> 32));
-        if (v0 > 0.f && v0 == p0) d0 = a.d_pc[o];
-        if (v1 > 0.f && v1 == p1) d1 = a.d_pc[o + 32];
-      }
-      sd2[row * LD64 + col] = d0;
-      sd2[row * LD64 + 32 + col] = d1;
-      gb2a += d0; gb2b += d1;
+      const float v = fmaxf(d2[r] + bias, 0.f);
+      const bool ok = crow(r, half) < nrows;
+      const float x = (ok && v > 0.f && v == pmv[r]) ? dpv[r] : 0.f;
+      gb2 += x;
+      sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
     }
-    wave_lds_sync();
-    mma_xty<2, 2>(aW2, sh1, LD64, sd2, LD64, lane);                 // d W2 += h1^T . d h2
-    f32x16 g1a = zero16(), g1b = zero16();                           // g1 = (d h2 . W2^T) * (h1 > 0)
-    mma_abt<D_P>(g1a, sd2, LD64, sW2, LD64, lane);
-    mma_abt<D_P>(g1b, sd2, LD64, sW2 + 32 * LD64, LD64, lane);
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      const float v0 = h1[0][r] > 0.f ? g1a[r] : 0.f, v1 = h1[1][r] > 0.f ? g1b[r] : 0.f;
-      sd2[row * LD64 + col] = v0;                                    // g1 staged over d h2
-      sd2[row * LD64 + 32 + col] = v1;
-      // g1 goes to HBM: blk_bwd_pre turns it into the centre (segment) and neighbour (reversed-edge
-      // gather) sums in a fixed order -- no float atomics
-      const int ee = e0 + row;
-      if (ee < a.n_edge) {
-        a.d_g1[(size_t)ee * D_P + col] = v0;
-        a.d_g1[(size_t)ee * D_P + 32 + col] = v1;
-      }
-    }
-    wave_lds_sync();
-    // ---- d Wp += P^T . g1 (P read straight from global: rows of the tile are contiguous)
+    __syncthreads();                                                // B2: d h2 tile complete
+    // ---- S3: d W2[mt-th row tile][nt-th column tile] += h1^T . d h2 over the 64 edges
     {
-      const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + h;
-        const int er = min(e0 + row, a.n_edge - 1);
-        const float x = a.pw[(size_t)er * D_E + r];
-        const float y0 = sd2[row * LD64 + r], y1 = sd2[row * LD64 + 32 + r];
-        aWp[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y0, aWp[0][0], 0, 0, 0);
-        aWp[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y1, aWp[0][1], 0, 0, 0);
+      const float* X = sA + 32 * mt + col;
+      const float* Y = sB + 32 * nt + col;
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) {
+        const int row = 2 * kk + half;
+        aW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(X[row * LD64], Y[row * LD64], aW2, 0, 0, 0);
       }
     }
-    // ---- d P = g1 . Wp^T
+    // ---- S4: g1 = (d h2 . W2^T) * (h1 > 0);  B[k = h2 f][n = h1 f] = W2[h1 f][h2 f] = sW2T[h2 f][h1 f]
+    f32x16 g1 = zero16();
+    {
+      const float* ap = sB + (32 * mt + col) * LD64 + 4 * half;
+      const float* bp = sW2T + (4 * half) * LD64 + 32 * nt + col;
+#pragma unroll
+      for (int k = 0; k < D_P; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD64], g1, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD64], g1, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD64], g1, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD64], g1, 0, 0, 0);
+      }
+    }
+    __syncthreads();                                                // B3: every read of h1 (sA) is done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      const float v = h1[r] > 0.f ? g1[r] : 0.f;
+      sA[(32 * mt + row) * LD64 + 32 * nt + col] = v;
+      // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order
+      if (row < nrows) a.d_g1[(size_t)(e0 + row) * D_P + 32 * nt + col] = v;
+    }
+    __syncthreads();                                                // B4: g1 tile complete
+    // ---- S6: d Wp[:, column tile nt] += P^T . g1 over edge half mt
+    {
+      const float* X = sP + (32 * mt) * LD32 + col;
+      const float* Y = sA + (32 * mt) * LD64 + 32 * nt + col;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(X[(2 * kk + half) * LD32], Y[(2 * kk + half) * LD64], aWp, 0, 0, 0);
+    }
+    // ---- S7: d P[rows mt] = g1 . Wp^T, K split over nt; partials through sB (d h2 is consumed)
     {
       f32x16 acc = zero16();
-      mma_abt<D_P>(acc, sd2, LD64, sWp, LD64, lane);
+      const float* ap = sA + (32 * mt + col) * LD64 + 32 * nt + 4 * half;
+      const float* bp = sWpT + (32 * nt + 4 * half) * LD32 + col;   // Wp[pf = col][f] = sWpT[f][pf]
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ee = e0 + crow(r, half);
-        if (ee < a.n_edge) {
-          float* dst = a.d_pw + (size_t)ee * D_E + col;
-          *dst = a.accumulate_dpw ? (*dst + acc[r]) : acc[r];
-        }
+      for (int k = 0; k < 32; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD32], acc, 0, 0, 0);
       }
+      float* part = sB + nt * (EB_T * D_E);                          // [2][64][32]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(32 * mt + crow(r, half)) * D_E + col] = acc[r];
     }
+    __syncthreads();                                                // B5: partials complete; sA, sP free
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < tvalid) dpw_tile[idx] = dold[i] + (sB[idx] + sB[EB_T * D_E + idx]);
+    }
+    // (the next tile's S2 writes sB only behind its B0/B1, i.e. after every wave finished this loop)
   }
-  // ---- workgroup reduction of the weight-gradient accumulators (waves 1..3 -> wave 0 through LDS)
-  __syncthreads();
-  float* red = sTiles;    // >= 3 * 1024 floats
+  // ---- partial weight gradients of this workgroup
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    f32x16& acc = (k < 4) ? aW2[k >> 1][k & 1] : aWp[0][k - 4];
-    if (wave > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane] + red[1024 + r * 64 + lane] + red[2048 + r * 64 + lane];
-      if (k < 4) store_acc(ar + a.o_w2 + (size_t)(32 * (k >> 1)) * D_P + 32 * (k & 1), D_P, acc, lane);
-      else store_acc(ar + a.o_w1 + 32 * (k - 4), D_P, acc, lane);     // rows 0-31 of pw_fc1
-    }
-    __syncthreads();
-  }
-  // bias gradient of pw_fc2: every lane holds the sum over its rows; fold halves and waves
-  red[wave * 128 + half * 64 + col] = gb2a;
-  red[wave * 128 + half * 64 + 32 + col] = gb2b;
+  store_acc(ar + a.o_w2 + (size_t)(32 * mt) * D_P + 32 * nt, D_P, aW2, lane);
   __syncthreads();
+  float* red = sA;
+  if (mt == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[nt * 1024 + r * 64 + lane] = aWp[r];
+  }
+  red[2048 + wave * 64 + lane] = gb2;
+  __syncthreads();
+  if (mt == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aWp[r] += red[nt * 1024 + r * 64 + lane];
+    store_acc(ar + a.o_w1 + 32 * nt, D_P, aWp, lane);               // rows 0-31 of pw_fc1
+  }
   if (tid < D_P) {
+    // column tid: waves (mt = 0,1; nt = tid >> 5), both half-waves
+    const int n2 = tid >> 5, c2 = tid & 31;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += red[w * 128 + tid] + red[w * 128 + 64 + tid];
+    for (int m2 = 0; m2 < 2; ++m2) v += red[2048 + (2 * m2 + n2) * 64 + c2] + red[2048 + (2 * m2 + n2) * 64 + 32 + c2];
     ar[a.o_b2 + tid] = v;
   }
 }
 
-constexpr size_t kEdgeBwdSmem =
-    (size_t)(D_P * LD32 + 2 * D_P * LD64 + D_E * LD64 + 4 * 2 * 32 * LD64) * sizeof(float);
+constexpr size_t kEdgeBwdSmem = (size_t)(D_P * LD32 + D_P * LD64 + 2 * EB_T * LD64 + EB_T * LD32) * sizeof(float);
 
 // ------------------------------------------------------------------------------------------
 struct PwBwdArgs {
@@ -745,7 +777,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   const int ntile_n = (N + 31) / 32;
   const int g_node = min(ntile_n, 128);
   const int etiles = (E + 31) / 32;
-  const int g_edge = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (etiles + 3) / 4)) : 0;
+  const int g_edge = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + EB_T - 1) / EB_T)) : 0;
   const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
   const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + 255) / 256)) : 0;
 

@@ -12,7 +12,7 @@ constexpr int D_H = 256;   // pwfeat_dim
 constexpr int D_E = 32;    // pwfeat_narrow_dim
 constexpr int D_HEAD = 128;
 // partial weight-gradient copies per parameter (upper bound on writer workgroups per kernel)
-constexpr int GNET_ARENA_PARTIALS = 256;
+constexpr int GNET_ARENA_PARTIALS = 512;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

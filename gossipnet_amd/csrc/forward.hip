@@ -201,100 +201,104 @@ struct EdgeFwdArgs {
   unsigned long long* pm;        // [N,64], zeroed
 };
 
-__device__ __forceinline__ void edge_tile_h1(const EdgeFwdArgs& a, int e0, int lane, int my_c, int my_n,
-                                             const float* sWp, f32x16 (&h1)[2]) {
-  const int col = lane & 31, half = lane >> 5;
-  // accumulator init = per-node halves of pw_fc1 (gathered), then += P . Wp on the matrix core
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = crow(r, half);
-    const int c = __shfl(my_c, row), n = __shfl(my_n, row);
-    float v0 = 0.f, v1 = 0.f;
-    if (c >= 0) {
-      v0 = a.rc[(size_t)c * D_P + col]; v1 = a.rc[(size_t)c * D_P + 32 + col];
-      if (c != n) { v0 += a.rn[(size_t)n * D_P + col]; v1 += a.rn[(size_t)n * D_P + 32 + col]; }  // :371-374
-    }
-    h1[0][r] = v0; h1[1][r] = v1;
-  }
-  const int er = min(e0 + (lane & 31), a.n_edge - 1);
-  const float* ap = a.pw + (size_t)er * D_E + 4 * half;
-  const float* b0 = sWp + (lane & 31) * E_LD1 + 4 * half;
-  const float* b1 = b0 + 32 * E_LD1;
-#pragma unroll
-  for (int k = 0; k < D_E; k += 8) {
-    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
-    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
-    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1[0], 0, 0, 0);
-    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1[1], 0, 0, 0);
-    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1[0], 0, 0, 0);
-    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1[1], 0, 0, 0);
-    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1[0], 0, 0, 0);
-    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1[1], 0, 0, 0);
-    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1[0], 0, 0, 0);
-    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1[1], 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { h1[0][r] = fmaxf(h1[0][r], 0.f); h1[1][r] = fmaxf(h1[1][r], 0.f); }
-}
+// One workgroup (4 waves) per 64-edge tile; wave (mt, nt) owns edge rows [32mt, 32mt+32) and feature
+// columns [32nt, 32nt+32).  48 MFMAs per wave and tile; 53 KB of LDS -> 3 independent workgroups per CU.
+// The centre row rc[c] is fetched once per distinct centre and the P tile once per workgroup (the L1
+// stalls on repeated requests to a line that is still in flight).
+constexpr int EF_T = 64;
 
-__global__ void __launch_bounds__(256) edge_fwd(const EdgeFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float sWp[D_P * E_LD1];      // [64][36]
-  __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]
-  __shared__ __attribute__((aligned(16))) float sH1[4][32 * E_LD2];    // per wave [32][68]
+__global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sWp[D_P * E_LD1];      // [64][36]  Wp^T
+  __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]  W2^T
+  __shared__ __attribute__((aligned(16))) float sH1[EF_T * E_LD2];     // [64][68]
+  __shared__ __attribute__((aligned(16))) float sP[EF_T * E_LD1];      // [64][36]  P tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < D_P * D_E; i += 256) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
   for (int i = tid; i < D_P * D_P; i += 256) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
-  __syncthreads();
   const int col = lane & 31, half = lane >> 5;
-  const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
-  const int ntiles = (a.n_edge + 31) / 32;
-  const int nwaves = gridDim.x * 4;
-  const int per = (ntiles + nwaves - 1) / nwaves;
-  const int gw = blockIdx.x * 4 + wave;
-  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
-  float* sh = sH1[wave];
-  int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned c0 = 0, c1 = 0;   // running (max, count) of this lane
+  const int mt = wave >> 1, nt = wave & 1;
+  const float bias = a.b2[32 * nt + col];
+  const int ntiles = (a.n_edge + EF_T - 1) / EF_T;
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
+  int nx_c = -1, nx_n = -1;
+  if (t0 < t1) {
+    const int e = t0 * EF_T + 32 * mt + col;
+    if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
+  }
+  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;          // P tile prefetch (one tile ahead)
+  const int prow0 = tid >> 3, pc4 = tid & 7;
+  if (t0 < t1) {
+    const int last = a.n_edge - 1;
+    pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EF_T + prow0, last) * D_E + 4 * pc4);
+    pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EF_T + 32 + prow0, last) * D_E + 4 * pc4);
+  }
+  int cur = -1; float mx = 0.f; unsigned cnt = 0;      // running (max, tie count) of this lane's column
+  unsigned long long* pm_col = a.pm + 32 * nt + col;
+  __syncthreads();
   for (int t = t0; t < t1; ++t) {
-    const int e0 = t * 32;
-    const int e = e0 + (lane & 31);
-    const int my_c = (e < a.n_edge) ? a.edge_c[e] : -1;
-    const int my_n = (e < a.n_edge) ? a.edge_n[e] : -1;
-    f32x16 h1[2];
-    edge_tile_h1(a, e0, lane, my_c, my_n, sWp, h1);
-    wave_lds_sync();   // previous tile's operand reads are complete
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      sh[row * E_LD2 + col] = h1[0][r];
-      sh[row * E_LD2 + 32 + col] = h1[1][r];
+    const int e0 = t * EF_T + 32 * mt;
+    const int my_c = nx_c, my_n = nx_n;
+    const int nrows = min(32, a.n_edge - e0);
+    *reinterpret_cast<float4*>(sP + prow0 * E_LD1 + 4 * pc4) = pf0;
+    *reinterpret_cast<float4*>(sP + (32 + prow0) * E_LD1 + 4 * pc4) = pf1;
+    nx_c = -1; nx_n = -1;
+    if (t + 1 < t1) {
+      const int e = e0 + EF_T + col;
+      if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
+      const int last = a.n_edge - 1;
+      pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EF_T + prow0, last) * D_E + 4 * pc4);
+      pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EF_T + 32 + prow0, last) * D_E + 4 * pc4);
     }
-    wave_lds_sync();
-    f32x16 h2a = zero16(), h2b = zero16();
-    mma_abt<D_P>(h2a, sh, E_LD2, sW2, E_LD2, lane);
-    mma_abt<D_P>(h2b, sh, E_LD2, sW2 + 32 * E_LD2, E_LD2, lane);
+    // h1 = relu(P . Wp + rc[c] + (c != n) rn[n]): accumulator starts from the gathered per-node halves
+    f32x16 h1;
+    {
+      int cprev = -2;
+      float rcv = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = __shfl(my_c, crow(r, half)), n = __shfl(my_n, crow(r, half));
+        if (c != cprev) { rcv = a.rc[(unsigned)max(c, 0) * D_P + 32 * nt + col]; cprev = c; }   // once per centre
+        const float u = a.rn[(unsigned)max(n, 0) * D_P + 32 * nt + col];
+        h1[r] = (c != n) ? rcv + u : rcv;                            // :371-374
+      }
+    }
+    __syncthreads();                                                 // P tile in LDS
+    {
+      const float* ap = sP + (32 * mt + col) * E_LD1 + 4 * half;
+      const float* bp = sWp + (32 * nt + col) * E_LD1 + 4 * half;
+#pragma unroll
+      for (int k = 0; k < D_E; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + k);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, h1, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, h1, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, h1, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, h1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sH1[(32 * mt + crow(r, half)) * E_LD2 + 32 * nt + col] = fmaxf(h1[r], 0.f);
+    __syncthreads();
+    f32x16 h2 = zero16();
+    mma_abt<D_P>(h2, sH1 + 32 * mt * E_LD2, E_LD2, sW2 + 32 * nt * E_LD2, E_LD2, lane);
+    // streaming (max, tie count) per (centre, column); rows ascend, centres are sorted
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, half);
       const int c = __shfl(my_c, row);
-      if (c < 0) continue;
-      const float v0 = fmaxf(h2a[r] + bias0, 0.f), v1 = fmaxf(h2b[r] + bias1, 0.f);
+      if (row >= nrows) continue;
+      const float v = fmaxf(h2[r] + bias, 0.f);
       if (c != cur) {
-        if (cur >= 0) {
-          pm_flush(a.pm + (size_t)cur * D_P + col, m0, c0);
-          pm_flush(a.pm + (size_t)cur * D_P + 32 + col, m1, c1);
-        }
-        cur = c; m0 = v0; c0 = 1; m1 = v1; c1 = 1;
+        if (cur >= 0) pm_flush(pm_col + (size_t)cur * D_P, mx, cnt);
+        cur = c; mx = v; cnt = 1;
       } else {
-        if (v0 > m0) { m0 = v0; c0 = 1; } else if (v0 == m0) { ++c0; }
-        if (v1 > m1) { m1 = v1; c1 = 1; } else if (v1 == m1) { ++c1; }
+        if (v > mx) { mx = v; cnt = 1; } else if (v == mx) { ++cnt; }
       }
     }
+    __syncthreads();      // h1 tile consumed before the next tile overwrites it
   }
-  if (cur >= 0) {
-    pm_flush(a.pm + (size_t)cur * D_P + col, m0, c0);
-    pm_flush(a.pm + (size_t)cur * D_P + 32 + col, m1, c1);
-  }
+  if (cur >= 0) pm_flush(pm_col + (size_t)cur * D_P, mx, cnt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -481,8 +485,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   }
 
   const int ntile_n = (N + 31) / 32;
-  const int etiles = (E + 31) / 32;
-  const int egrid = max(1, min(512, (etiles + 3) / 4));
+  const int egrid = max(1, min(768, (E + EF_T - 1) / EF_T));
   for (int b = 0; b <= B; ++b) {
     // node stage between edge kernels: finish block b (b >= 1), start block b+1 (b < B)
     NodeFwdArgs n;
