@@ -680,8 +680,9 @@ constexpr size_t kPwBwdSmem = (size_t)(2 * 32 * LD256 + 32 * LD32) * sizeof(floa
 // One wave per (edge chunk, 64-column slice); the class rows accumulate in LDS (single wave ->
 // plain read-modify-write, deterministic), the 7 geometry rows and the bias in registers.
 struct PwW1Args {
-  int n_edge; int cprime; int multiclass;
-  const int* edge_c; const int* edge_n; const float* scores; const int* classes; const float* geo;
+  int n_edge; int cprime;
+  const int4* einfo;      // per edge: fc1 row of the centre / neighbour score column, the two scores
+  const float* geo;
   const float* d_h1;
   float* arena; long long stride;
   long long o_w1, o_b1;
@@ -697,23 +698,27 @@ __global__ void __launch_bounds__(64) pw_bwd_w1(const PwW1Args a) {
   float gb = 0.f;
   const int per = (a.n_edge + gridDim.x - 1) / gridDim.x;
   const int eb = blockIdx.x * per, ee = min(a.n_edge, eb + per);
-  for (int e = eb; e < ee; ++e) {
-    const float d = a.d_h1[(size_t)e * D_H + fcol];
-    const int c = a.edge_c[e], n = a.edge_n[e];
-    float sc = a.scores[c], sn = a.scores[n];
-    int rc = 0, rn = 1;
-    if (a.multiclass) {
-      const int cc = a.classes[c] - 1, cn = a.classes[n] - 1;
-      if (cc >= 0 && cc < a.cprime) rc = cc; else sc = 0.f;
-      if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
+  constexpr int U = 4;                                            // edges in flight per wave
+  for (int e0 = eb; e0 < ee; e0 += U) {
+    float d[U]; int4 inf[U]; float4 ga[U], gc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                                 // independent loads first (wave-uniform
+      const int e = min(e0 + u, ee - 1);                          // addresses except the d_h1 column)
+      d[u] = (e0 + u < ee) ? a.d_h1[(size_t)e * D_H + fcol] : 0.f;
+      inf[u] = a.einfo[e];
+      ga[u] = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
+      gc[u] = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
     }
-    sAcc[rc * 64 + lane] = fmaf(sc, d, sAcc[rc * 64 + lane]);
-    sAcc[rn * 64 + lane] = fmaf(sn, d, sAcc[rn * 64 + lane]);
-    const float4 g0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
-    const float4 g1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
-    g[0] = fmaf(g0.x, d, g[0]); g[1] = fmaf(g0.y, d, g[1]); g[2] = fmaf(g0.z, d, g[2]); g[3] = fmaf(g0.w, d, g[3]);
-    g[4] = fmaf(g1.x, d, g[4]); g[5] = fmaf(g1.y, d, g[5]); g[6] = fmaf(g1.z, d, g[6]);
-    gb += d;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                                 // then the in-order accumulation
+      const float dd = d[u];
+      const int rc = inf[u].x, rn = inf[u].y;
+      sAcc[rc * 64 + lane] = fmaf(__int_as_float(inf[u].z), dd, sAcc[rc * 64 + lane]);
+      sAcc[rn * 64 + lane] = fmaf(__int_as_float(inf[u].w), dd, sAcc[rn * 64 + lane]);
+      g[0] = fmaf(ga[u].x, dd, g[0]); g[1] = fmaf(ga[u].y, dd, g[1]); g[2] = fmaf(ga[u].z, dd, g[2]); g[3] = fmaf(ga[u].w, dd, g[3]);
+      g[4] = fmaf(gc[u].x, dd, g[4]); g[5] = fmaf(gc[u].y, dd, g[5]); g[6] = fmaf(gc[u].z, dd, g[6]);
+      gb += dd;
+    }
   }
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
   for (int r = 0; r < nrow; ++r) ar[a.o_w1 + (size_t)r * D_H + fcol] = sAcc[r * 64 + lane];
@@ -779,7 +784,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + EB_T - 1) / EB_T)) : 0;
   const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
-  const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + 255) / 256)) : 0;
+  const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + 255) / 256)) : 0;   // x4 column slices
 
   static bool attr_set = false;
   if (!attr_set) {
@@ -838,9 +843,9 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
     GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<<<g_pw, 512, kPwBwdSmem, s>>>(p));
     PwW1Args w;
-    w.n_edge = E; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;
-    w.edge_c = buf->edge_c; w.edge_n = buf->edge_n; w.scores = in->det_scores; w.classes = in->det_classes;
-    w.geo = buf->geo; w.d_h1 = buf->d_h1; w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1;
+    w.n_edge = E; w.cprime = L.cprime;
+    w.einfo = (const int4*)buf->einfo; w.geo = buf->geo; w.d_h1 = buf->d_h1;
+    w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1;
     const size_t smem = (size_t)2 * L.cprime * 64 * sizeof(float);
     if (smem > 160 * 1024) return GNET_ERR_UNSUPPORTED;
     GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_bwd_w1<<<dim3(g_w1, 4), 64, smem, s>>>(w));

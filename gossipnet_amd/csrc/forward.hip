@@ -67,7 +67,7 @@ struct PwFwdArgs {
   const float* w1; const float* b1;     // natural [dpw,256]
   const float* w2t; const float* b2;    // transposed [256,256]
   const float* w3t; const float* b3;    // transposed [32,256]
-  float* geo; float* h1; float* h2; float* pw;
+  float* geo; int4* einfo; float* h1; float* h2; float* pw;
   int training;
 };
 
@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
           float4* gp = reinterpret_cast<float4*>(a.geo + (size_t)e * 8);
           gp[0] = make_float4(g[0], g[1], g[2], g[3]);
           gp[1] = make_float4(g[4], g[5], g[6], 0.f);
+          a.einfo[e] = make_int4(rc, rn, __float_as_int(sc), __float_as_int(sn));
         }
       }
       sSc[tid] = sc; sSn[tid] = sn; sRc[tid] = rc; sRn[tid] = rn;
@@ -474,7 +475,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     a.w1 = params + L.pw1; a.b1 = params + L.pb1;
     a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
     a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
-    a.geo = buf->geo; a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
+    a.geo = buf->geo; a.einfo = (int4*)buf->einfo; a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
     const int tiles = (E + PW_T - 1) / PW_T;
     static bool attr_set = false;
     if (!attr_set) {

@@ -1,6 +1,6 @@
 // RoiPool / RoiPoolGrad (Fast R-CNN max RoI pooling, NHWC) -- replaces
 // nms_net/roi_pooling_layer/roi_pooling_op.cc:128-187 (forward) and :374-449 (backward);
-// the CPU kernels are the oracle (the reference CUDA forward reads the wrong image for
+// the CPU kernels define the semantics (the reference CUDA forward reads the wrong image for
 // batch index > 0, roi_pooling_op_gpu.cu:75-76 -- not reproduced).
 //
 // Forward: one thread per output element (r, ph, pw, c), channel fastest -> coalesced reads of
@@ -8,7 +8,7 @@
 // PH*PW*C*(4+4) bytes and reads ~roi_area*C*4 bytes (mostly from L2: the map is small).
 // Backward: the reference scans all R ROIs for every input element (O(H*W*C*R)); here every
 // pooled element scatters its gradient to argmax with one float atomic (O(R*PH*PW*C)); the
-// summation order is not fixed, so bottom_diff equals the oracle to rounding (<= 1e-5 relative),
+// summation order is not fixed, so bottom_diff equals the CPU kernel to rounding (<= 1e-5 relative),
 // exactly when no input element is the argmax of more than one bin.
 #include "common.hpp"
 

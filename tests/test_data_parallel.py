@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the data-parallel glue (shard -> local gradient -> ONE
+all-reduce of the flat buffer) against the single-process result.  The local gradient is produced by
+the CPU oracle here (there is no GPU); the HIP path plugs into exactly the same collective."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gossipnet_amd.data_parallel import allreduce_gradients, broadcast_parameters, shard_images
+from gossipnet_amd.synthetic import make_image
+from oracle import gnet_oracle as go
+
+C_, B_, N_IMG = 1, 1, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _images():
+    return [make_image(12 + 3 * i, C_, seed=i) for i in range(N_IMG)]
+
+
+def _local_grad(images, scale):
+    orc = go.GnetOracle(C_, B_)
+    total = None
+    for im in images:
+        _, g = orc.forward_backward(im)
+        flat = go.flatten(g, C_, B_).astype(np.float64)
+        total = flat if total is None else total + flat
+    return torch.tensor(total * scale, dtype=torch.float32)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    params = torch.full((8,), float(rank))
+    broadcast_parameters(params, dist, src=0)
+    assert float(params.sum()) == 0.0                      # replicas start from rank 0's parameters
+    mine = shard_images(_images(), rank, world)
+    g = _local_grad(mine, 1.0 / N_IMG)                     # Gnet.grad_scale = 1 / (images of the global step)
+    allreduce_gradients(g, dist)
+    if rank == 0:
+        np.save(out, g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_equals_single_process(tmp_path):
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    ref = _local_grad(_images(), 1.0 / N_IMG).numpy()      # mean over the 4 images
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_shard_images_lpt_balances_edge_counts():
+    imgs = list(range(8))
+    costs = [100, 10, 10, 10, 90, 20, 20, 20]
+    shards = [shard_images(imgs, r, 2, costs) for r in range(2)]
+    assert sorted(shards[0] + shards[1]) == imgs
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert abs(loads[0] - loads[1]) <= 20
+    assert shard_images(imgs, 1, 4) == [1, 5]

@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from tests.util import make_pair, rel_err, make_image
 from oracle import gnet_oracle as go
 for (n, c, b, seed) in [(20, 1, 1, 0), (64, 1, 1, 2), (64, 1, 2, 2), (64, 80, 1, 2), (64, 80, 2, 2), (200, 1, 1, 3), (33,1,2,4)]:

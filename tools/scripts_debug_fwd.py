@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from tests.util import make_pair, rel_err, make_image
 for (n, c, b, seed) in [(6, 1, 1, 0), (64, 80, 2, 2), (300, 80, 16, 0), (2000, 80, 16, 0)]:
     net, orc = make_pair(c, b)

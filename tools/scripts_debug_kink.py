@@ -1,6 +1,6 @@
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from tests.util import make_pair, rel_err, make_image
 from oracle import gnet_oracle as go
 c, b, n = 80, 1, 64
