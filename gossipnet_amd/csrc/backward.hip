@@ -423,6 +423,17 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + prow0, last) * D_E + 4 * pc4);
     pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
   }
+  // neighbour rows rn[n] of the next tile and the centre-side values of its first centre are gathered
+  // in the middle of the current tile (hidden under its MFMA phases)
+  float rnv[16];
+  int c_first = -2; float rc_first = 0.f, pm_first = 0.f, dp_first = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
+  {
+    c_first = __shfl(nx_c, crow(0, half));
+    const unsigned oc = (unsigned)max(c_first, 0) * D_P + 32 * nt + col;
+    rc_first = a.rc[oc]; pm_first = __uint_as_float(pmw[2 * oc + 1]); dp_first = a.d_pc[oc];
+  }
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * EB_T + 32 * mt;                              // first edge of this wave's rows
@@ -440,18 +451,12 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + prow0, last) * D_E + 4 * pc4);
       pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
     }
-    float dold[8];                                                  // old d_pw values of the final RMW
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      dold[i] = (a.accumulate_dpw && idx < tvalid) ? dpw_tile[idx] : 0.f;
-    }
     // ---- S1: h1 = relu(P . Wp + rc[c] + (c != n) rn[n]) for this wave's quadrant
     f32x16 h1;
     float pmv[16], dpv[16];
     {
-      int cprev = -2;
-      float rcv = 0.f, pmq = 0.f, dpq = 0.f;
+      int cprev = c_first;                                           // prefetched during the previous tile
+      float rcv = rc_first, pmq = pm_first, dpq = dp_first;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = __shfl(my_c, crow(r, half)), n = __shfl(my_n, crow(r, half));
@@ -462,8 +467,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
           dpq = a.d_pc[oc];                                          // tie-split gradient of the centre
           cprev = c;
         }
-        const float u = a.rn[(unsigned)max(n, 0) * D_P + 32 * nt + col];
-        h1[r] = (c != n) ? rcv + u : rcv;                            // self pair: n_feats zeroed (:371-374)
+        h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // self pair: n_feats zeroed (:371-374)
         pmv[r] = pmq; dpv[r] = dpq;
       }
     }
@@ -481,10 +485,12 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
         h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, h1, 0, 0, 0);
       }
     }
+    unsigned h1mask = 0;                                            // ReLU mask of h1 (bit r = row crow(r, half))
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      h1[r] = fmaxf(h1[r], 0.f);
-      sA[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = h1[r];
+      const float v = fmaxf(h1[r], 0.f);
+      h1mask |= (v > 0.f ? 1u : 0u) << r;
+      sA[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = v;
     }
     __syncthreads();                                                // B1: h1 tile complete
     // ---- S2: h2 = relu(h1 . W2 + b2); d h2 = SegmentMax tie split + ReLU mask
@@ -499,6 +505,14 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
     }
     __syncthreads();                                                // B2: d h2 tile complete
+    // gathers of the NEXT tile (its indices arrived long ago): consumed at the top of the next iteration
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
+    {
+      c_first = __shfl(nx_c, crow(0, half));
+      const unsigned oc = (unsigned)max(c_first, 0) * D_P + 32 * nt + col;
+      rc_first = a.rc[oc]; pm_first = __uint_as_float(pmw[2 * oc + 1]); dp_first = a.d_pc[oc];
+    }
     // ---- S3: d W2[mt-th row tile][nt-th column tile] += h1^T . d h2 over the 64 edges
     {
       const float* X = sA + 32 * mt + col;
@@ -524,10 +538,16 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       }
     }
     __syncthreads();                                                // B3: every read of h1 (sA) is done
+    float dold[8];                                                  // old d_pw values of the final RMW
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      dold[i] = (a.accumulate_dpw && idx < tvalid) ? dpw_tile[idx] : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, half);
-      const float v = h1[r] > 0.f ? g1[r] : 0.f;
+      const float v = ((h1mask >> r) & 1u) ? g1[r] : 0.f;
       sA[(32 * mt + row) * LD64 + 32 * nt + col] = v;
       // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order
       if (row < nrows) a.d_g1[(size_t)(e0 + row) * D_P + 32 * nt + col] = v;
@@ -780,7 +800,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   void* prof = buf->profiler;
   const long long stride = L.total;
   const int ntile_n = (N + 31) / 32;
-  const int g_node = min(ntile_n, 128);
+  const int g_node = min(ntile_n, 256);
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + EB_T - 1) / EB_T)) : 0;
   const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;

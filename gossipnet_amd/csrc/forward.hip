@@ -236,6 +236,13 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
   }
   int cur = -1; float mx = 0.f; unsigned cnt = 0;      // running (max, tie count) of this lane's column
   unsigned long long* pm_col = a.pm + 32 * nt + col;
+  PmPending pend; pend.addr = nullptr; pend.key = 0; pend.old = 0;
+  // neighbour rows rn[n] of the next tile and rc of its first centre: gathered one tile ahead
+  float rnv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
+  int c_first = __shfl(nx_c, crow(0, half));
+  float rc_first = a.rc[(unsigned)max(c_first, 0) * D_P + 32 * nt + col];
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * EF_T + 32 * mt;
@@ -254,14 +261,13 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
     // h1 = relu(P . Wp + rc[c] + (c != n) rn[n]): accumulator starts from the gathered per-node halves
     f32x16 h1;
     {
-      int cprev = -2;
-      float rcv = 0.f;
+      int cprev = c_first;
+      float rcv = rc_first;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = __shfl(my_c, crow(r, half)), n = __shfl(my_n, crow(r, half));
         if (c != cprev) { rcv = a.rc[(unsigned)max(c, 0) * D_P + 32 * nt + col]; cprev = c; }   // once per centre
-        const float u = a.rn[(unsigned)max(n, 0) * D_P + 32 * nt + col];
-        h1[r] = (c != n) ? rcv + u : rcv;                            // :371-374
+        h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // :371-374
       }
     }
     __syncthreads();                                                 // P tile in LDS
@@ -281,6 +287,11 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sH1[(32 * mt + crow(r, half)) * E_LD2 + 32 * nt + col] = fmaxf(h1[r], 0.f);
     __syncthreads();
+    // gathers of the NEXT tile, hidden under this tile's layer 2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
+    c_first = __shfl(nx_c, crow(0, half));
+    rc_first = a.rc[(unsigned)max(c_first, 0) * D_P + 32 * nt + col];
     f32x16 h2 = zero16();
     mma_abt<D_P>(h2, sH1 + 32 * mt * E_LD2, E_LD2, sW2 + 32 * nt * E_LD2, E_LD2, lane);
     // streaming (max, tie count) per (centre, column); rows ascend, centres are sorted
@@ -291,7 +302,7 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
       if (row >= nrows) continue;
       const float v = fmaxf(h2[r] + bias, 0.f);
       if (c != cur) {
-        if (cur >= 0) pm_flush(pm_col + (size_t)cur * D_P, mx, cnt);
+        if (cur >= 0) pm_flush_async(pend, pm_col + (size_t)cur * D_P, mx, cnt);
         cur = c; mx = v; cnt = 1;
       } else {
         if (v > mx) { mx = v; cnt = 1; } else if (v == mx) { ++cnt; }
@@ -299,7 +310,8 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
     }
     __syncthreads();      // h1 tile consumed before the next tile overwrites it
   }
-  if (cur >= 0) pm_flush(pm_col + (size_t)cur * D_P, mx, cnt);
+  if (cur >= 0) pm_flush_async(pend, pm_col + (size_t)cur * D_P, mx, cnt);
+  pm_resolve(pend);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -129,3 +129,29 @@ def test_weight_reg_gradient():
     expect = 0.0005 * net.params * net._reg_mask
     # the neighbour scatter uses float atomics: two runs differ by rounding
     assert float((diff - expect).abs().max()) < 2e-6 * float(net.grads.abs().max())
+
+
+def test_exact_ties_from_duplicate_detections():
+    """Duplicate detections give bit-identical edge activations: the segment max then has exact positive
+    ties and TF splits the gradient evenly among them.  Exercises the tie counting of the
+    streaming (max, count) combine, including its deferred tie repair across waves."""
+    net, orc = make_pair(80, 2, bias=0.5)
+    ok = 0
+    for seed in range(3):
+        base = make_image(60, 80, seed=seed)
+        rep = np.repeat(np.arange(60), 3)                       # every detection three times
+        rng = np.random.default_rng(seed)
+        rng.shuffle(rep)
+        batch = dict(base)
+        for k in ("dets", "det_scores", "det_classes"):
+            batch[k] = base[k][rep]
+        ref, gref = orc.forward_backward(batch)
+        net.run(batch)
+        torch.cuda.synchronize()
+        pm = net.debug_view("blk_pm", 180 * 64, dtype=torch.int64, index=1).cpu().numpy()
+        assert (((pm & 0xffffffff) > 1) & ((pm >> 32) > 0)).any(), "test must contain positive ties"
+        assert rel_err(net.prediction.cpu().numpy(), ref["prediction"].detach().numpy()) < 1e-5
+        worst = max(grad_errors(net, gref, 80, 2).values())
+        assert worst < LOOSE, worst
+        ok += worst < TIGHT
+    assert ok >= 2
