@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     // d(fc1 pre) tile w = (d2 . W2^T) * (h1 > 0)
     {
       f32x16 acc = zero16();
-      mma_abt<D_H>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
+      mma_abt_gB<D_H, 6>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow(r, half);

@@ -159,6 +159,58 @@ __device__ __forceinline__ void mma_abt2(f32x16& acc0, f32x16& acc1, const float
   }
 }
 
+// Variants whose B operand streams from global memory (weights that do not fit in LDS): the 16-byte
+// B loads run PF k-steps (8 k each) ahead of the MFMAs that consume them, in a register ring.
+template <int K, int PF>
+__device__ __forceinline__ void mma_abt_gB(f32x16& acc, const float* A, int lda, const float* __restrict__ Bt, int ldb,
+                                           int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* ap = A + r * lda + 4 * h;
+  const float* bp = Bt + (size_t)r * ldb + 4 * h;
+  constexpr int NS = K / 8;
+  f32x4 ring[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(bp + 8 * (i < NS ? i : NS - 1));
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4 b = ring[s % PF];
+    if (s + PF < NS) ring[s % PF] = *reinterpret_cast<const f32x4*>(bp + 8 * (s + PF));
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * s);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+
+template <int K, int PF>
+__device__ __forceinline__ void mma_abt2_gB(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1, int lda,
+                                            const float* __restrict__ Bt, int ldb, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* a0p = A0 + r * lda + 4 * h;
+  const float* a1p = A1 + r * lda + 4 * h;
+  const float* bp = Bt + (size_t)r * ldb + 4 * h;
+  constexpr int NS = K / 8;
+  f32x4 ring[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(bp + 8 * (i < NS ? i : NS - 1));
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4 b = ring[s % PF];
+    if (s + PF < NS) ring[s % PF] = *reinterpret_cast<const f32x4*>(bp + 8 * (s + PF));
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * s);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * s);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+  }
+}
+
 // acc[m][n] += X[32 rows x (32*MI)]^T * Y[32 rows x (32*NJ)] (weight-gradient shape: the
 // contraction runs over the 32 tile rows).  X, Y row-major; rows that do not exist must be 0 in Y.
 template <int MI, int NJ>

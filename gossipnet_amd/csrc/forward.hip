@@ -59,27 +59,64 @@ __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ 
 constexpr int PW_T = 64;         // edges per workgroup iteration
 constexpr int PW_LD = D_H + 4;   // padded LDS row (conflict-free 16-B operand reads)
 
-struct PwFwdArgs {
+struct GeoArgs {
   int n_edge;
   const int* edge_c; const int* edge_n; const float* edge_iou;
   const float4* dets; const float* scores; const int* classes;
   int cprime, multiclass;
+  float* geo;       // [E,8]  (iou, x_dist, y_dist, l2_dist, w_diff, h_diff, aspect_diff, 0)
+  int4* einfo;      // [E]    (fc1 row of c's score column, fc1 row of n's score column, score_c, score_n)
+};
+
+// _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns are kept
+// as (row, score) pairs; the 7 geometry columns are evaluated in the reference's fp32 operation order.
+__global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.n_edge) return;
+  const float log2f_ = 0.69314718f;          // float32(np.log(2.0)) network.py:447
+  const int c = a.edge_c[e], n = a.edge_n[e];
+  const float4 cb = a.dets[c], nb = a.dets[n];
+  const float c_w = cb.z - cb.x, c_h = cb.w - cb.y;
+  const float n_w = nb.z - nb.x, n_h = nb.w - nb.y;
+  const float c_scale = (c_w + c_h) / 2.0f;
+  const float c_cx = cb.x + c_w / 2.0f, c_cy = cb.y + c_h / 2.0f;
+  const float n_cx = nb.x + n_w / 2.0f, n_cy = nb.y + n_h / 2.0f;
+  float xd = n_cx - c_cx, yd = n_cy - c_cy;
+  const float l2 = sqrtf(xd * xd + yd * yd) / c_scale;
+  xd = xd / c_scale; yd = yd / c_scale;
+  const float wd = logf(n_w / c_w) / log2f_;
+  const float hd = logf(n_h / c_h) / log2f_;
+  const float ad = (logf(n_w / n_h) - logf(c_w / c_h)) / log2f_;
+  float sc = a.scores[c], sn = a.scores[n];
+  int rc = 0, rn = 1;
+  if (a.multiclass) {                   // scatter_nd one-hot x score (network.py:413-419)
+    const int cc = a.classes[c] - 1, cn = a.classes[n] - 1;
+    if (cc >= 0 && cc < a.cprime) rc = cc; else sc = 0.f;
+    if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
+  }
+  float4* gp = reinterpret_cast<float4*>(a.geo + (size_t)e * 8);
+  gp[0] = make_float4(a.edge_iou[e], xd, yd, l2);
+  gp[1] = make_float4(wd, hd, ad, 0.f);
+  a.einfo[e] = make_int4(rc, rn, __float_as_int(sc), __float_as_int(sn));
+}
+
+struct PwFwdArgs {
+  int n_edge;
+  int cprime;
+  const float* geo; const int4* einfo;
   const float* w1; const float* b1;     // natural [dpw,256]
   const float* w2t; const float* b2;    // transposed [256,256]
   const float* w3t; const float* b3;    // transposed [32,256]
-  float* geo; int4* einfo; float* h1; float* h2; float* pw;
+  float* h1; float* h2; float* pw;
   int training;
 };
 
-__global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
+__global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                          // [64][260]
-  float* sR = sH + PW_T * PW_LD;             // [4][64][32]
-  float* sGeo = sR + 4 * PW_T * D_E;         // [64][8]
-  float* sSc = sGeo + PW_T * 8;              // [64]
-  float* sSn = sSc + PW_T;                   // [64]
-  int* sRc = reinterpret_cast<int*>(sSn + PW_T);   // [64] fc1 row of the centre score column
-  int* sRn = sRc + PW_T;                     // [64]
+  float* sR = sH;                            // [4][64][32] fc3 partials, aliased over sH (2 workgroups / CU)
+  float* sGeo = sH + PW_T * PW_LD;           // [64][8]
+  int4* sInf = reinterpret_cast<int4*>(sGeo + PW_T * 8);   // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = tid & 255, eh = tid >> 8;
   const int geo_row0 = 2 * a.cprime;
@@ -87,54 +124,28 @@ __global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 7; ++g) wg[g] = a.w1[(size_t)(geo_row0 + g) * D_H + f];
   const float bias1 = a.b1[f];
-  const float log2f_ = 0.69314718f;          // float32(np.log(2.0)) network.py:447
 
   for (int tile = blockIdx.x; tile * PW_T < a.n_edge; tile += gridDim.x) {
     const int e0 = tile * PW_T;
-    // ---- phase 0: one thread per edge -> geometry features (network.py:427-450)
-    if (tid < PW_T) {
-      const int e = e0 + tid;
-      float sc = 0.f, sn = 0.f; int rc = 0, rn = 0;
-      float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (e < a.n_edge) {
-        const int c = a.edge_c[e], n = a.edge_n[e];
-        const float4 cb = a.dets[c], nb = a.dets[n];
-        const float c_w = cb.z - cb.x, c_h = cb.w - cb.y;
-        const float n_w = nb.z - nb.x, n_h = nb.w - nb.y;
-        const float c_scale = (c_w + c_h) / 2.0f;
-        const float c_cx = cb.x + c_w / 2.0f, c_cy = cb.y + c_h / 2.0f;
-        const float n_cx = nb.x + n_w / 2.0f, n_cy = nb.y + n_h / 2.0f;
-        float xd = n_cx - c_cx, yd = n_cy - c_cy;
-        const float l2 = sqrtf(xd * xd + yd * yd) / c_scale;
-        xd = xd / c_scale; yd = yd / c_scale;
-        g[0] = a.edge_iou[e];
-        g[1] = xd; g[2] = yd; g[3] = l2;
-        g[4] = logf(n_w / c_w) / log2f_;
-        g[5] = logf(n_h / c_h) / log2f_;
-        g[6] = (logf(n_w / n_h) - logf(c_w / c_h)) / log2f_;
-        sc = a.scores[c]; sn = a.scores[n];
-        if (a.multiclass) {                   // scatter_nd one-hot x score (network.py:413-419)
-          const int cc = a.classes[c] - 1, cn = a.classes[n] - 1;
-          if (cc >= 0 && cc < a.cprime) rc = cc; else sc = 0.f;
-          if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
-        } else { rc = 0; rn = 1; }
-        if (a.training) {
-          float4* gp = reinterpret_cast<float4*>(a.geo + (size_t)e * 8);
-          gp[0] = make_float4(g[0], g[1], g[2], g[3]);
-          gp[1] = make_float4(g[4], g[5], g[6], 0.f);
-          a.einfo[e] = make_int4(rc, rn, __float_as_int(sc), __float_as_int(sn));
-        }
-      }
-      sSc[tid] = sc; sSn[tid] = sn; sRc[tid] = rc; sRn[tid] = rn;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sGeo[tid * 8 + k] = g[k];
+    // ---- phase 0: stage the tile's geometry columns and (row, score) pairs
+    if (tid < 2 * PW_T) {
+      const int el = tid >> 1, hf = tid & 1;
+      const int e = min(e0 + el, a.n_edge - 1);
+      *reinterpret_cast<float4*>(sGeo + el * 8 + 4 * hf) = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4 * hf);
+    } else if (tid < 3 * PW_T) {
+      const int el = tid - 2 * PW_T;
+      sInf[el] = a.einfo[min(e0 + el, a.n_edge - 1)];
     }
     __syncthreads();
-    // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output)
+    // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output).  Edges are
+    // sorted by centre, so the centre's row of W1 is re-read only when it changes.
+    int rc_prev = -1; float wc = 0.f;
     for (int k = 0; k < PW_T / 2; ++k) {
       const int el = 2 * k + eh;
-      float v = sSc[el] * a.w1[(size_t)sRc[el] * D_H + f];
-      v = fmaf(sSn[el], a.w1[(size_t)sRn[el] * D_H + f], v);
+      const int4 inf = sInf[el];
+      if (inf.x != rc_prev) { wc = a.w1[(size_t)inf.x * D_H + f]; rc_prev = inf.x; }
+      float v = __int_as_float(inf.z) * wc;
+      v = fmaf(__int_as_float(inf.w), a.w1[(size_t)inf.y * D_H + f], v);
 #pragma unroll
       for (int g = 0; g < 7; ++g) v = fmaf(sGeo[el * 8 + g], wg[g], v);
       v = fmaxf(v + bias1, 0.f);
@@ -144,7 +155,7 @@ __global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
     __syncthreads();
     // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
     f32x16 acc0 = zero16(), acc1 = zero16();
-    mma_abt2<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
+    mma_abt2_gB<D_H, 4>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
     const int col = lane & 31, half = lane >> 5;
     const float bias2 = a.b2[32 * wave + col];
     __syncthreads();   // every wave has finished reading fc1 activations
@@ -165,6 +176,7 @@ __global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
       const int mt = wave & 1, kq = wave >> 1;
       f32x16 acc = zero16();
       mma_abt<64>(acc, sH + mt * 32 * PW_LD + 64 * kq, PW_LD, a.w3t + 64 * kq, D_H, lane);
+      __syncthreads();   // every wave is done with the fc2 outputs: the partials may overwrite them
 #pragma unroll
       for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
     }
@@ -183,7 +195,7 @@ __global__ void __launch_bounds__(512) pw_fwd(const PwFwdArgs a) {
   }
 }
 
-constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 4 * PW_T * D_E + PW_T * 8 + 4 * PW_T) * sizeof(float);
+constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + PW_T * 8 + 4 * PW_T) * sizeof(float);   // sInf = 4 ints per edge
 
 // ------------------------------------------------------------------------------------------
 // edge_fwd: one wave = one 32-edge tile at a time, 4 independent waves per workgroup sharing the
@@ -480,21 +492,26 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B));
 
   if (E > 0) {
+    // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
+    GeoArgs g;
+    g.n_edge = E; g.edge_c = buf->edge_c; g.edge_n = buf->edge_n; g.edge_iou = buf->edge_iou;
+    g.dets = (const float4*)in->dets; g.scores = in->det_scores; g.classes = in->det_classes;
+    g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
+    g.geo = buf->geo; g.einfo = (int4*)buf->einfo;
+    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, edge_geometry<<<(E + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
-    a.n_edge = E; a.edge_c = buf->edge_c; a.edge_n = buf->edge_n; a.edge_iou = buf->edge_iou;
-    a.dets = (const float4*)in->dets; a.scores = in->det_scores; a.classes = in->det_classes;
-    a.cprime = L.cprime; a.multiclass = cfg->num_classes > 1;
+    a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.einfo = (const int4*)buf->einfo;
     a.w1 = params + L.pw1; a.b1 = params + L.pb1;
     a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
     a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
-    a.geo = buf->geo; a.einfo = (int4*)buf->einfo; a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
+    a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
     const int tiles = (E + PW_T - 1) / PW_T;
     static bool attr_set = false;
     if (!attr_set) {
       HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
       attr_set = true;
     }
-    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<min(tiles, 256), 512, kPwFwdSmem, s>>>(a));
+    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<min(tiles, 512), 512, kPwFwdSmem, s>>>(a));
   }
 
   const int ntile_n = (N + 31) / 32;

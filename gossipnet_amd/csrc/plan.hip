@@ -41,9 +41,9 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
   b.packed_t = c.take<float>((size_t)L.total);
   b.prediction = c.take<float>(Np);
   b.scratch_i = c.take<int32_t>(N + 1024);
+  b.geo = c.take<float>(Ep * 8);
+  b.einfo = c.take<int32_t>(Ep * 4);
   if (training) {
-    b.geo = c.take<float>(Ep * 8);
-    b.einfo = c.take<int32_t>(Ep * 4);
     b.pw_h1 = c.take<float>(Ep * D_H);
     b.pw_h2 = c.take<float>(Ep * D_H);
     b.block_feats[0] = nullptr;
