@@ -14,7 +14,7 @@
 //     gather_sums   centre segment sums / neighbour reversed-edge sums of d_g1 -> d_rc, d_rn
 //     blk_bwd_pre   per-node halves of pw_fc1, reduce_dim         -> d_x := dz + drpre . Wr^T
 //   pw_bwd_main    pw_feats fc3, fc2 (+ d_h1 = grad wrt fc1 pre-activation)
-//   pw_bwd_w1      pw_feats fc1 (one-hot x score structure + 7 geometry rows)
+//   pw_w1_nodesums + pw_w1_classrows   pw_feats fc1 (score columns via per-detection sums, 7 geometry rows)
 //   reduce_partials  sums the per-workgroup partial weight gradients in a fixed order
 // Weight gradients are accumulated in MFMA accumulators across a workgroup's tiles and written once
 // per workgroup to an arena; reduce_partials adds them in index order.  There are no float atomics:
@@ -697,64 +697,117 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
 constexpr size_t kPwBwdSmem = (size_t)(2 * 32 * LD256 + 32 * LD32) * sizeof(float);
 
 // fc1 of the pw-MLP: d W1 = X^T . d_h1 with X = [one-hot(c) * s_c | one-hot(n) * s_n | geo(7)].
-// One wave per (edge chunk, 64-column slice); the class rows accumulate in LDS (single wave ->
-// plain read-modify-write, deterministic), the 7 geometry rows and the bias in registers.
+// The score columns factor through per-detection sums (deterministic, no class table in LDS):
+//   d W1[class k        ] = sum_{i : class_i = k} s_i * S[i],  S[i] = sum over i's own pairs of d_h1
+//   d W1[C' + class k   ] = sum_{i : class_i = k} s_i * T[i],  T[i] = sum over the reversed pairs
+// pw_w1_nodesums streams d_h1 twice (own rows, reversed rows: 2 x 1 KB per edge, HBM-bound) and also
+// accumulates the 7 geometry rows and the bias; pw_w1_classrows folds S/T by class.
 struct PwW1Args {
-  int n_edge; int cprime;
-  const int4* einfo;      // per edge: fc1 row of the centre / neighbour score column, the two scores
-  const float* geo;
-  const float* d_h1;
+  int n_det; int cprime; int multiclass;
+  const int* row_ptr; const int* edge_t; const float* geo; const float* d_h1;
+  const float* scores; const int* classes;
+  float* w1_s; float* w1_t;
   float* arena; long long stride;
   long long o_w1, o_b1;
+  int nchunks;
 };
 
-__global__ void __launch_bounds__(64) pw_bwd_w1(const PwW1Args a) {
-  extern __shared__ __attribute__((aligned(16))) float sAcc[];   // [2*cprime][64]
-  const int lane = threadIdx.x;
-  const int fcol = blockIdx.y * 64 + lane;
-  const int nrow = 2 * a.cprime;
-  for (int i = lane; i < nrow * 64; i += 64) sAcc[i] = 0.f;
-  float g[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float gb = 0.f;
-  const int per = (a.n_edge + gridDim.x - 1) / gridDim.x;
-  const int eb = blockIdx.x * per, ee = min(a.n_edge, eb + per);
-  constexpr int U = 4;                                            // edges in flight per wave
-  for (int e0 = eb; e0 < ee; e0 += U) {
-    float d[U]; int4 inf[U]; float4 ga[U], gc[U];
+__global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
+  __shared__ float red[4 * 8 * D_H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 g[7], gb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {                                 // independent loads first (wave-uniform
-      const int e = min(e0 + u, ee - 1);                          // addresses except the d_h1 column)
-      d[u] = (e0 + u < ee) ? a.d_h1[(size_t)e * D_H + fcol] : 0.f;
-      inf[u] = a.einfo[e];
-      ga[u] = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
-      gc[u] = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
+  for (int k = 0; k < 7; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nwaves = gridDim.x * 4;
+  for (int node = blockIdx.x * 4 + wave; node < a.n_det; node += nwaves) {
+    const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f), T = S;
+    for (int e = eb; e < ee; e += 2) {
+      const int e1 = min(e + 1, ee - 1);
+      const bool two = e + 1 < ee;
+      const float4 d0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e * D_H + 4 * lane);
+      float4 d1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e1 * D_H + 4 * lane);
+      const float4 t0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)a.edge_t[e] * D_H + 4 * lane);
+      float4 t1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)a.edge_t[e1] * D_H + 4 * lane);
+      const float4 ga0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
+      const float4 gc0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
+      float4 ga1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8);
+      float4 gc1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8 + 4);
+      if (!two) { d1 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = d1; }
+#define ACC4(dst, s, v) dst.x = fmaf(s, v.x, dst.x); dst.y = fmaf(s, v.y, dst.y); dst.z = fmaf(s, v.z, dst.z); dst.w = fmaf(s, v.w, dst.w)
+      S.x += d0.x; S.y += d0.y; S.z += d0.z; S.w += d0.w;
+      T.x += t0.x; T.y += t0.y; T.z += t0.z; T.w += t0.w;
+      ACC4(g[0], ga0.x, d0); ACC4(g[1], ga0.y, d0); ACC4(g[2], ga0.z, d0); ACC4(g[3], ga0.w, d0);
+      ACC4(g[4], gc0.x, d0); ACC4(g[5], gc0.y, d0); ACC4(g[6], gc0.z, d0);
+      S.x += d1.x; S.y += d1.y; S.z += d1.z; S.w += d1.w;
+      T.x += t1.x; T.y += t1.y; T.z += t1.z; T.w += t1.w;
+      ACC4(g[0], ga1.x, d1); ACC4(g[1], ga1.y, d1); ACC4(g[2], ga1.z, d1); ACC4(g[3], ga1.w, d1);
+      ACC4(g[4], gc1.x, d1); ACC4(g[5], gc1.y, d1); ACC4(g[6], gc1.z, d1);
+#undef ACC4
     }
+    gb.x += S.x; gb.y += S.y; gb.z += S.z; gb.w += S.w;                 // bias: sum of d_h1 over all edges
+    *reinterpret_cast<float4*>(a.w1_s + (size_t)node * D_H + 4 * lane) = S;
+    *reinterpret_cast<float4*>(a.w1_t + (size_t)node * D_H + 4 * lane) = T;
+  }
+  // fold the four waves, write the 7 geometry rows + bias partial of this workgroup
 #pragma unroll
-    for (int u = 0; u < U; ++u) {                                 // then the in-order accumulation
-      const float dd = d[u];
-      const int rc = inf[u].x, rn = inf[u].y;
-      sAcc[rc * 64 + lane] = fmaf(__int_as_float(inf[u].z), dd, sAcc[rc * 64 + lane]);
-      sAcc[rn * 64 + lane] = fmaf(__int_as_float(inf[u].w), dd, sAcc[rn * 64 + lane]);
-      g[0] = fmaf(ga[u].x, dd, g[0]); g[1] = fmaf(ga[u].y, dd, g[1]); g[2] = fmaf(ga[u].z, dd, g[2]); g[3] = fmaf(ga[u].w, dd, g[3]);
-      g[4] = fmaf(gc[u].x, dd, g[4]); g[5] = fmaf(gc[u].y, dd, g[5]); g[6] = fmaf(gc[u].z, dd, g[6]);
-      gb += dd;
+  for (int k = 0; k < 7; ++k) *reinterpret_cast<float4*>(red + (wave * 8 + k) * D_H + 4 * lane) = g[k];
+  *reinterpret_cast<float4*>(red + (wave * 8 + 7) * D_H + 4 * lane) = gb;
+  __syncthreads();
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  const int f = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = red[(0 * 8 + k) * D_H + f] + red[(1 * 8 + k) * D_H + f] + red[(2 * 8 + k) * D_H + f] + red[(3 * 8 + k) * D_H + f];
+    if (k < 7) ar[a.o_w1 + (size_t)(2 * a.cprime + k) * D_H + f] = v; else ar[a.o_b1 + f] = v;
+  }
+}
+
+// grid (2 C', nchunks): row r < C' folds S by class r + 1 (centre score column), row C' + k folds T.
+// Each wave scans its quarter of the chunk 64 detections at a time (one coalesced class/score load,
+// a ballot picks the members of the class), then adds the selected 1 KB rows in index order.
+__global__ void __launch_bounds__(256) pw_w1_classrows(const PwW1Args a) {
+  __shared__ float red[4 * D_H];
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = r < a.cprime ? r : r - a.cprime;
+  const float* src = r < a.cprime ? a.w1_s : a.w1_t;
+  const int per = (a.n_det + a.nchunks - 1) / a.nchunks;
+  const int c0 = blockIdx.y * per, c1 = min(a.n_det, c0 + per);
+  const int wper = ((c1 - c0 + 3) / 4 + 63) / 64 * 64;
+  const int i0 = c0 + wave * wper, i1 = min(c1, i0 + wper);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int base = i0; base < i1; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < i1;
+    const float sc = valid ? a.scores[i] : 0.f;
+    const bool member = valid && (!a.multiclass || a.classes[i] - 1 == k);
+    unsigned long long mask = __ballot(member);
+    while (mask) {
+      const int j = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float s = __shfl(sc, j);
+      const float* row = src + (size_t)(base + j) * D_H + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(s, row[64 * q], acc[q]);
     }
   }
-  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
-  for (int r = 0; r < nrow; ++r) ar[a.o_w1 + (size_t)r * D_H + fcol] = sAcc[r * 64 + lane];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) ar[a.o_w1 + (size_t)(nrow + k) * D_H + fcol] = g[k];
-  ar[a.o_b1 + fcol] = gb;
+  for (int q = 0; q < 4; ++q) red[wave * D_H + 64 * q + lane] = acc[q];
+  __syncthreads();
+  const int f = threadIdx.x;
+  a.arena[(size_t)blockIdx.y * a.stride + a.o_w1 + (size_t)r * D_H + f] =
+      red[f] + red[D_H + f] + red[2 * D_H + f] + red[3 * D_H + f];
 }
 
 // ------------------------------------------------------------------------------------------
 // grads[p] = sum over the n(p) partial copies arena[k][p], k ascending.
 struct ReduceArgs {
   const float* arena; long long stride; long long total;
+  long long w1c_end;      // end of the score-column rows of pw fc1 (2 C' x 256)
   long long pw1_end;      // end of pw fc1 weights+bias
   long long pw_end;       // end of the pw-MLP parameters
   long long blk_sz; int nblocks;
-  int n_w1, n_pw, n_edge, n_node, n_head;
+  int n_w1c, n_w1, n_pw, n_edge, n_node, n_head;
   float* grads;
 };
 
@@ -762,7 +815,8 @@ __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.total) return;
   int n;
-  if (p < a.pw1_end) n = a.n_w1;
+  if (p < a.w1c_end) n = a.n_w1c;
+  else if (p < a.pw1_end) n = a.n_w1;
   else if (p < a.pw_end) n = a.n_pw;
   else if (p < a.pw_end + a.blk_sz * a.nblocks) {
     const long long q = (p - a.pw_end) % a.blk_sz;
@@ -804,13 +858,13 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + EB_T - 1) / EB_T)) : 0;
   const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
-  const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (E + 255) / 256)) : 0;   // x4 column slices
+  const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (N + 3) / 4)) : 0;          // node-sum workgroups
+  const int g_w1c = E > 0 ? max(1, min(128, 256 / (2 * L.cprime))) : 0;               // node chunks per class row
 
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
 
@@ -863,20 +917,21 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
     GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<<<g_pw, 512, kPwBwdSmem, s>>>(p));
     PwW1Args w;
-    w.n_edge = E; w.cprime = L.cprime;
-    w.einfo = (const int4*)buf->einfo; w.geo = buf->geo; w.d_h1 = buf->d_h1;
-    w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1;
-    const size_t smem = (size_t)2 * L.cprime * 64 * sizeof(float);
-    if (smem > 160 * 1024) return GNET_ERR_UNSUPPORTED;
-    GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_bwd_w1<<<dim3(g_w1, 4), 64, smem, s>>>(w));
+    w.n_det = N; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;
+    w.row_ptr = buf->row_ptr; w.edge_t = buf->edge_t; w.geo = buf->geo; w.d_h1 = buf->d_h1;
+    w.scores = in->det_scores; w.classes = in->det_classes;
+    w.w1_s = buf->w1_s; w.w1_t = buf->w1_t;
+    w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1; w.nchunks = g_w1c;
+    GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_w1_nodesums<<<g_w1, 256, 0, s>>>(w));
+    GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_w1_classrows<<<dim3(2 * L.cprime, g_w1c), 256, 0, s>>>(w));
   }
   {
     ReduceArgs r;
     r.arena = buf->arena; r.stride = stride; r.total = L.total;
-    r.pw1_end = L.pw2; r.pw_end = L.blk[1].wr;
+    r.w1c_end = (long long)2 * L.cprime * D_H; r.pw1_end = L.pw2; r.pw_end = L.blk[1].wr;
     r.blk_sz = (B > 1) ? (L.blk[2].wr - L.blk[1].wr) : (L.hw1 - L.blk[1].wr);
     r.nblocks = B;
-    r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_node;
+    r.n_w1c = g_w1c; r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_node;
     r.grads = grads;
     GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 255) / 256), 256, 0, s>>>(r));
   }

@@ -72,6 +72,8 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_pw = c.take<float>(Ep * D_E);
     b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
+    b.w1_s = c.take<float>(Np * D_H);
+    b.w1_t = c.take<float>(Np * D_H);
     b.arena_floats = arena_floats(cfg, sh);
     b.arena = c.take<float>(b.arena_floats);
   } else {
