@@ -624,11 +624,26 @@ struct PwBwdArgs {
   long long o_w2, o_b2, o_w3, o_b3;
 };
 
+// Asynchronous global -> LDS copy of a [32][256] fp32 tile (one 1 KB row per wave-instruction: the LDS
+// destination of global_load_lds is wave-uniform base + lane * 16, exactly one padded row).  No staging
+// registers; completion is tracked by vmcnt.  Rows past the end re-read the last real row (finite data;
+// their d3 rows are zero, so they contribute nothing).
+__device__ __forceinline__ void dma_tile32(float* sdst, const float* __restrict__ g, long long e0, long long n_rows,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wave * 4 + q;
+    const long long er = min(e0 + row, n_rows - 1);
+    const float* src = g + (size_t)er * D_H + 4 * lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sdst + row * LD256), 16, 0, 0);
+  }
+}
+
 __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sH1 = smem;                    // [32][260]
-  float* sH2 = sH1 + 32 * LD256;        // [32][260]  fc2 output, then d(fc2 pre-activation)
-  float* sD3 = sH2 + 32 * LD256;        // [32][36]
+  // two tile buffers {h1 [32][260], h2 [32][260]} filled by DMA one tile ahead, + d3 [32][36]
+  float* sD3 = smem + 4 * 32 * LD256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
   f32x16 aW2[1][8];
@@ -637,11 +652,16 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   f32x16 aW3 = zero16();
   float gb2 = 0.f, gb3 = 0.f;
   const int ntiles = (a.n_edge + 31) / 32;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  if ((int)blockIdx.x < ntiles) {
+    dma_tile32(smem, a.h1, (long long)blockIdx.x * 32, a.n_edge, wave, lane);
+    dma_tile32(smem + 32 * LD256, a.h2, (long long)blockIdx.x * 32, a.n_edge, wave, lane);
+  }
+  int it = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
     const long long e0 = (long long)t * 32;
-    __syncthreads();
-    load_tile<D_H, LD256>(sH1, a.h1, e0, a.n_edge, tid, 512);
-    load_tile<D_H, LD256>(sH2, a.h2, e0, a.n_edge, tid, 512);
+    float* sH1 = smem + (it & 1) * (2 * 32 * LD256);
+    float* sH2 = sH1 + 32 * LD256;        // fc2 output, then d(fc2 pre-activation)
+    float* nH1 = smem + ((it & 1) ^ 1) * (2 * 32 * LD256);
     for (int i = tid; i < 32 * D_E; i += 512) {
       const int row = i >> 5, j = i & 31;
       float v = 0.f;
@@ -651,6 +671,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       }
       sD3[row * LD32 + j] = v;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's DMA (issued one tile ago) has landed
     __syncthreads();
     // d(fc2 pre) tile w = (d3 . W3^T) * (h2 > 0)
     f32x16 d2 = zero16();
@@ -667,10 +688,16 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       }
     }
     if (tid < D_E) gb3 += col_sum32(sD3, LD32, tid);
-    __syncthreads();      // every wave is done with the fc2 outputs
+    __syncthreads();      // every wave is done with the fc2 outputs (and with d3)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sH2[crow(r, half) * LD256 + 32 * wave + col] = d2[r];
     __syncthreads();
+    // next tile's h1/h2 -> the other buffer (last read during the previous tile).  Issued here: the
+    // d W2 phase below touches only LDS, so the in-order vmcnt never waits on this copy.
+    if (t + (int)gridDim.x < ntiles) {
+      dma_tile32(nH1, a.h1, e0 + (long long)gridDim.x * 32, a.n_edge, wave, lane);
+      dma_tile32(nH1 + 32 * LD256, a.h2, e0 + (long long)gridDim.x * 32, a.n_edge, wave, lane);
+    }
     if (tid < D_H) gb2 += col_sum32(sH2, LD256, tid);
     // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
     mma_xty<1, 8>(aW2, sH1 + 32 * wave, LD256, sH2, LD256, lane);
@@ -694,7 +721,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   if (tid < D_E) ar[a.o_b3 + tid] = gb3;
 }
 
-constexpr size_t kPwBwdSmem = (size_t)(2 * 32 * LD256 + 32 * LD32) * sizeof(float);
+constexpr size_t kPwBwdSmem = (size_t)(4 * 32 * LD256 + 32 * LD32) * sizeof(float);
 
 // fc1 of the pw-MLP: d W1 = X^T . d_h1 with X = [one-hot(c) * s_c | one-hot(n) * s_n | geo(7)].
 // The score columns factor through per-detection sums (deterministic, no class table in LDS):
