@@ -166,8 +166,13 @@ def main():
             if fl is not None:
                 avg_s = ms / cnt * 1e-3
                 ach = fl / avg_s / 1e12
+                traffic = None
+                tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if os.path.exists(tf) and args.dets == 2000 and args.images == 8 and args.preset == "dense" and args.classes == 80:
+                    # HBM bytes per launch from a separate rocprofv3 --pmc run of this same workload
+                    traffic = json.load(open(tf))["kernels"].get(cls, {}).get("hbm_bytes")
                 roofline = {"bound": "mfma", "kernel": cls, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                             "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
                             "flops_per_launch": fl}
 
