@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--preset", default="dense", choices=["dense", "coco_like"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="split the step's images over this many streams "
+                    "(replica Gnets sharing the variables): overlaps MFMA-bound and HBM-bound kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,22 +114,41 @@ def main():
     reset_cfg()
     cfg.gnet.num_blocks = args.blocks
     net = Gnet(args.classes, device=dev)
-    # gradient of the mean over all images of the global batch
-    net.grad_scale = 1.0 / (args.images * world)
+    nets = [net] + [Gnet(args.classes, device=dev, reuse=True) for _ in range(args.lanes - 1)]
+    for n_ in nets:   # gradient of the mean over all images of the global batch
+        n_.grad_scale = 1.0 / (args.images * world)
 
     images = [make_image(args.dets, args.classes, seed=rank * args.images + i, preset=args.preset) for i in range(args.images)]
-    batch = DeviceBatch(images, dev)          # inputs resident in HBM before the timed region
+    # inputs resident in HBM before the timed region
+    batches = [DeviceBatch(images[l::args.lanes], dev) for l in range(args.lanes)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.lanes)] if args.lanes > 1 else [None]
 
     def step():
-        net.run(batch)
+        if args.lanes == 1:
+            net.run(batches[0])
+        else:
+            main_s = torch.cuda.current_stream(dev)
+            for n_, b_, s_ in zip(nets, batches, streams):
+                s_.wait_stream(main_s)
+                with torch.cuda.stream(s_):
+                    n_.begin(b_)
+            for n_, s_ in zip(nets, streams):
+                with torch.cuda.stream(s_):
+                    n_.run()
+            for n_, s_ in zip(nets[1:], streams[1:]):
+                main_s.wait_stream(s_)
+            main_s.wait_stream(streams[0])
+            for n_ in nets[1:]:
+                net.grads.add_(n_.grads)
         if dist is not None:
             allreduce_gradients(net.grads, dist)
 
     for _ in range(args.warmup):
         step()
-    E = int(net.num_edges)
+    E = sum(int(n_.num_edges) for n_ in nets)
     if not args.no_kernel_timing:
-        net.enable_kernel_timing(classes=None, capacity=(args.steps + 1) * 128)
+        for n_ in nets:
+            n_.enable_kernel_timing(classes=None, capacity=(args.steps + 1) * 128)
 
     torch.cuda.synchronize()
     if dist is not None:
@@ -157,12 +178,15 @@ def main():
     roofline = None
     timing = {}
     if not args.no_kernel_timing:
-        timing = net.read_kernel_timing()
+        for n_ in nets:
+            for k_, (ms_, c_) in n_.read_kernel_timing().items():
+                pm_, pc_ = timing.get(k_, (0.0, 0))
+                timing[k_] = (pm_ + ms_, pc_ + c_)
         N_local = args.dets * args.images
         dom = max(timing.items(), key=lambda kv: kv[1][0]) if timing else None
         if dom is not None:
             cls, (ms, cnt) = dom
-            fl = algorithmic_flops(cls, E, N_local, args.classes)
+            fl = algorithmic_flops(cls, E / args.lanes, N_local / args.lanes, args.classes)
             if fl is not None:
                 avg_s = ms / cnt * 1e-3
                 ach = fl / avg_s / 1e12
@@ -186,7 +210,7 @@ def main():
                                    "%d images/step/GPU (configs[4] per-GPU share), %d blocks" % (args.preset, args.images, args.blocks),
                        "dets_per_image": args.dets, "images_per_step_per_gpu": args.images, "num_classes": args.classes,
                        "num_blocks": args.blocks, "edges_per_step_all_gpus": e_total,
-                       "edges_per_det": round(e_total / dets_per_step, 2), "parallelism": "dp%d" % world,
+                       "edges_per_det": round(e_total / dets_per_step, 2), "parallelism": "dp%d" % world, "lanes_per_gpu": args.lanes,
                        "step": "graph build + fwd + matching/loss + bwd" + (" + RCCL all-reduce" if world > 1 else "")},
             "whole_step": {"nominal_tflops": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * world * args.steps / elapsed / 1e12, 3),
                            "frac_fp32_mfma_peak": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * args.steps / elapsed / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},

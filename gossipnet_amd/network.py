@@ -243,7 +243,8 @@ class Gnet(object):
         off = ptr - self._ws.data_ptr()
         return self._ws[off:off + count * esz].view(dtype)
 
-    def _build_graph(self, db, training):
+    def _count_graph(self, db):
+        """Pass 1 of the graph build (asynchronous): per-row neighbour counts + scan."""
         lib, s = self._lib, self._stream()
         N = db.n_det
         if self._row_ptr_tmp is None or self._row_ptr_tmp.numel() < N + 1:
@@ -252,6 +253,11 @@ class Gnet(object):
         thr = float(cfg.gnet.neighbor_thresh)
         _lib.check(lib.gnet_graph_count(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, _vp(self._row_ptr_tmp),
                                         _vp(self._scratch_tmp), s), "gnet_graph_count")
+
+    def _build_graph(self, db, training):
+        lib, s = self._lib, self._stream()
+        N = db.n_det
+        thr = float(cfg.gnet.neighbor_thresh)
         E = int(self._row_ptr_tmp[N].item()) if N > 0 else 0     # the one host sync of a step
         shape = _lib.gnet_shape(db.n_img, N, db.n_gt, E, db.n_anno)
         need = lib.gnet_workspace_bytes(C.byref(self._cfg), C.byref(shape), int(training))
@@ -271,9 +277,21 @@ class Gnet(object):
         self.num_edges = E
         return shape, buf
 
+    def begin(self, batch=None):
+        """First, asynchronous half of run(): feed + neighbour counting.  Several Gnets (sharing variables
+        through reuse=True, each on its own stream) can be begun before any of them is finished, so that the
+        one host sync of a step (reading the edge count) of one lane overlaps the kernels of the others."""
+        db = self.feed(batch) if batch is not None else self._dbatch
+        self._count_graph(db)
+        self._begun = True
+        return self
+
     def run(self, batch=None, training=None, backward=None):
         """One evaluation of the graph = the reference's sess.run.  training=None -> GT present."""
-        db = self.feed(batch) if batch is not None else self._dbatch
+        if batch is not None or not getattr(self, "_begun", False):
+            self.begin(batch)
+        self._begun = False
+        db = self._dbatch
         if training is None:
             training = db.has_gt
         if backward is None:
