@@ -57,7 +57,7 @@ class gnet_buffers(C.Structure):
 EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_graph_transpose", "gnet_workspace_bytes", "gnet_plan",
            "gnet_forward", "gnet_loss", "gnet_backward", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
-           "gnet_profiler_destroy"]
+           "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "blk_bwd_post", "edge_bwd", "blk_bwd_pre",
             "pw_bwd_main", "pw_bwd_w1", "reduce_partials"]
@@ -111,6 +111,12 @@ def load():
     lib.gnet_profiler_read.argtypes = [vp, P(C.c_double), P(i32)]
     lib.gnet_profiler_destroy.restype = C.c_int
     lib.gnet_profiler_destroy.argtypes = [vp]
+    lib.gnet_adam_step.restype = C.c_int
+    lib.gnet_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp]
+    lib.gnet_momentum_step.restype = C.c_int
+    lib.gnet_momentum_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp]
+    lib.gnet_clip_by_norm.restype = C.c_int
+    lib.gnet_clip_by_norm.argtypes = [vp, vp, i32, f32, vp]
     lib.gnet_version.restype = C.c_char_p
     lib.gnet_version.argtypes = []
     _lib = lib

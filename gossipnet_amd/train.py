@@ -1,0 +1,91 @@
+"""Training step around the hot path -- mirror of the reference's train.py:26-37 (LearningRate),
+train.py:64-77 (get_optimizer: Adam / Momentum through slim.learning.create_train_op with optional
+per-gradient norm clipping) and train.py:263-272 (EMA(0.7) loss smoothing).  SURVEY.md 8f rank 1.
+The update itself runs in libgossipnet_hip.so (csrc/optim.hip) on the flat parameter buffer.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import cfg
+
+
+class LearningRate(object):
+    """train.py:26-37 -- multi-step table cfg.train.lr_multi_step = [(iteration, lr), ...]."""
+
+    def __init__(self):
+        self.steps = cfg.train.lr_multi_step
+        self.current_step = 0
+
+    def get_lr(self, iter):
+        if self.current_step >= len(self.steps):
+            return self.steps[-1][1]
+        lr = self.steps[self.current_step][1]
+        if iter == self.steps[self.current_step][0]:
+            self.current_step += 1
+        return lr
+
+
+class ExponentialMovingAverage(object):
+    """tf.train.ExponentialMovingAverage(decay) without num_updates (train.py:263-272): shadow starts
+    at the first value; shadow -= (1 - decay) * (shadow - value)."""
+
+    def __init__(self, decay=0.7):
+        self.decay = decay
+        self.shadow = {}
+
+    def apply(self, **values):
+        for k, v in values.items():
+            v = float(v)
+            self.shadow[k] = v if k not in self.shadow else self.shadow[k] - (1.0 - self.decay) * (self.shadow[k] - v)
+        return dict(self.shadow)
+
+    def average(self, name):
+        return self.shadow[name]
+
+
+class Optimizer(object):
+    """get_optimizer (train.py:64-77) for a Gnet: cfg.train.optimizer in {'adam', 'sgd'}; sgd = Momentum
+    with cfg.train.momentum; cfg.train.gradient_clipping > 0 -> clip_by_norm of every gradient tensor."""
+
+    def __init__(self, net):
+        self.net = net
+        self.lib = _lib.load()
+        self.kind = cfg.train.optimizer
+        if self.kind not in ("adam", "sgd"):
+            raise ValueError('unknown optimizer {}'.format(self.kind))
+        n = net.params.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=net.device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=net.device) if self.kind == "adam" else None
+        self.global_step = 0
+        self.clip = float(cfg.train.gradient_clipping)
+        offs = np.concatenate([[0], np.cumsum([int(np.prod(s)) for _, s in net._spec])]).astype(np.int64)
+        self._offs = torch.from_numpy(offs).to(net.device)
+        self._ntensors = len(net._spec)
+
+    def apply_gradients(self, lr, grad_scale=1.0):
+        net, s = self.net, C.c_void_p(torch.cuda.current_stream(self.net.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        n = net.params.numel()
+        if self.clip > 0:
+            _lib.check(self.lib.gnet_clip_by_norm(p(net.grads), p(self._offs), self._ntensors, self.clip, s),
+                       "gnet_clip_by_norm")
+        self.global_step += 1
+        if self.kind == "adam":
+            _lib.check(self.lib.gnet_adam_step(p(net.params), p(net.grads), p(self.m), p(self.v), n, float(lr), 0.9,
+                                               0.999, 1e-8, self.global_step, float(grad_scale), s), "gnet_adam_step")
+        else:
+            _lib.check(self.lib.gnet_momentum_step(p(net.params), p(net.grads), p(self.m), n, float(lr),
+                                                   float(cfg.train.momentum), float(grad_scale), s), "gnet_momentum_step")
+
+
+def train_step(net, opt, batch, lr, dist=None):
+    """One iteration of train.py:316-320: forward + loss (+ l2) + backward [+ all-reduce] + update."""
+    net.run(batch)
+    if dist is not None:
+        from .data_parallel import allreduce_gradients
+        allreduce_gradients(net.grads, dist)
+    opt.apply_gradients(lr)
+    return net.loss

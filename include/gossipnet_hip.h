@@ -171,6 +171,18 @@ int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs
 int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                   const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream);
 
+/* ---- training step around the path (train.py:64-77: slim create_train_op with Adam / Momentum) --------
+ * All buffers are flat fp32 of n = gnet_param_count elements (device).  grad_scale multiplies the
+ * gradient on the fly (e.g. 1/world after a sum all-reduce).  t = 1-based step count (Adam bias terms).
+ * gnet_clip_by_norm = tf.clip_by_norm of every gradient tensor (clip_gradient_norm > 0), tensors given by
+ * n_tensors+1 device offsets into the flat buffer. */
+int gnet_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t t, float grad_scale, gnet_stream_t stream);
+int gnet_momentum_step(float* params, const float* grads, float* accum, int64_t n, float lr, float momentum,
+                       float grad_scale, gnet_stream_t stream);
+int gnet_clip_by_norm(float* grads, const int64_t* tensor_offsets, int32_t n_tensors, float clip_norm,
+                      gnet_stream_t stream);
+
 /* ---- DetectionMatching (det_matching.cc:72-160).  iou [n_det,n_gt], score [n_det],
  * ignore [n_gt] (bool as u8) -> labels, weights (f32 [n_det]), assignment (i32 [n_det]).
  * Ties in score: higher index first; equal ignore flags: lower index first.
