@@ -428,9 +428,9 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   float rnv[16];
   int c_first = -2; float rc_first = 0.f, pm_first = 0.f, dp_first = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
+  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
   {
-    c_first = __shfl(nx_c, crow(0, half));
+    c_first = row_bcast(nx_c, 0, half);
     const unsigned oc = (unsigned)max(c_first, 0) * D_P + 32 * nt + col;
     rc_first = a.rc[oc]; pm_first = __uint_as_float(pmw[2 * oc + 1]); dp_first = a.d_pc[oc];
   }
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       float rcv = rc_first, pmq = pm_first, dpq = dp_first;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = __shfl(my_c, crow(r, half)), n = __shfl(my_n, crow(r, half));
+        const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
         if (c != cprev) {                                            // once per distinct centre
           const unsigned oc = (unsigned)max(c, 0) * D_P + 32 * nt + col;
           rcv = a.rc[oc];
@@ -507,9 +507,9 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     __syncthreads();                                                // B2: d h2 tile complete
     // gathers of the NEXT tile (its indices arrived long ago): consumed at the top of the next iteration
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
+    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
     {
-      c_first = __shfl(nx_c, crow(0, half));
+      c_first = row_bcast(nx_c, 0, half);
       const unsigned oc = (unsigned)max(c_first, 0) * D_P + 32 * nt + col;
       rc_first = a.rc[oc]; pm_first = __uint_as_float(pmw[2 * oc + 1]); dp_first = a.d_pc[oc];
     }

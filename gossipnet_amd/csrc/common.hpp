@@ -115,6 +115,15 @@ static inline ParamLayout make_layout(const gnet_config* c) {
 // row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Exact f32 fma chain.
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// Value held by the lane that owns tile row crow(r, half) (lanes 0..31 hold rows 0..31).  The row of an
+// accumulator register is uniform per half-wave, so two v_readlane (scalar results, no LDS round trip --
+// __shfl would be a ds_bpermute) and a select replace a cross-lane shuffle.  r must be a constant.
+__device__ __forceinline__ int row_bcast(int v, int r, int half) {
+  const int lo = __builtin_amdgcn_readlane(v, crow(r, 0));
+  const int hi = __builtin_amdgcn_readlane(v, crow(r, 1));
+  return half ? hi : lo;
+}
+
 // acc += A[32 x K] * Bt[32 x K]^T ; A, Bt row-major with leading dims lda/ldb (floats),
 // both 16-byte aligned at (row*ld + 4*half).  Each lane reads 4 consecutive k per 16-B load:
 // the half-waves pair k = kb+t (half 0) with k = kb+4+t (half 1), a permutation of the k sum.

@@ -10,6 +10,7 @@
 //   node_fwd         per block: fc1, fc2, shortcut (:390-408) of block b and reduce_dim (:348-354)
 //                    + the per-node halves of pw_fc1 of block b+1; after the last block: head (:258-273)
 // All dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -212,6 +213,7 @@ struct EdgeFwdArgs {
   const float* w1t;              // transposed pw_fc1 [64][96]: columns 0-31 = pairwise rows
   const float* w2t; const float* b2;   // transposed pw_fc2 [64][64]
   unsigned long long* pm;        // [N,64], zeroed
+  const int* row_ptr;            // [N+1]
 };
 
 // One workgroup (4 waves) per 64-edge tile; wave (mt, nt) owns edge rows [32mt, 32mt+32) and feature
@@ -252,8 +254,8 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
   // neighbour rows rn[n] of the next tile and rc of its first centre: gathered one tile ahead
   float rnv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
-  int c_first = __shfl(nx_c, crow(0, half));
+  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
+  int c_first = row_bcast(nx_c, 0, half);
   float rc_first = a.rc[(unsigned)max(c_first, 0) * D_P + 32 * nt + col];
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
       float rcv = rc_first;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = __shfl(my_c, crow(r, half)), n = __shfl(my_n, crow(r, half));
+        const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
         if (c != cprev) { rcv = a.rc[(unsigned)max(c, 0) * D_P + 32 * nt + col]; cprev = c; }   // once per centre
         h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // :371-374
       }
@@ -301,8 +303,8 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
     __syncthreads();
     // gathers of the NEXT tile, hidden under this tile's layer 2
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(__shfl(nx_n, crow(r, half)), 0) * D_P + 32 * nt + col];
-    c_first = __shfl(nx_c, crow(0, half));
+    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
+    c_first = row_bcast(nx_c, 0, half);
     rc_first = a.rc[(unsigned)max(c_first, 0) * D_P + 32 * nt + col];
     f32x16 h2 = zero16();
     mma_abt<D_P>(h2, sH1 + 32 * mt * E_LD2, E_LD2, sW2 + 32 * nt * E_LD2, E_LD2, lane);
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, half);
-      const int c = __shfl(my_c, row);
+      const int c = row_bcast(my_c, r, half);
       if (row >= nrows) continue;
       const float v = fmaxf(h2[r] + bias, 0.f);
       if (c != cur) {
@@ -324,6 +326,194 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
   }
   if (cur >= 0) pm_flush_async(pend, pm_col + (size_t)cur * D_P, mx, cnt);
   pm_resolve(pend);
+}
+
+// Variant W: every wave owns whole 32-edge x 64-column tiles (96 MFMAs per tile), no workgroup barriers in
+// the tile loop (h1 goes through a wave-private LDS tile), all gathers prefetched one tile ahead.
+// Segment handling is WAVE-UNIFORM: the rows of a tile are sorted by centre, a ballot yields the segment
+// heads, and per segment the wave reduces (max, tie count) over its rows, folds the two half-waves with
+// one cross-lane exchange, and flushes a finished centre ONCE -- by a plain 512-byte store when all of
+// the centre's edges lie inside this wave's edge range (no other wave touches it), by the exact atomic
+// combine only for the (at most two) centres that straddle the range.  No loads or returning atomics sit
+// in divergent code, so the in-order vmcnt never drains the prefetches early.
+// branch-free (selects only): divergent control flow costs far more than the few extra VALU ops
+__device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, unsigned k2) {
+  const bool gt = m2 > m, eq = m2 == m;
+  k = gt ? k2 : (eq ? k + k2 : k);
+  m = gt ? m2 : m;
+}
+
+__global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sWp[D_P * E_LD1];      // [64][36]  Wp^T
+  __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]  W2^T
+  __shared__ __attribute__((aligned(16))) float sHw[4][32 * E_LD2];    // per wave [32][68]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < D_P * D_E; i += 256) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 256) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
+  __syncthreads();
+  const int col = lane & 31, half = lane >> 5;
+  const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
+  const int ntiles = (a.n_edge + 31) / 32;
+  const int nwaves = gridDim.x * 4;
+  const int per = (ntiles + nwaves - 1) / nwaves;
+  const int gw = blockIdx.x * 4 + wave;
+  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  float* sh = sHw[wave];
+  if (t0 >= t1) return;
+  const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
+  // ---- prefetch state for the first tile
+  int nx_c = -1, nx_n = -1;
+  { const int e = t0 * 32 + col; if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; } }
+  f32x4 pa[4];
+  {
+    const float* ap = a.pw + (size_t)min(t0 * 32 + col, a.n_edge - 1) * D_E + 4 * half;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+  }
+  float rn0[16], rn1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned on = (unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + col;
+    rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
+  }
+  // centre rows of the first two segments of the next tile (A = first centre, B = second or the same)
+  int cA = __builtin_amdgcn_readfirstlane(nx_c), cB = cA, hiA = 32;
+  {
+    const int prev = __shfl_up(nx_c, 1);
+    const unsigned hm = (unsigned)__ballot(col > 0 && nx_c != prev && nx_c >= 0);
+    if (hm) { hiA = __builtin_ctz(hm); cB = __builtin_amdgcn_readlane(nx_c, hiA); }
+  }
+  float rcA0 = a.rc[(unsigned)max(cA, 0) * D_P + col], rcA1 = a.rc[(unsigned)max(cA, 0) * D_P + 32 + col];
+  float rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col], rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
+  int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
+  for (int t = t0; t < t1; ++t) {
+    const int e0 = t * 32;
+    const int my_c = nx_c, my_n = nx_n;
+    const int nrows = min(32, a.n_edge - e0);
+    const int tcA = cA, tcB = cB, thiA = hiA;
+    const float trcA0 = rcA0, trcA1 = rcA1, trcB0 = rcB0, trcB1 = rcB1;
+    // segment heads of THIS tile (bit r set = row r starts a new centre)
+    unsigned heads;
+    {
+      const int prev = __shfl_up(my_c, 1);
+      heads = (unsigned)__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev));
+    }
+    const int nseg = __popc(heads);
+    nx_c = -1; nx_n = -1;
+    if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; } }
+    f32x16 h1a, h1b;
+    if (nseg <= 2) {                                   // common case: centre rows were prefetched
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const int n = row_bcast(my_n, r, half);
+        const bool inA = row < thiA;
+        const int c = inA ? tcA : tcB;
+        const float r0 = inA ? trcA0 : trcB0, r1 = inA ? trcA1 : trcB1;
+        h1a[r] = (c != n) ? r0 + rn0[r] : r0;          // self pair: n_feats zeroed (:371-374)
+        h1b[r] = (c != n) ? r1 + rn1[r] : r1;
+      }
+    } else {                                           // many short segments: gather the centre row per edge
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
+        const unsigned oc = (unsigned)max(c, 0) * D_P + col;
+        const float r0 = a.rc[oc], r1 = a.rc[oc + 32];
+        h1a[r] = (c != n) ? r0 + rn0[r] : r0;
+        h1b[r] = (c != n) ? r1 + rn1[r] : r1;
+      }
+    }
+    {
+      const float* b0 = sWp + col * E_LD1 + 4 * half;
+      const float* b1 = b0 + 32 * E_LD1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 av = pa[k];
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+      }
+    }
+    // ---- prefetch for the next tile: P rows, neighbour rows, the first two centre rows
+    {
+      const float* ap = a.pw + (size_t)min(e0 + 32 + col, a.n_edge - 1) * D_E + 4 * half;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+    }
+    wave_lds_sync();        // the previous tile's layer-2 reads of sh are complete
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      sh[row * E_LD2 + col] = fmaxf(h1a[r], 0.f);
+      sh[row * E_LD2 + 32 + col] = fmaxf(h1b[r], 0.f);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned on = (unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + col;
+      rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
+    }
+    {
+      cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;
+      const int prev = __shfl_up(nx_c, 1);
+      const unsigned hm = (unsigned)__ballot(col > 0 && nx_c != prev && nx_c >= 0);
+      if (hm) { hiA = __builtin_ctz(hm); cB = __builtin_amdgcn_readlane(nx_c, hiA); }
+      rcA0 = a.rc[(unsigned)max(cA, 0) * D_P + col]; rcA1 = a.rc[(unsigned)max(cA, 0) * D_P + 32 + col];
+      rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col]; rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
+    }
+    f32x16 h2a = zero16(), h2b = zero16();
+    mma_abt<D_P>(h2a, sh, E_LD2, sW2, E_LD2, lane);
+    mma_abt<D_P>(h2b, sh, E_LD2, sW2 + 32 * E_LD2, E_LD2, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h2a[r] = fmaxf(h2a[r] + bias0, 0.f); h2b[r] = fmaxf(h2b[r] + bias1, 0.f); }
+    // ---- wave-uniform segment loop
+    unsigned hleft = heads;
+    while (hleft) {
+      const int lo = __builtin_ctz(hleft);
+      hleft &= hleft - 1;
+      const int hi = hleft ? __builtin_ctz(hleft) : nrows;
+      const int cseg = __builtin_amdgcn_readlane(my_c, lo);
+      float s0 = 0.f, s1 = 0.f; unsigned q0 = 0, q1 = 0;          // values are >= 0: (0, 0) is neutral
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        const bool in = row >= lo && row < hi;
+        // rows outside the segment contribute (-1, 0): never the maximum of non-negative values
+        segmax_merge(s0, q0, in ? h2a[r] : -1.f, in ? 1u : 0u);
+        segmax_merge(s1, q1, in ? h2b[r] : -1.f, in ? 1u : 0u);
+      }
+      // fold the two half-waves (they hold different rows of the same columns)
+      segmax_merge(s0, q0, __shfl_xor(s0, 32), __shfl_xor(q0, 32));
+      segmax_merge(s1, q1, __shfl_xor(s1, 32), __shfl_xor(q1, 32));
+      if (cseg == cur) {
+        segmax_merge(m0, k0, s0, q0);
+        segmax_merge(m1, k1, s1, q1);
+      } else {
+        if (cur >= 0) {                                           // the previous centre is complete
+          const bool interior = a.row_ptr[cur] >= e_begin && a.row_ptr[cur + 1] <= e_end;
+          unsigned long long* dst = a.pm + (size_t)cur * D_P + 32 * half + col;
+          const float mm = half ? m1 : m0; const unsigned kk = half ? k1 : k0;
+          if (interior) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
+          else pm_flush(dst, mm, kk);
+        }
+        cur = cseg; m0 = s0; k0 = q0; m1 = s1; k1 = q1;
+      }
+    }
+  }
+  if (cur >= 0) {
+    const bool interior = a.row_ptr[cur] >= e_begin && a.row_ptr[cur + 1] <= e_end;
+    unsigned long long* dst = a.pm + (size_t)cur * D_P + 32 * half + col;
+    const float mm = half ? m1 : m0; const unsigned kk = half ? k1 : k0;
+    if (interior) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
+    else pm_flush(dst, mm, kk);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -543,8 +733,16 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.n_edge = E; e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
         e.rc = buf->blk_rc[b + 1]; e.rn = buf->blk_rn[b + 1];
         e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
-        e.pm = (unsigned long long*)buf->blk_pm[b + 1];
-        GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd<<<egrid, 256, 0, s>>>(e));
+        e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
+        // default: variant W (wave-owned tiles, 2 workgroups per CU); GNET_EDGE_FWD_W=0 selects the
+        // cooperative 64-edge-tile kernel (kept for A/B measurements)
+        static const int variant_w = getenv("GNET_EDGE_FWD_W") ? atoi(getenv("GNET_EDGE_FWD_W")) : 2;
+        if (variant_w) {
+          const int wg = max(1, min(variant_w * 256, ((E + 31) / 32 + 3) / 4));
+          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<<<wg, 256, 0, s>>>(e));
+        } else {
+          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd<<<egrid, 256, 0, s>>>(e));
+        }
       }
     }
   }

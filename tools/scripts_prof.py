@@ -14,7 +14,7 @@ lib.gnet_debug_prof(buf, 1)
 net.run(batch); torch.cuda.synchronize()
 lib.gnet_debug_prof(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
-names = ["looptop", "S1 gathers", "B0", "L1 mfma+sA", "B1", "S2 L2+dh2", "B2", "S3 dW2+S4 g1", "B3", "g1 write", "B4", "S6+S7", "B5", "combine"]
-tot = v[:14].sum()
-for n_, x in zip(names, v): print("%-14s %10.0f  %5.1f%%" % (n_, x / 16, 100 * x / tot))
-print("total cycles per launch (wave)", tot / 16, "E", net.num_edges)
+names = ["looptop", "h1 init", "L1 mfma", "P prefetch", "lds write+sync", "rn prefetch", "L2 mfma", "segment"]
+tot = v[:8].sum()
+for n_, x in zip(names, v): print('%-14s %10.0f  %5.1f%%' % (n_, x / 16, 100 * x / tot))
+print('total cycles per launch (wave)', tot / 16, 'E', net.num_edges)
