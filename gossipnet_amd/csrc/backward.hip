@@ -426,19 +426,36 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   // neighbour rows rn[n] of the next tile and the centre-side values of its first centre are gathered
   // in the middle of the current tile (hidden under its MFMA phases)
   float rnv[16];
-  int c_first = -2; float rc_first = 0.f, pm_first = 0.f, dp_first = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
-  {
-    c_first = row_bcast(nx_c, 0, half);
-    const unsigned oc = (unsigned)max(c_first, 0) * D_P + 32 * nt + col;
-    rc_first = a.rc[oc]; pm_first = __uint_as_float(pmw[2 * oc + 1]); dp_first = a.d_pc[oc];
-  }
+  // centre-side values of the first two segments (A = first centre of this wave's 32 rows, B = the next
+  // distinct centre or the same): fetched unconditionally, wave-uniformly, one tile ahead
+  int cA = -1, cB = -1, hiA = 32;
+  float rcA = 0.f, pmA = 0.f, dpA = 0.f, rcB = 0.f, pmB = 0.f, dpB = 0.f;
+#define EB_PREFETCH_NEXT()                                                                             \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
+      rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];                 \
+    cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;                                      \
+    const int prev_ = __shfl_up(nx_c, 1);                                                              \
+    const unsigned hm_ = (unsigned)__ballot(half == 0 && col > 0 && nx_c != prev_ && nx_c >= 0);       \
+    if (hm_) { hiA = __builtin_ctz(hm_); cB = __builtin_amdgcn_readlane(nx_c, hiA); }                  \
+    const unsigned oa_ = (unsigned)max(cA, 0) * D_P + 32 * nt + col, ob_ = (unsigned)max(cB, 0) * D_P + 32 * nt + col; \
+    rcA = a.rc[oa_]; pmA = __uint_as_float(pmw[2 * oa_ + 1]); dpA = a.d_pc[oa_];                       \
+    rcB = a.rc[ob_]; pmB = __uint_as_float(pmw[2 * ob_ + 1]); dpB = a.d_pc[ob_];                       \
+  } while (0)
+  EB_PREFETCH_NEXT();
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * EB_T + 32 * mt;                              // first edge of this wave's rows
     const int my_c = nx_c, my_n = nx_n;
     const int nrows = min(32, a.n_edge - e0);                       // may be <= 0 for the last tile
+    const int tcA = cA, tcB = cB, thiA = hiA;
+    const float trcA = rcA, tpmA = pmA, tdpA = dpA, trcB = rcB, tpmB = pmB, tdpB = dpB;
+    int nseg;
+    {
+      const int prev = __shfl_up(my_c, 1);
+      nseg = __popcll(__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev)));
+    }
+    const bool simple = nseg <= 2;                                  // wave-uniform
     const int tvalid = min(EB_T, a.n_edge - t * EB_T) * D_E;        // valid floats of the d_pw tile
     float* dpw_tile = a.d_pw + (size_t)(t * EB_T) * D_E;
     *reinterpret_cast<float4*>(sP + prow0 * LD32 + 4 * pc4) = pf0;
@@ -453,22 +470,20 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     }
     // ---- S1: h1 = relu(P . Wp + rc[c] + (c != n) rn[n]) for this wave's quadrant
     f32x16 h1;
-    float pmv[16], dpv[16];
-    {
-      int cprev = c_first;                                           // prefetched during the previous tile
-      float rcv = rc_first, pmq = pm_first, dpq = dp_first;
+    if (simple) {                                                   // centre rows were prefetched (A / B)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool inA = crow(r, half) < thiA;
+        const int c = inA ? tcA : tcB, n = row_bcast(my_n, r, half);
+        const float rcv = inA ? trcA : trcB;
+        h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // self pair: n_feats zeroed (:371-374)
+      }
+    } else {                                                        // many short segments: gather per edge
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
-        if (c != cprev) {                                            // once per distinct centre
-          const unsigned oc = (unsigned)max(c, 0) * D_P + 32 * nt + col;
-          rcv = a.rc[oc];
-          pmq = __uint_as_float(pmw[2 * oc + 1]);                    // segment max
-          dpq = a.d_pc[oc];                                          // tie-split gradient of the centre
-          cprev = c;
-        }
-        h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // self pair: n_feats zeroed (:371-374)
-        pmv[r] = pmq; dpv[r] = dpq;
+        const float rcv = a.rc[(unsigned)max(c, 0) * D_P + 32 * nt + col];
+        h1[r] = (c != n) ? rcv + rnv[r] : rcv;
       }
     }
     __syncthreads();                                                // B0: P tile in LDS
@@ -496,23 +511,30 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     // ---- S2: h2 = relu(h1 . W2 + b2); d h2 = SegmentMax tie split + ReLU mask
     f32x16 d2 = zero16();
     mma_abt<D_P>(d2, sA + 32 * mt * LD64, LD64, sW2T + 32 * nt * LD64, LD64, lane);
+    if (simple) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = fmaxf(d2[r] + bias, 0.f);
-      const bool ok = crow(r, half) < nrows;
-      const float x = (ok && v > 0.f && v == pmv[r]) ? dpv[r] : 0.f;
-      gb2 += x;
-      sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(d2[r] + bias, 0.f);
+        const bool inA = crow(r, half) < thiA;
+        const float pmr = inA ? tpmA : tpmB, dpr = inA ? tdpA : tdpB;
+        const float x = (crow(r, half) < nrows && v > 0.f && v == pmr) ? dpr : 0.f;
+        gb2 += x;
+        sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(d2[r] + bias, 0.f);
+        const unsigned oc = (unsigned)max(row_bcast(my_c, r, half), 0) * D_P + 32 * nt + col;
+        const float pmr = __uint_as_float(pmw[2 * oc + 1]), dpr = a.d_pc[oc];
+        const float x = (crow(r, half) < nrows && v > 0.f && v == pmr) ? dpr : 0.f;
+        gb2 += x;
+        sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
+      }
     }
     __syncthreads();                                                // B2: d h2 tile complete
     // gathers of the NEXT tile (its indices arrived long ago): consumed at the top of the next iteration
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
-    {
-      c_first = row_bcast(nx_c, 0, half);
-      const unsigned oc = (unsigned)max(c_first, 0) * D_P + 32 * nt + col;
-      rc_first = a.rc[oc]; pm_first = __uint_as_float(pmw[2 * oc + 1]); dp_first = a.d_pc[oc];
-    }
+    EB_PREFETCH_NEXT();
     // ---- S3: d W2[mt-th row tile][nt-th column tile] += h1^T . d h2 over the 64 edges
     {
       const float* X = sA + 32 * mt + col;
