@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
 
 // ------------------------------------------------------------------------------------------
 struct EdgeBwdArgs {
-  int n_edge;
+  int n_edge; int n_det;
   int accumulate_dpw;               // 0 for the first block processed (writes), 1 afterwards (adds)
   const int* edge_c; const int* edge_n;
   const float* pw; const float* rc; const float* rn;
@@ -430,10 +430,19 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   // distinct centre or the same): fetched unconditionally, wave-uniformly, one tile ahead
   int cA = -1, cB = -1, hiA = 32;
   float rcA = 0.f, pmA = 0.f, dpA = 0.f, rcB = 0.f, pmB = 0.f, dpB = 0.f;
+  // neighbour indices of this lane's 16 rows: rows crow(r, half) = 8 (r>>2) + 4 half + (r&3) are four groups of
+  // four consecutive edges -> four 16-byte loads (edge buffers carry 64 entries of slack; clamped)
+  int4 nn4[4];
+#define EB_LOAD_NN(tile_)                                                                              \
+  do {                                                                                                 \
+    const int4* np_ = reinterpret_cast<const int4*>(a.edge_n + (size_t)(tile_) * EB_T + 32 * mt + 4 * half); \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) nn4[g_] = np_[2 * g_];                            \
+  } while (0)
+#define EB_NN(r_) (((r_) & 3) == 0 ? nn4[(r_) >> 2].x : ((r_) & 3) == 1 ? nn4[(r_) >> 2].y : ((r_) & 3) == 2 ? nn4[(r_) >> 2].z : nn4[(r_) >> 2].w)
 #define EB_PREFETCH_NEXT()                                                                             \
   do {                                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
-      rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];                 \
+      rnv[r] = a.rn[(unsigned)min(max(EB_NN(r), 0), a.n_det - 1) * D_P + 32 * nt + col];               \
     cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;                                      \
     const int prev_ = __shfl_up(nx_c, 1);                                                              \
     const unsigned hm_ = (unsigned)__ballot(half == 0 && col > 0 && nx_c != prev_ && nx_c >= 0);       \
@@ -442,13 +451,14 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     rcA = a.rc[oa_]; pmA = __uint_as_float(pmw[2 * oa_ + 1]); dpA = a.d_pc[oa_];                       \
     rcB = a.rc[ob_]; pmB = __uint_as_float(pmw[2 * ob_ + 1]); dpB = a.d_pc[ob_];                       \
   } while (0)
+  EB_LOAD_NN(min(t0, max(ntiles - 1, 0)));
   EB_PREFETCH_NEXT();
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * EB_T + 32 * mt;                              // first edge of this wave's rows
     const int my_c = nx_c, my_n = nx_n;
     const int nrows = min(32, a.n_edge - e0);                       // may be <= 0 for the last tile
-    const int tcA = cA, tcB = cB, thiA = hiA;
+    const int thiA = hiA;
     const float trcA = rcA, tpmA = pmA, tdpA = dpA, trcB = rcB, tpmB = pmB, tdpB = dpB;
     int nseg;
     {
@@ -456,12 +466,17 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       nseg = __popcll(__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev)));
     }
     const bool simple = nseg <= 2;                                  // wave-uniform
+    // bit crow(r, 0) of `selfm` = this lane's row crow(r, half) is a self pair (c == n)
+    const unsigned selfm = (unsigned)__ballot(half == 0 && my_c == my_n) >> (4 * half);
+    float* sAp = sA + (32 * mt + 4 * half) * LD64 + 32 * nt + col;   // + crow(r, 0) * LD64 = row crow(r, half)
+    float* sBp = sB + (32 * mt + 4 * half) * LD64 + 32 * nt + col;
     const int tvalid = min(EB_T, a.n_edge - t * EB_T) * D_E;        // valid floats of the d_pw tile
     float* dpw_tile = a.d_pw + (size_t)(t * EB_T) * D_E;
     *reinterpret_cast<float4*>(sP + prow0 * LD32 + 4 * pc4) = pf0;
     *reinterpret_cast<float4*>(sP + (32 + prow0) * LD32 + 4 * pc4) = pf1;
     nx_c = -1; nx_n = -1;
     if (t + 1 < t1) {
+      EB_LOAD_NN(t + 1);
       const int e = e0 + EB_T + col;
       if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
       const int last = a.n_edge - 1;
@@ -473,17 +488,14 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     if (simple) {                                                   // centre rows were prefetched (A / B)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool inA = crow(r, half) < thiA;
-        const int c = inA ? tcA : tcB, n = row_bcast(my_n, r, half);
-        const float rcv = inA ? trcA : trcB;
-        h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // self pair: n_feats zeroed (:371-374)
+        const float rcv = (crow(r, half) < thiA) ? trcA : trcB;
+        h1[r] = ((selfm >> crow(r, 0)) & 1u) ? rcv : rcv + rnv[r];   // self pair: n_feats zeroed (:371-374)
       }
     } else {                                                        // many short segments: gather per edge
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
-        const float rcv = a.rc[(unsigned)max(c, 0) * D_P + 32 * nt + col];
-        h1[r] = (c != n) ? rcv + rnv[r] : rcv;
+        const float rcv = a.rc[(unsigned)max(row_bcast(my_c, r, half), 0) * D_P + 32 * nt + col];
+        h1[r] = ((selfm >> crow(r, 0)) & 1u) ? rcv : rcv + rnv[r];
       }
     }
     __syncthreads();                                                // B0: P tile in LDS
@@ -505,7 +517,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     for (int r = 0; r < 16; ++r) {
       const float v = fmaxf(h1[r], 0.f);
       h1mask |= (v > 0.f ? 1u : 0u) << r;
-      sA[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = v;
+      sAp[crow(r, 0) * LD64] = v;
     }
     __syncthreads();                                                // B1: h1 tile complete
     // ---- S2: h2 = relu(h1 . W2 + b2); d h2 = SegmentMax tie split + ReLU mask
@@ -519,7 +531,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
         const float pmr = inA ? tpmA : tpmB, dpr = inA ? tdpA : tdpB;
         const float x = (crow(r, half) < nrows && v > 0.f && v == pmr) ? dpr : 0.f;
         gb2 += x;
-        sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
+        sBp[crow(r, 0) * LD64] = x;
       }
     } else {
 #pragma unroll
@@ -529,7 +541,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
         const float pmr = __uint_as_float(pmw[2 * oc + 1]), dpr = a.d_pc[oc];
         const float x = (crow(r, half) < nrows && v > 0.f && v == pmr) ? dpr : 0.f;
         gb2 += x;
-        sB[(32 * mt + crow(r, half)) * LD64 + 32 * nt + col] = x;
+        sBp[crow(r, 0) * LD64] = x;
       }
     }
     __syncthreads();                                                // B2: d h2 tile complete
@@ -560,19 +572,29 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       }
     }
     __syncthreads();                                                // B3: every read of h1 (sA) is done
+    // interior tiles (all 64 edges exist) take unconditional, constant-offset loads/stores
+    const bool full = tvalid == EB_T * D_E;
     float dold[8];                                                  // old d_pw values of the final RMW
+    if (full && a.accumulate_dpw) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      dold[i] = (a.accumulate_dpw && idx < tvalid) ? dpw_tile[idx] : 0.f;
+      for (int i = 0; i < 8; ++i) dold[i] = dpw_tile[tid + 256 * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        dold[i] = (a.accumulate_dpw && idx < tvalid) ? dpw_tile[idx] : 0.f;
+      }
     }
+    {
+      // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order.
+      // row crow(r, half) = crow(r, 0) + 4 half: per-lane base + compile-time row offsets
+      float* g1p = a.d_g1 + (size_t)e0 * D_P + (4 * half) * D_P + 32 * nt + col;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      const float v = ((h1mask >> r) & 1u) ? g1[r] : 0.f;
-      sA[(32 * mt + row) * LD64 + 32 * nt + col] = v;
-      // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order
-      if (row < nrows) a.d_g1[(size_t)(e0 + row) * D_P + 32 * nt + col] = v;
+      for (int r = 0; r < 16; ++r) {
+        const float v = ((h1mask >> r) & 1u) ? g1[r] : 0.f;
+        sAp[crow(r, 0) * LD64] = v;
+        if (full || crow(r, half) < nrows) g1p[crow(r, 0) * D_P] = v;
+      }
     }
     __syncthreads();                                                // B4: g1 tile complete
     // ---- S6: d Wp[:, column tile nt] += P^T . g1 over edge half mt
@@ -601,10 +623,18 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       for (int r = 0; r < 16; ++r) part[(32 * mt + crow(r, half)) * D_E + col] = acc[r];
     }
     __syncthreads();                                                // B5: partials complete; sA, sP free
+    if (full) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < tvalid) dpw_tile[idx] = dold[i] + (sB[idx] + sB[EB_T * D_E + idx]);
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        dpw_tile[idx] = dold[i] + (sB[idx] + sB[EB_T * D_E + idx]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < tvalid) dpw_tile[idx] = dold[i] + (sB[idx] + sB[EB_T * D_E + idx]);
+      }
     }
     // (the next tile's S2 writes sB only behind its B0/B1, i.e. after every wave finished this loop)
   }
@@ -938,7 +968,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     }
     if (E > 0) {
       EdgeBwdArgs e;
-      e.n_edge = E; e.accumulate_dpw = b != B;
+      e.n_edge = E; e.n_det = N; e.accumulate_dpw = b != B;
       e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
       e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b];
       e.pm = (const unsigned long long*)buf->blk_pm[b]; e.d_pc = buf->d_pc;
