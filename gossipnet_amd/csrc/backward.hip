@@ -757,12 +757,11 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     {
       f32x16 acc = zero16();
       mma_abt_gB<D_H, 6>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
+      // rows past E land in the buffer's slack (their d3 rows are zero anyway)
+      float* dp = a.d_h1 + (size_t)(e0 + 4 * half) * D_H + 32 * wave + col;
+      const float* hp = sH1 + (4 * half) * LD256 + 32 * wave + col;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, half);
-        if (e0 + row < a.n_edge)
-          a.d_h1[(size_t)(e0 + row) * D_H + 32 * wave + col] = sH1[row * LD256 + 32 * wave + col] > 0.f ? acc[r] : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) dp[crow(r, 0) * D_H] = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
     }
   }
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
