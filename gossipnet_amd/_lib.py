@@ -71,8 +71,13 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise GnetError("libgossipnet_hip.so is missing (%s): build it with "
-                        "`python -m gossipnet_amd.build` -- there is no CPU fallback" % LIB_PATH)
+        # not a fallback: the same HIP sources, compiled on the spot when hipcc is available
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as exc:      # noqa: BLE001
+            raise GnetError("libgossipnet_hip.so is missing (%s) and could not be built (%s): run "
+                            "`python -m gossipnet_amd.build` -- there is no CPU fallback" % (LIB_PATH, exc))
     # torch bundles its own HIP runtime: it must be mapped first so that this library binds to the
     # same libamdhip64 as the streams/allocations it is handed (loading /opt/rocm's copy first breaks launches)
     import torch  # noqa: F401

@@ -133,3 +133,22 @@ def test_graph_build_dense_10000():
         cnt += len(ref)
     assert cnt == len(pairs)
     assert np.isfinite(net.prediction.cpu().numpy()).all()
+
+
+def test_config4_dense_10000_forward_backward_runs():
+    """BASELINE config 4 end to end (N = 10000, E ~ 3.2 M): finite logits, loss and gradients; the gradient
+    of the image equals the gradient of the same image inside a two-image batch (block-diagonal property)."""
+    from tests.util import make_pair, make_image
+    net, _ = make_pair(80, 2)
+    big = make_image(10000, 80, seed=0)
+    small = make_image(50, 80, seed=1)
+    net.run(big)
+    g_big = net.grads.clone()
+    assert net.num_edges > 3000000 and torch.isfinite(g_big).all() and torch.isfinite(net.prediction).all()
+    loss_big = float(net.loss)
+    net.run(small)
+    g_small = net.grads.clone()
+    net.run([big, small])
+    both = net.grads
+    assert abs(float(net.image_losses[0, 0]) - loss_big) <= 1e-5 * abs(loss_big)
+    assert float((both - (g_big + g_small)).abs().max()) <= 2e-5 * float(g_big.abs().max())
