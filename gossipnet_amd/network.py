@@ -420,3 +420,30 @@ class Gnet(object):
         if index is not None:
             p = p[index]
         return self._view(p, count, dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# Thin helpers of the image-feature variant (network.py:78-118).  The ResNet trunk itself is out of scope
+# (SURVEY §2 row 12); these produce the RoI-pooled detection features from a caller-supplied feature map.
+def enlarge_windows(dets, padding=0.5):
+    """network.py:78-86: pad every box by `padding` of its width/height on each side (xyxy in, xyxy out)."""
+    x1, y1, x2, y2 = dets[:, 0:1], dets[:, 1:2], dets[:, 2:3], dets[:, 3:4]
+    w, h = x2 - x1, y2 - y1
+    cx, cy = (x1 + x2) / 2.0, (y1 + y2) / 2.0
+    nw2, nh2 = w * (0.5 + padding), h * (0.5 + padding)
+    return torch.cat([cx - nw2, cy - nh2, cx + nw2, cy + nh2], 1)
+
+
+def to_frcn_coords(boxes):
+    """network.py:97-100: prepend the batch index 0."""
+    return torch.cat([torch.zeros(boxes.shape[0], 1, dtype=boxes.dtype, device=boxes.device), boxes], 1)
+
+
+def crop_windows(imfeats, dets, stride):
+    """network.py:103-118: RoI max pooling of the enlarged detection windows, NHWC feature map.
+    Returns (detection_feats [N, crop_h, crop_w, C], frcn_boxes [N,5]); differentiable w.r.t. imfeats."""
+    from .roi_pooling_layer.roi_pooling_op import roi_pool
+    frcn_boxes = to_frcn_coords(enlarge_windows(dets))
+    feats, _ = roi_pool(imfeats, frcn_boxes, pooled_height=cfg.imfeat_crop_height,
+                        pooled_width=cfg.imfeat_crop_width, spatial_scale=1.0 / stride)
+    return feats, frcn_boxes

@@ -152,3 +152,19 @@ def test_config4_dense_10000_forward_backward_runs():
     both = net.grads
     assert abs(float(net.image_losses[0, 0]) - loss_big) <= 1e-5 * abs(loss_big)
     assert float((both - (g_big + g_small)).abs().max()) <= 2e-5 * float(g_big.abs().max())
+
+
+def test_crop_windows_matches_oracle():
+    """network.py:78-118 (enlarge_windows -> to_frcn_coords -> roi_pool 7x7 at 1/16) against the C oracle."""
+    from gossipnet_amd.network import crop_windows
+    from tests.util import make_image
+    rng = np.random.default_rng(0)
+    dets = make_image(64, 80, seed=0)["dets"]
+    fmap = rng.normal(size=(1, 30, 40, 32)).astype(np.float32)
+    feats, boxes = crop_windows(torch.tensor(fmap, device="cuda:0"), torch.tensor(dets, device="cuda:0"), 16)
+    w = dets[:, 2:3] - dets[:, 0:1]; h = dets[:, 3:4] - dets[:, 1:2]
+    cx = (dets[:, 0:1] + dets[:, 2:3]) / np.float32(2); cy = (dets[:, 1:2] + dets[:, 3:4]) / np.float32(2)
+    ref_boxes = np.concatenate([np.zeros_like(cx), cx - w, cy - h, cx + w, cy + h], 1).astype(np.float32)
+    assert np.array_equal(boxes.cpu().numpy(), ref_boxes)
+    rtop, _ = native.roi_pool(fmap, ref_boxes, 7, 7, 1.0 / 16)
+    assert np.array_equal(feats.cpu().numpy(), rtop)
