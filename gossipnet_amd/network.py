@@ -86,6 +86,9 @@ class DeviceBatch(object):
         else:
             gtb = np.zeros((0, 4), f32); crowd = np.zeros(0, np.uint8); gcls = np.zeros(0, i32)
             m_per = [0] * self.n_img
+        if max(m_per) > 2048:
+            raise _lib.GnetError("more than 2048 ground-truth boxes in one image: the matching kernel keeps the "
+                                 "matched flags in a 64-lane x 32-bit register bitmask")
         self.gt_off_h = np.concatenate([[0], np.cumsum(m_per)]).astype(i32)
         self.anno_off_h = np.concatenate([[0], np.cumsum(np.asarray(n_per, np.int64) * np.asarray(m_per, np.int64))]).astype(np.int64)
         self.n_det, self.n_gt = int(dets.shape[0]), int(gtb.shape[0])

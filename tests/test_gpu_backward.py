@@ -155,3 +155,31 @@ def test_exact_ties_from_duplicate_detections():
         assert worst < LOOSE, worst
         ok += worst < TIGHT
     assert ok >= 2
+
+
+def test_batch_with_empty_image_and_image_without_gt():
+    """Ragged batch: an image with zero detections, one with zero GT, one ordinary (edge cases of the
+    block-diagonal batch; the reference feeds one image at a time and skips images without detections,
+    train.py:141-142)."""
+    net, orc = make_pair(80, 2)
+    empty = {"dets": np.zeros((0, 4), np.float32), "det_scores": np.zeros(0, np.float32),
+             "det_classes": np.zeros(0, np.int32), "gt_boxes": np.zeros((0, 4), np.float32),
+             "gt_crowd": np.zeros(0, bool), "gt_classes": np.zeros(0, np.int32)}
+    nogt = make_image(40, 80, seed=3)
+    nogt["gt_boxes"] = np.zeros((0, 4), np.float32); nogt["gt_crowd"] = np.zeros(0, bool)
+    nogt["gt_classes"] = np.zeros(0, np.int32)
+    normal = make_image(70, 80, seed=4)
+    net.run([empty, nogt, normal])
+    torch.cuda.synchronize()
+    losses = net.image_losses[:, 0].cpu().numpy()
+    assert losses[0] == 0.0
+    r1, g1 = orc.forward_backward(nogt)
+    r2, g2 = orc.forward_backward(normal)
+    assert abs(losses[1] - float(r1["loss"])) < 1e-4 and abs(losses[2] - float(r2["loss"])) < 1e-4
+    assert np.array_equal(net.det_gt_matching.cpu().numpy()[:40], np.full(40, -1))
+    assert np.array_equal(net.det_gt_matching.cpu().numpy()[40:], r2["det_gt_matching"])
+    gsum = {k: g1[k] + g2[k] for k in g1}
+    assert max(grad_errors(net, gsum, 80, 2).values()) < LOOSE
+    # a batch of only an empty image
+    net.run([empty])
+    assert float(net.grads.abs().max()) == 0.0 and net.num_edges == 0
