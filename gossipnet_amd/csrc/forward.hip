@@ -67,13 +67,18 @@ struct GeoArgs {
   int cprime, multiclass;
   float* geo;       // [E,8]  (iou, x_dist, y_dist, l2_dist, w_diff, h_diff, aspect_diff, 0)
   int4* einfo;      // [E]    (fc1 row of c's score column, fc1 row of n's score column, score_c, score_n)
+  int* edge_nz;     // [E+64] n, or n_det for self pairs (their neighbour features are zeroed, network.py:371-374) and the tail
+  int n_det;
 };
 
 // _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns are kept
 // as (row, score) pairs; the 7 geometry columns are evaluated in the reference's fp32 operation order.
 __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= a.n_edge) return;
+  if (e >= a.n_edge) {
+    if (e < a.n_edge + 64) a.edge_nz[e] = a.n_det;
+    return;
+  }
   const float log2f_ = 0.69314718f;          // float32(np.log(2.0)) network.py:447
   const int c = a.edge_c[e], n = a.edge_n[e];
   const float4 cb = a.dets[c], nb = a.dets[n];
@@ -99,6 +104,7 @@ __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   gp[0] = make_float4(a.edge_iou[e], xd, yd, l2);
   gp[1] = make_float4(wd, hd, ad, 0.f);
   a.einfo[e] = make_int4(rc, rn, __float_as_int(sc), __float_as_int(sn));
+  a.edge_nz[e] = c == n ? a.n_det : n;
 }
 
 struct PwFwdArgs {
@@ -214,6 +220,7 @@ struct EdgeFwdArgs {
   const float* w2t; const float* b2;   // transposed pw_fc2 [64][64]
   unsigned long long* pm;        // [N,64], zeroed
   const int* row_ptr;            // [N+1]
+  const int* edge_nz;            // [E+64] neighbour index, n_det (a zero row of rn) for self pairs and the tail
 };
 
 // One workgroup (4 waves) per 64-edge tile; wave (mt, nt) owns edge rows [32mt, 32mt+32) and feature
@@ -361,19 +368,34 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
   float* sh = sHw[wave];
   if (t0 >= t1) return;
   const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
+  // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
+  // tools/mfma_valu_overlap.hip) -- every vector instruction in this loop is paid in MFMA time.  Hence:
+  //   * self pairs and the edge tail are resolved once per batch into edge_nz (index of a zero row of rn),
+  //     so the tile loop has no clamps and no (c != n) selects;
+  //   * neighbour indices arrive in the accumulator row layout (four int4 per lane), no cross-lane moves;
+  //   * the segment maximum is taken on h2 + b2 and rectified once per segment, not per element.
   // ---- prefetch state for the first tile
-  int nx_c = -1, nx_n = -1;
-  { const int e = t0 * 32 + col; if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; } }
+  int nx_c = -1;
+  { const int e = t0 * 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
   f32x4 pa[4];
   {
     const float* ap = a.pw + (size_t)min(t0 * 32 + col, a.n_edge - 1) * D_E + 4 * half;
 #pragma unroll
     for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
   }
+  // neighbour rows of this lane's 16 accumulator rows crow(r, half) = 8 (r >> 2) + 4 half + (r & 3)
+  int4 nz4[4];
+#define EF_LOAD_NZ(tile_)                                                                              \
+  do {                                                                                                 \
+    const int4* np_ = reinterpret_cast<const int4*>(a.edge_nz + (size_t)(tile_) * 32 + 4 * half);      \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) nz4[g_] = np_[2 * g_];                            \
+  } while (0)
+#define EF_NZ(r_) (((r_) & 3) == 0 ? nz4[(r_) >> 2].x : ((r_) & 3) == 1 ? nz4[(r_) >> 2].y : ((r_) & 3) == 2 ? nz4[(r_) >> 2].z : nz4[(r_) >> 2].w)
+  EF_LOAD_NZ(t0);
   float rn0[16], rn1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const unsigned on = (unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + col;
+    const unsigned on = (unsigned)EF_NZ(r) * D_P + col;
     rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
   }
   // centre rows of the first two segments of the next tile (A = first centre, B = second or the same)
@@ -388,9 +410,9 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
   int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * 32;
-    const int my_c = nx_c, my_n = nx_n;
+    const int my_c = nx_c;
     const int nrows = min(32, a.n_edge - e0);
-    const int tcA = cA, tcB = cB, thiA = hiA;
+    const int thiA = hiA;
     const float trcA0 = rcA0, trcA1 = rcA1, trcB0 = rcB0, trcB1 = rcB1;
     // segment heads of THIS tile (bit r set = row r starts a new centre)
     unsigned heads;
@@ -399,28 +421,26 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
       heads = (unsigned)__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev));
     }
     const int nseg = __popc(heads);
-    nx_c = -1; nx_n = -1;
-    if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; } }
+    nx_c = -1;
+    if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
+    EF_LOAD_NZ(t + 1);                                 // the tail of edge_nz is padded: no bounds check
     f32x16 h1a, h1b;
-    if (nseg <= 2) {                                   // common case: centre rows were prefetched
+    if (nseg == 1) {                                   // one centre fills the tile
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { h1a[r] = trcA0 + rn0[r]; h1b[r] = trcA1 + rn1[r]; }
+    } else if (nseg == 2) {                            // centre rows were prefetched (A below thiA, B from it)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, half);
-        const int n = row_bcast(my_n, r, half);
-        const bool inA = row < thiA;
-        const int c = inA ? tcA : tcB;
-        const float r0 = inA ? trcA0 : trcB0, r1 = inA ? trcA1 : trcB1;
-        h1a[r] = (c != n) ? r0 + rn0[r] : r0;          // self pair: n_feats zeroed (:371-374)
-        h1b[r] = (c != n) ? r1 + rn1[r] : r1;
+        const bool inA = crow(r, half) < thiA;
+        h1a[r] = (inA ? trcA0 : trcB0) + rn0[r];
+        h1b[r] = (inA ? trcA1 : trcB1) + rn1[r];
       }
     } else {                                           // many short segments: gather the centre row per edge
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
-        const unsigned oc = (unsigned)max(c, 0) * D_P + col;
-        const float r0 = a.rc[oc], r1 = a.rc[oc + 32];
-        h1a[r] = (c != n) ? r0 + rn0[r] : r0;
-        h1b[r] = (c != n) ? r1 + rn1[r] : r1;
+        const unsigned oc = (unsigned)max(row_bcast(my_c, r, half), 0) * D_P + col;
+        h1a[r] = a.rc[oc] + rn0[r];
+        h1b[r] = a.rc[oc + 32] + rn1[r];
       }
     }
     {
@@ -448,16 +468,18 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
       for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
     }
     wave_lds_sync();        // the previous tile's layer-2 reads of sh are complete
+    {
+      float* hp = sh + (4 * half) * E_LD2 + col;         // + crow(r, 0) * E_LD2: compile-time offsets
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      sh[row * E_LD2 + col] = fmaxf(h1a[r], 0.f);
-      sh[row * E_LD2 + 32 + col] = fmaxf(h1b[r], 0.f);
+      for (int r = 0; r < 16; ++r) {
+        hp[crow(r, 0) * E_LD2] = fmaxf(h1a[r], 0.f);
+        hp[crow(r, 0) * E_LD2 + 32] = fmaxf(h1b[r], 0.f);
+      }
     }
     wave_lds_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned on = (unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + col;
+      const unsigned on = (unsigned)EF_NZ(r) * D_P + col;
       rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
     }
     {
@@ -469,29 +491,71 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
       rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col]; rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
     }
     f32x16 h2a = zero16(), h2b = zero16();
-    mma_abt<D_P>(h2a, sh, E_LD2, sW2, E_LD2, lane);
-    mma_abt<D_P>(h2b, sh, E_LD2, sW2 + 32 * E_LD2, E_LD2, lane);
+    {                                                   // both column tiles share the A fragments of h1
+      const float* ap = sh + col * E_LD2 + 4 * half;
+      const float* b0 = sW2 + col * E_LD2 + 4 * half;
+      const float* b1 = b0 + 32 * E_LD2;
+#pragma unroll 4
+      for (int k = 0; k < D_P; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
+      }
+    }
+    // pre-activations; relu is monotone, so max(relu(v)) = relu(max(v)): rectify once per segment.  The
+    // tie count is the number of rows equal to the maximum (when the maximum is <= 0 every gradient through
+    // it is zero and only count >= 1 matters).
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { h2a[r] = fmaxf(h2a[r] + bias0, 0.f); h2b[r] = fmaxf(h2b[r] + bias1, 0.f); }
+    for (int r = 0; r < 16; ++r) { h2a[r] += bias0; h2b[r] += bias1; }
     // ---- wave-uniform segment loop
     unsigned hleft = heads;
+    const bool whole = nseg == 1 && nrows == 32;       // one centre fills the tile: no row masks
     while (hleft) {
       const int lo = __builtin_ctz(hleft);
       hleft &= hleft - 1;
       const int hi = hleft ? __builtin_ctz(hleft) : nrows;
       const int cseg = __builtin_amdgcn_readlane(my_c, lo);
-      float s0 = 0.f, s1 = 0.f; unsigned q0 = 0, q1 = 0;          // values are >= 0: (0, 0) is neutral
+      float s0, s1; unsigned q0 = 0, q1 = 0;
+      if (whole) {
+        s0 = h2a[0]; s1 = h2b[0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, half);
-        const bool in = row >= lo && row < hi;
-        // rows outside the segment contribute (-1, 0): never the maximum of non-negative values
-        segmax_merge(s0, q0, in ? h2a[r] : -1.f, in ? 1u : 0u);
-        segmax_merge(s1, q1, in ? h2b[r] : -1.f, in ? 1u : 0u);
+        for (int r = 1; r < 16; ++r) { s0 = fmaxf(s0, h2a[r]); s1 = fmaxf(s1, h2b[r]); }
+        s0 = fmaxf(s0, __shfl_xor(s0, 32));
+        s1 = fmaxf(s1, __shfl_xor(s1, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { q0 += h2a[r] == s0 ? 1u : 0u; q1 += h2b[r] == s1 ? 1u : 0u; }
+      } else {
+        // rows [lo, hi) of the tile; this lane's row crow(r, half) is bit crow(r, 0) of `mine`
+        const unsigned rowmask = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        const unsigned mine = rowmask >> (4 * half);
+        const float ninf = -__builtin_inff();
+        s0 = ninf; s1 = ninf;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool in = (mine >> crow(r, 0)) & 1u;
+          s0 = fmaxf(s0, in ? h2a[r] : ninf);
+          s1 = fmaxf(s1, in ? h2b[r] : ninf);
+        }
+        s0 = fmaxf(s0, __shfl_xor(s0, 32));
+        s1 = fmaxf(s1, __shfl_xor(s1, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool in = (mine >> crow(r, 0)) & 1u;
+          q0 += (in && h2a[r] == s0) ? 1u : 0u;
+          q1 += (in && h2b[r] == s1) ? 1u : 0u;
+        }
       }
-      // fold the two half-waves (they hold different rows of the same columns)
-      segmax_merge(s0, q0, __shfl_xor(s0, 32), __shfl_xor(q0, 32));
-      segmax_merge(s1, q1, __shfl_xor(s1, 32), __shfl_xor(q1, 32));
+      s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
+      q0 += __shfl_xor(q0, 32);
+      q1 += __shfl_xor(q1, 32);
       if (cseg == cur) {
         segmax_merge(m0, k0, s0, q0);
         segmax_merge(m1, k1, s1, q1);
@@ -514,6 +578,8 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
     if (interior) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
     else pm_flush(dst, mm, kk);
   }
+#undef EF_LOAD_NZ
+#undef EF_NZ
 }
 
 // ------------------------------------------------------------------------------------------
@@ -620,6 +686,8 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
         if (node < a.n_det) dst[(size_t)node * D_P + 32 * nt + col] = acc[r] + bb;
       }
     }
+    // row n_det of rn stays zero: the edge kernels read it for self pairs (edge_nz)
+    if (blockIdx.x == 0 && tid < D_P) a.rn[(size_t)a.n_det * D_P + tid] = 0.f;
   }
   if (a.do_head) {
     __syncthreads();
@@ -687,8 +755,8 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.n_edge = E; g.edge_c = buf->edge_c; g.edge_n = buf->edge_n; g.edge_iou = buf->edge_iou;
     g.dets = (const float4*)in->dets; g.scores = in->det_scores; g.classes = in->det_classes;
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
-    g.geo = buf->geo; g.einfo = (int4*)buf->einfo;
-    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, edge_geometry<<<(E + 255) / 256, 256, 0, s>>>(g));
+    g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N;
+    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
     a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.einfo = (const int4*)buf->einfo;
     a.w1 = params + L.pw1; a.b1 = params + L.pb1;
@@ -734,6 +802,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.rc = buf->blk_rc[b + 1]; e.rn = buf->blk_rn[b + 1];
         e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
         e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
+        e.edge_nz = buf->edge_nz;
         // default: variant W (wave-owned tiles, 2 workgroups per CU); GNET_EDGE_FWD_W=0 selects the
         // cooperative 64-edge-tile kernel (kept for A/B measurements)
         static const int variant_w = getenv("GNET_EDGE_FWD_W") ? atoi(getenv("GNET_EDGE_FWD_W")) : 2;

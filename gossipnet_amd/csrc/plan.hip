@@ -37,6 +37,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
   b.edge_n = c.take<int32_t>(Ep);
   b.edge_iou = c.take<float>(Ep);
   b.edge_t = c.take<int32_t>(Ep);
+  b.edge_nz = c.take<int32_t>(Ep);
   b.pw_feats = c.take<float>(Ep * D_E);
   b.packed_t = c.take<float>((size_t)L.total);
   b.prediction = c.take<float>(Np);

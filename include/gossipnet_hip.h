@@ -87,6 +87,7 @@ typedef struct gnet_buffers {
   int32_t* edge_n;    /* [n_edge] pair_n_idxs          */
   float* edge_iou;    /* [n_edge] det_det_iou at pairs */
   int32_t* edge_t;    /* [n_edge] index of the reversed pair (n,c); the graph is symmetric */
+  int32_t* edge_nz;   /* [n_edge+64] neighbour index for the rn gathers: n_det (a zero row) for self pairs and the tail */
   float* geo;         /* [n_edge,8] 7 geometry columns of _geometry_feats (+pad) */
   int32_t* einfo;     /* [n_edge,4] fc1 rows of the centre/neighbour score columns + the two scores (bits) */
   float* pw_h1;       /* [n_edge,256]  pw_feats/fc1 output (training)            */

@@ -1,0 +1,88 @@
+// Micro-benchmark: do fp32 MFMAs and VALU instructions overlap on a CDNA4 SIMD?
+//   mode 1: MFMA only      mode 2: VALU only      mode 3: both in one wave's loop
+//   mode 4: 8-wave workgroups, waves 0-3 MFMA only, waves 4-7 VALU only (two waves per SIMD)
+//   mode 5: 8-wave workgroups, every wave alternates a pure MFMA phase and a pure VALU phase
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o gpurun_out/overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VALU8(x) \
+  asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n" \
+               "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n" \
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(a), "v"(b))
+
+template <int NM, int NV>
+__global__ void __launch_bounds__(512) bench(float* out, int iters, int mode) {
+  f32x16 acc0, acc1;
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+  const float a = 0.999f, b = 0.001f;
+  const int wave = threadIdx.x >> 6;
+  const bool split = mode == 4;
+  const bool do_m = mode == 1 || mode == 3 || (split && wave < 4);
+  const bool do_v = mode == 2 || mode == 3 || (split && wave >= 4);
+  if (mode == 5) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < NM; ++j) { acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0); }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { VALU8(x); }
+    }
+  } else if (do_m && do_v) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < NM; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NV / NM; ++q) { VALU8(x); }
+      }
+    }
+  } else if (do_m) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < NM; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+    }
+  } else if (do_v) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { VALU8(x); }
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+  for (int i = 0; i < 8; ++i) s += x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NM, int NV>
+void run(const char* name, int mode, int threads, float* out) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 2000;
+  bench<NM, NV><<<256, threads>>>(out, 10, mode);
+  hipEventRecord(e0);
+  bench<NM, NV><<<256, threads>>>(out, iters, mode);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  // per wave per iteration: NM MFMAs (64 cycles each), NV*8 VALU (4 cycles each)
+  printf("%-46s NM=%2d NV8=%2d threads=%d  %.3f ms  -> %.0f ns/iter (MFMA alone %.0f cyc, VALU alone %.0f cyc)\n", name, NM, NV, threads, ms,
+         ms * 1e6 / iters, NM * 64.0, NV * 8 * 4.0);
+}
+
+int main() {
+  float* out; hipMalloc(&out, 256 * 512 * sizeof(float));
+  run<16, 16>("1 MFMA only, 1 wave/SIMD", 1, 256, out);
+  run<16, 16>("2 VALU only, 1 wave/SIMD", 2, 256, out);
+  run<16, 16>("3 interleaved in one wave, 1 wave/SIMD", 3, 256, out);
+  run<16, 16>("5 phases MFMA then VALU, 1 wave/SIMD", 5, 256, out);
+  run<16, 16>("1 MFMA only, 2 waves/SIMD", 1, 512, out);
+  run<16, 16>("2 VALU only, 2 waves/SIMD", 2, 512, out);
+  run<16, 16>("3 interleaved, 2 waves/SIMD", 3, 512, out);
+  run<16, 16>("4 split: waves 0-3 MFMA, 4-7 VALU", 4, 512, out);
+  run<16, 16>("5 phases MFMA then VALU, 2 waves/SIMD", 5, 512, out);
+  run<16, 32>("3 interleaved, 2 waves/SIMD", 3, 512, out);
+  run<16, 32>("4 split: waves 0-3 MFMA, 4-7 VALU", 4, 512, out);
+  run<16, 32>("5 phases MFMA then VALU, 2 waves/SIMD", 5, 512, out);
+  return 0;
+}
