@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
 struct EdgeBwdArgs {
   int n_edge; int n_det;
   int accumulate_dpw;               // 0 for the first block processed (writes), 1 afterwards (adds)
-  const int* edge_c; const int* edge_n;
+  const int* edge_c; const int* edge_nz;   // edge_nz: neighbour index, n_det (zero row of rn) for self pairs / the tail
   const float* pw; const float* rc; const float* rn;
   const unsigned long long* pm; const float* d_pc;
   const float* w1t; const float* w2t; const float* b2;   // transposed copies (forward recompute)
@@ -413,12 +413,12 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
   // one-tile-ahead prefetch: indices of this wave's rows and this thread's two float4 of the P tile
-  int nx_c = -1, nx_n = -1;
+  int nx_c = -1;
   float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
   const int prow0 = tid >> 3, pc4 = tid & 7;                        // P tile: thread -> (row, float4) x 2
   if (t0 < t1) {
     const int e = t0 * EB_T + 32 * mt + col;
-    if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
+    if (e < a.n_edge) nx_c = a.edge_c[e];
     const int last = a.n_edge - 1;
     pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + prow0, last) * D_E + 4 * pc4);
     pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
@@ -435,14 +435,14 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   int4 nn4[4];
 #define EB_LOAD_NN(tile_)                                                                              \
   do {                                                                                                 \
-    const int4* np_ = reinterpret_cast<const int4*>(a.edge_n + (size_t)(tile_) * EB_T + 32 * mt + 4 * half); \
+    const int4* np_ = reinterpret_cast<const int4*>(a.edge_nz + (size_t)(tile_) * EB_T + 32 * mt + 4 * half); \
     _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) nn4[g_] = np_[2 * g_];                            \
   } while (0)
 #define EB_NN(r_) (((r_) & 3) == 0 ? nn4[(r_) >> 2].x : ((r_) & 3) == 1 ? nn4[(r_) >> 2].y : ((r_) & 3) == 2 ? nn4[(r_) >> 2].z : nn4[(r_) >> 2].w)
 #define EB_PREFETCH_NEXT()                                                                             \
   do {                                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
-      rnv[r] = a.rn[(unsigned)min(max(EB_NN(r), 0), a.n_det - 1) * D_P + 32 * nt + col];               \
+      rnv[r] = a.rn[(unsigned)EB_NN(r) * D_P + 32 * nt + col];                                         \
     cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;                                      \
     const int prev_ = __shfl_up(nx_c, 1);                                                              \
     const unsigned hm_ = (unsigned)__ballot(half == 0 && col > 0 && nx_c != prev_ && nx_c >= 0);       \
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * EB_T + 32 * mt;                              // first edge of this wave's rows
-    const int my_c = nx_c, my_n = nx_n;
+    const int my_c = nx_c;
     const int nrows = min(32, a.n_edge - e0);                       // may be <= 0 for the last tile
     const int thiA = hiA;
     const float trcA = rcA, tpmA = pmA, tdpA = dpA, trcB = rcB, tpmB = pmB, tdpB = dpB;
@@ -466,37 +466,34 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       nseg = __popcll(__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev)));
     }
     const bool simple = nseg <= 2;                                  // wave-uniform
-    // bit crow(r, 0) of `selfm` = this lane's row crow(r, half) is a self pair (c == n)
-    const unsigned selfm = (unsigned)__ballot(half == 0 && my_c == my_n) >> (4 * half);
     float* sAp = sA + (32 * mt + 4 * half) * LD64 + 32 * nt + col;   // + crow(r, 0) * LD64 = row crow(r, half)
     float* sBp = sB + (32 * mt + 4 * half) * LD64 + 32 * nt + col;
     const int tvalid = min(EB_T, a.n_edge - t * EB_T) * D_E;        // valid floats of the d_pw tile
     float* dpw_tile = a.d_pw + (size_t)(t * EB_T) * D_E;
     *reinterpret_cast<float4*>(sP + prow0 * LD32 + 4 * pc4) = pf0;
     *reinterpret_cast<float4*>(sP + (32 + prow0) * LD32 + 4 * pc4) = pf1;
-    nx_c = -1; nx_n = -1;
+    nx_c = -1;
     if (t + 1 < t1) {
       EB_LOAD_NN(t + 1);
       const int e = e0 + EB_T + col;
-      if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
+      if (e < a.n_edge) nx_c = a.edge_c[e];
       const int last = a.n_edge - 1;
       pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + prow0, last) * D_E + 4 * pc4);
       pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
     }
     // ---- S1: h1 = relu(P . Wp + rc[c] + (c != n) rn[n]) for this wave's quadrant
+    // (self pairs read a zero row of rn through edge_nz: n_feats zeroed, network.py:371-374)
     f32x16 h1;
-    if (simple) {                                                   // centre rows were prefetched (A / B)
+    if (nseg == 1) {                                                // one centre in this wave's 32 rows
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float rcv = (crow(r, half) < thiA) ? trcA : trcB;
-        h1[r] = ((selfm >> crow(r, 0)) & 1u) ? rcv : rcv + rnv[r];   // self pair: n_feats zeroed (:371-374)
-      }
+      for (int r = 0; r < 16; ++r) h1[r] = trcA + rnv[r];
+    } else if (simple) {                                            // centre rows were prefetched (A / B)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[r] = ((crow(r, half) < thiA) ? trcA : trcB) + rnv[r];
     } else {                                                        // many short segments: gather per edge
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float rcv = a.rc[(unsigned)max(row_bcast(my_c, r, half), 0) * D_P + 32 * nt + col];
-        h1[r] = ((selfm >> crow(r, 0)) & 1u) ? rcv : rcv + rnv[r];
-      }
+      for (int r = 0; r < 16; ++r)
+        h1[r] = a.rc[(unsigned)max(row_bcast(my_c, r, half), 0) * D_P + 32 * nt + col] + rnv[r];
     }
     __syncthreads();                                                // B0: P tile in LDS
     {
@@ -512,18 +509,28 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
         h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, h1, 0, 0, 0);
       }
     }
-    unsigned h1mask = 0;                                            // ReLU mask of h1 (bit r = row crow(r, half))
+    // h1 stays in registers for the ReLU mask of g1 (every vector instruction costs MFMA time: the fp32
+    // MFMA runs on the same FP32 lanes -- tools/mfma_valu_overlap.hip -- so no bit masks are built)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float v = fmaxf(h1[r], 0.f);
-      h1mask |= (v > 0.f ? 1u : 0u) << r;
-      sAp[crow(r, 0) * LD64] = v;
+      h1[r] = fmaxf(h1[r], 0.f);
+      sAp[crow(r, 0) * LD64] = h1[r];
     }
     __syncthreads();                                                // B1: h1 tile complete
     // ---- S2: h2 = relu(h1 . W2 + b2); d h2 = SegmentMax tie split + ReLU mask
     f32x16 d2 = zero16();
     mma_abt<D_P>(d2, sA + 32 * mt * LD64, LD64, sW2T + 32 * nt * LD64, LD64, lane);
-    if (simple) {
+    if (nseg == 1 && nrows >= 32) {
+      // relu(v) == max > 0  <=>  v == max: one compare per element against the maximum (NaN when the
+      // maximum is 0: nothing passes the ReLU then)
+      const float pmq = tpmA > 0.f ? tpmA : __builtin_nanf("");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = (d2[r] + bias == pmq) ? tdpA : 0.f;
+        gb2 += x;
+        sBp[crow(r, 0) * LD64] = x;
+      }
+    } else if (simple) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = fmaxf(d2[r] + bias, 0.f);
@@ -589,11 +596,20 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order.
       // row crow(r, half) = crow(r, 0) + 4 half: per-lane base + compile-time row offsets
       float* g1p = a.d_g1 + (size_t)e0 * D_P + (4 * half) * D_P + 32 * nt + col;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = ((h1mask >> r) & 1u) ? g1[r] : 0.f;
-        sAp[crow(r, 0) * LD64] = v;
-        if (full || crow(r, half) < nrows) g1p[crow(r, 0) * D_P] = v;
+        for (int r = 0; r < 16; ++r) {
+          const float v = h1[r] > 0.f ? g1[r] : 0.f;
+          sAp[crow(r, 0) * LD64] = v;
+          g1p[crow(r, 0) * D_P] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = h1[r] > 0.f ? g1[r] : 0.f;
+          sAp[crow(r, 0) * LD64] = v;
+          if (crow(r, half) < nrows) g1p[crow(r, 0) * D_P] = v;
+        }
       }
     }
     __syncthreads();                                                // B4: g1 tile complete
@@ -917,7 +933,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
-  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1) return GNET_ERR_INVALID;   // plan(training=1)
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->edge_nz) return GNET_ERR_INVALID;   // plan(training=1)
   hipStream_t s = (hipStream_t)stream;
   const ParamLayout L = make_layout(cfg);
   const int B = cfg->num_blocks;
@@ -968,7 +984,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     if (E > 0) {
       EdgeBwdArgs e;
       e.n_edge = E; e.n_det = N; e.accumulate_dpw = b != B;
-      e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
+      e.edge_c = buf->edge_c; e.edge_nz = buf->edge_nz; e.pw = buf->pw_feats;
       e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b];
       e.pm = (const unsigned long long*)buf->blk_pm[b]; e.d_pc = buf->d_pc;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2; e.b2 = params + K.b2; e.w1 = params + K.w1; e.w2 = params + K.w2;

@@ -350,22 +350,26 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
   m = gt ? m2 : m;
 }
 
-__global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float sWp[D_P * E_LD1];      // [64][36]  Wp^T
-  __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]  W2^T
-  __shared__ __attribute__((aligned(16))) float sHw[4][32 * E_LD2];    // per wave [32][68]
+constexpr int EFW_WAVES = 4;      // waves per workgroup; 2 workgroups per CU.  (6 waves = 3 per SIMD measured 28% SLOWER)
+constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 32 * E_LD2) * sizeof(float);
+
+__global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sWp = smem;                           // [64][36]  Wp^T
+  float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T
+  float* sHw = sW2 + D_P * E_LD2;              // per wave [32][68]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < D_P * D_E; i += 256) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
-  for (int i = tid; i < D_P * D_P; i += 256) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
+  for (int i = tid; i < D_P * D_E; i += 64 * EFW_WAVES) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 64 * EFW_WAVES) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
   __syncthreads();
   const int col = lane & 31, half = lane >> 5;
   const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
   const int ntiles = (a.n_edge + 31) / 32;
-  const int nwaves = gridDim.x * 4;
+  const int nwaves = gridDim.x * EFW_WAVES;
   const int per = (ntiles + nwaves - 1) / nwaves;
-  const int gw = blockIdx.x * 4 + wave;
+  const int gw = blockIdx.x * EFW_WAVES + wave;
   const int t0 = gw * per, t1 = min(ntiles, t0 + per);
-  float* sh = sHw[wave];
+  float* sh = sHw + wave * (32 * E_LD2);
   if (t0 >= t1) return;
   const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
   // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
@@ -408,6 +412,8 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
   float rcA0 = a.rc[(unsigned)max(cA, 0) * D_P + col], rcA1 = a.rc[(unsigned)max(cA, 0) * D_P + 32 + col];
   float rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col], rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
   int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
+  // does the first centre of this range start in the previous wave's range?
+  bool head_shared = e_begin > 0 && a.edge_c[e_begin - 1] == cA;
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * 32;
     const int my_c = nx_c;
@@ -561,21 +567,24 @@ __global__ void __launch_bounds__(256, 2) edge_fwd_w(const EdgeFwdArgs a) {
         segmax_merge(m1, k1, s1, q1);
       } else {
         if (cur >= 0) {                                           // the previous centre is complete
-          const bool interior = a.row_ptr[cur] >= e_begin && a.row_ptr[cur + 1] <= e_end;
+          // edges are sorted by centre: only the first centre of this wave's range can have begun in
+          // another wave's range; every later one that completes here lies entirely inside it
           unsigned long long* dst = a.pm + (size_t)cur * D_P + 32 * half + col;
           const float mm = half ? m1 : m0; const unsigned kk = half ? k1 : k0;
-          if (interior) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
+          if (!head_shared) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
           else pm_flush(dst, mm, kk);
+          head_shared = false;
         }
         cur = cseg; m0 = s0; k0 = q0; m1 = s1; k1 = q1;
       }
     }
   }
   if (cur >= 0) {
-    const bool interior = a.row_ptr[cur] >= e_begin && a.row_ptr[cur + 1] <= e_end;
+    // the last centre may continue in the next wave's range
+    const bool tail_shared = e_end < a.n_edge && a.edge_c[e_end] == cur;
     unsigned long long* dst = a.pm + (size_t)cur * D_P + 32 * half + col;
     const float mm = half ? m1 : m0; const unsigned kk = half ? k1 : k0;
-    if (interior) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
+    if (!head_shared && !tail_shared) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
     else pm_flush(dst, mm, kk);
   }
 #undef EF_LOAD_NZ
@@ -807,8 +816,13 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         // cooperative 64-edge-tile kernel (kept for A/B measurements)
         static const int variant_w = getenv("GNET_EDGE_FWD_W") ? atoi(getenv("GNET_EDGE_FWD_W")) : 2;
         if (variant_w) {
-          const int wg = max(1, min(variant_w * 256, ((E + 31) / 32 + 3) / 4));
-          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<<<wg, 256, 0, s>>>(e));
+          const int wg = max(1, min(variant_w * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+          static bool attr_w = false;
+          if (!attr_w) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+            attr_w = true;
+          }
+          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e));
         } else {
           GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd<<<egrid, 256, 0, s>>>(e));
         }
