@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sD2[32 * LD128];
   __shared__ __attribute__((aligned(16))) float sD1[32 * LD128];
   __shared__ float sDl[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   f32x16 aW2[1][4], aW1[1][4];
 #pragma unroll
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) blk_bwd_post(const BlkPostArgs a) {
   __shared__ __attribute__((aligned(16))) float sP[32 * LD64];
   __shared__ __attribute__((aligned(16))) float sDq[32 * LD64];
   __shared__ __attribute__((aligned(16))) float sR[2 * 32 * D_P];   // K-half partials
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   f32x16 aW4[2][1], aW3[1][1];
   aW4[0][0] = zero16(); aW4[1][0] = zero16(); aW3[0][0] = zero16();
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
   __shared__ __attribute__((aligned(16))) float sDr[32 * LD32];
   __shared__ __attribute__((aligned(16))) float sX[32 * LD128];
   __shared__ __attribute__((aligned(16))) float sPart[4 * 32 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   f32x16 aWcn = zero16(), aWr = zero16();
   float gb1 = 0.f, gbr = 0.f;
@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   float* sA = sW2T + D_P * LD64;          // [64][68]  h1, later g1
   float* sB = sA + EB_T * LD64;           // [64][68]  d h2, later the K-split partials of d P
   float* sP = sB + EB_T * LD64;           // [64][36]  P tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: mt, nt and every tile offset stay in SGPRs
   for (int i = tid; i < D_P * D_E; i += 256) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
   for (int i = tid; i < D_P * D_P; i += 256) sW2T[(i >> 6) * LD64 + (i & 63)] = a.w2t[i];
   const int col = lane & 31, half = lane >> 5;
@@ -433,6 +434,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   // neighbour indices of this lane's 16 rows: rows crow(r, half) = 8 (r>>2) + 4 half + (r&3) are four groups of
   // four consecutive edges -> four 16-byte loads (edge buffers carry 64 entries of slack; clamped)
   int4 nn4[4];
+  const unsigned lane_b = (unsigned)(32 * nt + col) * 4u;           // byte offset of this lane's column in a 64-float row
 #define EB_LOAD_NN(tile_)                                                                              \
   do {                                                                                                 \
     const int4* np_ = reinterpret_cast<const int4*>(a.edge_nz + (size_t)(tile_) * EB_T + 32 * mt + 4 * half); \
@@ -442,14 +444,14 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
 #define EB_PREFETCH_NEXT()                                                                             \
   do {                                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
-      rnv[r] = a.rn[(unsigned)EB_NN(r) * D_P + 32 * nt + col];                                         \
+      rnv[r] = ldg_b(a.rn, (unsigned)EB_NN(r) * (D_P * 4u) + lane_b);                                  \
     cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;                                      \
     const int prev_ = __shfl_up(nx_c, 1);                                                              \
     const unsigned hm_ = (unsigned)__ballot(half == 0 && col > 0 && nx_c != prev_ && nx_c >= 0);       \
     if (hm_) { hiA = __builtin_ctz(hm_); cB = __builtin_amdgcn_readlane(nx_c, hiA); }                  \
-    const unsigned oa_ = (unsigned)max(cA, 0) * D_P + 32 * nt + col, ob_ = (unsigned)max(cB, 0) * D_P + 32 * nt + col; \
-    rcA = a.rc[oa_]; pmA = __uint_as_float(pmw[2 * oa_ + 1]); dpA = a.d_pc[oa_];                       \
-    rcB = a.rc[ob_]; pmB = __uint_as_float(pmw[2 * ob_ + 1]); dpB = a.d_pc[ob_];                       \
+    const unsigned oa_ = (unsigned)max(cA, 0) * (D_P * 4u) + lane_b, ob_ = (unsigned)max(cB, 0) * (D_P * 4u) + lane_b; \
+    rcA = ldg_b(a.rc, oa_); pmA = __uint_as_float(ldg_b(pmw, 2 * oa_ + 4)); dpA = ldg_b(a.d_pc, oa_);   \
+    rcB = ldg_b(a.rc, ob_); pmB = __uint_as_float(ldg_b(pmw, 2 * ob_ + 4)); dpB = ldg_b(a.d_pc, ob_);   \
   } while (0)
   EB_LOAD_NN(min(t0, max(ntiles - 1, 0)));
   EB_PREFETCH_NEXT();
@@ -595,20 +597,21 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     {
       // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order.
       // row crow(r, half) = crow(r, 0) + 4 half: per-lane base + compile-time row offsets
-      float* g1p = a.d_g1 + (size_t)e0 * D_P + (4 * half) * D_P + 32 * nt + col;
+      float* g1t = a.d_g1 + (size_t)e0 * D_P;                       // uniform
+      const unsigned g1o = (unsigned)(4 * half) * (D_P * 4u) + lane_b;
       if (full) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = h1[r] > 0.f ? g1[r] : 0.f;
           sAp[crow(r, 0) * LD64] = v;
-          g1p[crow(r, 0) * D_P] = v;
+          stg_b(g1t, g1o + crow(r, 0) * (D_P * 4u), v);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = h1[r] > 0.f ? g1[r] : 0.f;
           sAp[crow(r, 0) * LD64] = v;
-          if (crow(r, half) < nrows) g1p[crow(r, 0) * D_P] = v;
+          if (crow(r, half) < nrows) stg_b(g1t, g1o + crow(r, 0) * (D_P * 4u), v);
         }
       }
     }
@@ -712,7 +715,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // two tile buffers {h1 [32][260], h2 [32][260]} filled by DMA one tile ahead, + d3 [32][36]
   float* sD3 = smem + 4 * 32 * LD256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   f32x16 aW2[1][8];
 #pragma unroll

@@ -144,6 +144,19 @@ __device__ __forceinline__ void mma_abt(f32x16& acc, const float* A, int lda, co
   }
 }
 
+// Global accesses as (uniform base pointer) + (32-bit byte offset): selects the "saddr + voffset" form of
+// global_load / global_store, one 32-bit VALU op per address instead of the 64-bit pointer arithmetic of
+// base[index] (3-4 VALU ops).  Vector instructions are paid in MFMA time (the fp32 MFMA shares the FP32 lanes).
+__device__ __forceinline__ float ldg_b(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ unsigned ldg_b(const unsigned* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg_b(float* __restrict__ base, unsigned byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // Two row tiles (A0, A1) against the same Bt (B fetched once).
 template <int K>
 __device__ __forceinline__ void mma_abt2(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1,

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
   float* sR = sH;                            // [4][64][32] fc3 partials, aliased over sH (2 workgroups / CU)
   float* sGeo = sH + PW_T * PW_LD;           // [64][8]
   int4* sInf = reinterpret_cast<int4*>(sGeo + PW_T * 8);   // [64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = tid & 255, eh = tid >> 8;
   const int geo_row0 = 2 * a.cprime;
   float wg[7];
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]  W2^T
   __shared__ __attribute__((aligned(16))) float sH1[EF_T * E_LD2];     // [64][68]
   __shared__ __attribute__((aligned(16))) float sP[EF_T * E_LD1];      // [64][36]  P tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < D_P * D_E; i += 256) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
   for (int i = tid; i < D_P * D_P; i += 256) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
   const int col = lane & 31, half = lane >> 5;
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
   float* sWp = smem;                           // [64][36]  Wp^T
   float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T
   float* sHw = sW2 + D_P * E_LD2;              // per wave [32][68]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < D_P * D_E; i += 64 * EFW_WAVES) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
   for (int i = tid; i < D_P * D_P; i += 64 * EFW_WAVES) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
   __syncthreads();
@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[32 * N_LD];
   __shared__ __attribute__((aligned(16))) float sY[32 * N_LD];
   __shared__ __attribute__((aligned(16))) float sR[4 * 32 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int row0 = blockIdx.x * 32;
   if (a.do_post) {
