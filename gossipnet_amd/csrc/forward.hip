@@ -118,71 +118,132 @@ struct PwFwdArgs {
   int training;
 };
 
+// Memory discipline (vmcnt is one in-order counter for loads AND stores: a wait on a load also waits for
+// every older store to be acknowledged by L2, ~1-2 k cycles): inside a tile no global load is issued
+// behind a store.  The tile's 32 neighbour rows of W1 are all requested before the first is used; h1 and
+// h2 leave through LDS as whole 1 KB rows (one 16-byte store per lane) after the MFMA phase that reads
+// them; the next tile's geometry and the fc3 operand (W3) are fetched into registers before those stores.
 __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                          // [64][260]
   float* sR = sH;                            // [4][64][32] fc3 partials, aliased over sH (2 workgroups / CU)
-  float* sGeo = sH + PW_T * PW_LD;           // [64][8]
-  int4* sInf = reinterpret_cast<int4*>(sGeo + PW_T * 8);   // [64]
+  float* sStage = sH + PW_T * PW_LD;         // 2 x { geo [64][8], (row, score) records [64] }: this tile / the next
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int f = tid & 255, eh = tid >> 8;
+  const int f = tid & 255, eh = wave >> 2;   // eh (scalar): which of the two interleaved edge sets
+  const int col = lane & 31, half = lane >> 5;
   const int geo_row0 = 2 * a.cprime;
   float wg[7];
 #pragma unroll
   for (int g = 0; g < 7; ++g) wg[g] = a.w1[(size_t)(geo_row0 + g) * D_H + f];
   const float bias1 = a.b1[f];
+  const float bias2 = a.b2[32 * wave + col];
+  const float bias3 = a.b3[tid & 31];
+  // fc3: wave = (row tile mt, K quarter kq)
+  const int mt = wave & 1, kq = wave >> 1;
+  // staging registers of the next tile: threads 0-127 one float4 of geo, 128-191 one (row, score) record
+  float4 st_geo = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 st_inf = make_int4(0, 0, 0, 0);
+  const int last = a.n_edge - 1;
+#define PW_PREFETCH(tile_)                                                                              \
+  do {                                                                                                  \
+    if (tid < 2 * PW_T) {                                                                               \
+      const int e_ = min((tile_) * PW_T + (tid >> 1), last);                                            \
+      st_geo = *reinterpret_cast<const float4*>(a.geo + (size_t)e_ * 8 + 4 * (tid & 1));               \
+    } else if (tid < 3 * PW_T) {                                                                        \
+      st_inf = a.einfo[min((tile_) * PW_T + tid - 2 * PW_T, last)];                                     \
+    }                                                                                                   \
+  } while (0)
+  if ((int)blockIdx.x * PW_T < a.n_edge) {
+    PW_PREFETCH((int)blockIdx.x);
+    if (tid < 2 * PW_T) *reinterpret_cast<float4*>(sStage + (tid >> 1) * 8 + 4 * (tid & 1)) = st_geo;
+    else if (tid < 3 * PW_T) reinterpret_cast<int4*>(sStage + PW_T * 8)[tid - 2 * PW_T] = st_inf;
+  }
+  int it = 0;
 
-  for (int tile = blockIdx.x; tile * PW_T < a.n_edge; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile * PW_T < a.n_edge; tile += gridDim.x, ++it) {
     const int e0 = tile * PW_T;
-    // ---- phase 0: stage the tile's geometry columns and (row, score) pairs
-    if (tid < 2 * PW_T) {
-      const int el = tid >> 1, hf = tid & 1;
-      const int e = min(e0 + el, a.n_edge - 1);
-      *reinterpret_cast<float4*>(sGeo + el * 8 + 4 * hf) = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4 * hf);
-    } else if (tid < 3 * PW_T) {
-      const int el = tid - 2 * PW_T;
-      sInf[el] = a.einfo[min(e0 + el, a.n_edge - 1)];
-    }
+    // ---- phase 0: the tile's geometry columns and (row, score) pairs were staged during the previous tile
+    const float* sGeo = sStage + (it & 1) * (PW_T * 12);
+    const int4* sInf = reinterpret_cast<const int4*>(sGeo + PW_T * 8);
+    float* nGeo = sStage + ((it & 1) ^ 1) * (PW_T * 12);
     __syncthreads();
     // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output).  Edges are
-    // sorted by centre, so the centre's row of W1 is re-read only when it changes.
+    // sorted by centre, so the centre's row of W1 is re-read only when it changes (scalar branch: the
+    // pair index is wave-uniform).
     int rc_prev = -1; float wc = 0.f;
-    for (int k = 0; k < PW_T / 2; ++k) {
-      const int el = 2 * k + eh;
-      const int4 inf = sInf[el];
-      if (inf.x != rc_prev) { wc = a.w1[(size_t)inf.x * D_H + f]; rc_prev = inf.x; }
-      float v = __int_as_float(inf.z) * wc;
-      v = fmaf(__int_as_float(inf.w), a.w1[(size_t)inf.y * D_H + f], v);
 #pragma unroll
-      for (int g = 0; g < 7; ++g) v = fmaf(sGeo[el * 8 + g], wg[g], v);
-      v = fmaxf(v + bias1, 0.f);
-      sH[el * PW_LD + f] = v;
-      if (a.training && e0 + el < a.n_edge) a.h1[(size_t)(e0 + el) * D_H + f] = v;
+    for (int kb = 0; kb < PW_T / 2; kb += 16) {        // neighbour rows in two batches of 16 requests
+      float wn[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int ry = __builtin_amdgcn_readfirstlane(sInf[2 * (kb + k) + eh].y);
+        wn[k] = a.w1[(size_t)ry * D_H + f];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int el = 2 * (kb + k) + eh;
+        const int4 inf = sInf[el];
+        const int rx = __builtin_amdgcn_readfirstlane(inf.x);
+        if (rx != rc_prev) { wc = a.w1[(size_t)rx * D_H + f]; rc_prev = rx; }
+        float v = __int_as_float(inf.z) * wc;
+        v = fmaf(__int_as_float(inf.w), wn[k], v);
+#pragma unroll
+        for (int g = 0; g < 7; ++g) v = fmaf(sGeo[el * 8 + g], wg[g], v);
+        sH[el * PW_LD + f] = fmaxf(v + bias1, 0.f);
+        __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting every edge's LDS reads (spills)
+      }
     }
     __syncthreads();
     // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
     f32x16 acc0 = zero16(), acc1 = zero16();
     mma_abt2_gB<D_H, 4>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
-    const int col = lane & 31, half = lane >> 5;
-    const float bias2 = a.b2[32 * wave + col];
+    // requested before this tile's stores: the next tile's geometry
+    {
+      const int next = tile + (int)gridDim.x;
+      if (next * PW_T < a.n_edge) PW_PREFETCH(next);
+    }
+    if (a.training) {      // fc1 activations: rows [8 wave, 8 wave + 8) of the tile (rows past E land in the slack)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = 8 * wave + q;
+        *reinterpret_cast<float4*>(a.h1 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
+      }
+    }
     __syncthreads();   // every wave has finished reading fc1 activations
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, half);
-      const float v0 = fmaxf(acc0[r] + bias2, 0.f), v1 = fmaxf(acc1[r] + bias2, 0.f);
-      sH[row * PW_LD + 32 * wave + col] = v0;
-      sH[(32 + row) * PW_LD + 32 * wave + col] = v1;
-      if (a.training) {
-        if (e0 + row < a.n_edge) a.h2[(size_t)(e0 + row) * D_H + 32 * wave + col] = v0;
-        if (e0 + 32 + row < a.n_edge) a.h2[(size_t)(e0 + 32 + row) * D_H + 32 * wave + col] = v1;
-      }
+      sH[row * PW_LD + 32 * wave + col] = fmaxf(acc0[r] + bias2, 0.f);
+      sH[(32 + row) * PW_LD + 32 * wave + col] = fmaxf(acc1[r] + bias2, 0.f);
     }
+    // fc3 operand of this wave (its wait sits two barriers behind the h1 stores, which are long acknowledged)
+    f32x4 w3f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3t + (size_t)col * D_H + 64 * kq + 4 * half + 8 * k);
     __syncthreads();
     // ---- phase 3: fc3 (256 -> 32): wave = (row tile, K quarter), partial sums through LDS
     {
-      const int mt = wave & 1, kq = wave >> 1;
       f32x16 acc = zero16();
-      mma_abt<64>(acc, sH + mt * 32 * PW_LD + 64 * kq, PW_LD, a.w3t + 64 * kq, D_H, lane);
+      const float* ap = sH + (mt * 32 + col) * PW_LD + 64 * kq + 4 * half;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w3f[k].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w3f[k].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w3f[k].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w3f[k].w, acc, 0, 0, 0);
+      }
+      if (a.training) {    // fc2 activations, same row split
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int row = 8 * wave + q;
+          *reinterpret_cast<float4*>(a.h2 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
+        }
+      }
+      // the next tile's staging data (requested before the stores) -> the other staging buffer
+      if (tid < 2 * PW_T) *reinterpret_cast<float4*>(nGeo + (tid >> 1) * 8 + 4 * (tid & 1)) = st_geo;
+      else if (tid < 3 * PW_T) reinterpret_cast<int4*>(nGeo + PW_T * 8)[tid - 2 * PW_T] = st_inf;
       __syncthreads();   // every wave is done with the fc2 outputs: the partials may overwrite them
 #pragma unroll
       for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
@@ -191,18 +252,17 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 512 * i;
-      const int el = idx >> 5, pf = idx & 31;
-      float v = sR[(0 * PW_T + el) * D_E + pf];
-      v += sR[(1 * PW_T + el) * D_E + pf];
-      v += sR[(2 * PW_T + el) * D_E + pf];
-      v += sR[(3 * PW_T + el) * D_E + pf];
-      v = fmaxf(v + a.b3[pf], 0.f);
-      if (e0 + el < a.n_edge) a.pw[(size_t)(e0 + el) * D_E + pf] = v;
+      float v = sR[0 * PW_T * D_E + idx];
+      v += sR[1 * PW_T * D_E + idx];
+      v += sR[2 * PW_T * D_E + idx];
+      v += sR[3 * PW_T * D_E + idx];
+      a.pw[(size_t)e0 * D_E + idx] = fmaxf(v + bias3, 0.f);     // rows past E land in the buffer's slack
     }
   }
+#undef PW_PREFETCH
 }
 
-constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + PW_T * 8 + 4 * PW_T) * sizeof(float);   // sInf = 4 ints per edge
+constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 2 * (PW_T * 8 + 4 * PW_T)) * sizeof(float);   // records = 4 ints per edge
 
 // ------------------------------------------------------------------------------------------
 // edge_fwd: one wave = one 32-edge tile at a time, 4 independent waves per workgroup sharing the

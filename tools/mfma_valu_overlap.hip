@@ -13,7 +13,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(a), "v"(b))
 
 template <int NM, int NV>
-__global__ void __launch_bounds__(512) bench(float* out, int iters, int mode) {
+__global__ void __launch_bounds__(512) bench(float* out, int iters, int mode, long long* ticks) {
+  const long long c0 = clock64();
   f32x16 acc0, acc1;
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
   float x[8];
@@ -54,20 +55,23 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters, int mode) {
   for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
   for (int i = 0; i < 8; ++i) s += x[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (ticks && blockIdx.x == 0 && threadIdx.x == 0) *ticks = clock64() - c0;
 }
 
 template <int NM, int NV>
 void run(const char* name, int mode, int threads, float* out) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 2000;
-  bench<NM, NV><<<256, threads>>>(out, 10, mode);
+  static long long* ticks = nullptr; if (!ticks) hipMalloc(&ticks, 8);
+  bench<NM, NV><<<256, threads>>>(out, 10, mode, nullptr);
   hipEventRecord(e0);
-  bench<NM, NV><<<256, threads>>>(out, iters, mode);
+  bench<NM, NV><<<256, threads>>>(out, iters, mode, ticks);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
+  long long th = 0; hipMemcpy(&th, ticks, 8, hipMemcpyDeviceToHost);
   // per wave per iteration: NM MFMAs (64 cycles each), NV*8 VALU (4 cycles each)
-  printf("%-46s NM=%2d NV8=%2d threads=%d  %.3f ms  -> %.0f ns/iter (MFMA alone %.0f cyc, VALU alone %.0f cyc)\n", name, NM, NV, threads, ms,
-         ms * 1e6 / iters, NM * 64.0, NV * 8 * 4.0);
+  printf("%-46s NM=%2d NV8=%2d threads=%d  %.3f ms  -> %.0f ns/iter, %.0f s_memtime ticks/iter (MFMA alone %.0f cyc)\n", name, NM, NV, threads, ms,
+         ms * 1e6 / iters, (double)th / iters, NM * 64.0);
 }
 
 int main() {
