@@ -19,6 +19,7 @@
 // Weight gradients are accumulated in MFMA accumulators across a workgroup's tiles and written once
 // per workgroup to an arena; reduce_partials adds them in index order.  There are no float atomics:
 // every sum has a fixed order, so gradients are reproducible run to run.
+#include <type_traits>
 #include "common.hpp"
 
 namespace {
@@ -372,10 +373,11 @@ __global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
 struct EdgeBwdArgs {
   int n_edge; int n_det;
   int accumulate_dpw;               // 0 for the first block processed (writes), 1 afterwards (adds)
-  const int* edge_c; const int* edge_nz;   // edge_nz: neighbour index, n_det (zero row of rn) for self pairs / the tail
-  const float* pw; const float* rc; const float* rn;
+  const int* edge_c;
+  const float* pw;                  // [E,32] pairwise features P
+  const float* h1;                  // [E+64,64] relu(pw_fc1) stored by the forward pass
   const unsigned long long* pm; const float* d_pc;
-  const float* w1t; const float* w2t; const float* b2;   // transposed copies (forward recompute)
+  const float* w1t; const float* w2t; const float* b2;   // transposed copies (w2t: recompute of pw_fc2)
   const float* w1; const float* w2;                       // natural layouts (input gradients)
   float* d_pw; float* d_g1;
   float* arena; long long stride;
@@ -383,16 +385,19 @@ struct EdgeBwdArgs {
 };
 
 // edge_bwd: one workgroup (4 waves) per 64-edge tile; wave (mt, nt) owns edge rows [32mt, 32mt+32)
-// and feature columns [32nt, 32nt+32) of every 64-wide tensor (h1, h2, d h2, g1).  Per tile and wave:
-// 144 MFMAs (16 L1 + 32 L2 + 32 dW2 + 32 g1 + 16 dWp + 16 dP), two LDS tiles shared by the workgroup.
+// and feature columns [32nt, 32nt+32) of every 64-wide tensor (h2, d h2, g1).  Per tile and wave:
+// 128 MFMAs (32 L2 + 32 dW2 + 32 g1 + 16 dWp + 16 dP), two LDS tiles shared by the workgroup.
+// h1 = relu(pw_fc1) is NOT recomputed: the forward pass kept it in HBM (256 B per edge and block), so this
+// kernel has no rc/rn gathers and no layer-1 MFMAs; it streams the h1 and P tiles one tile ahead through
+// registers.  Only pw_fc2 is recomputed (its output is compared with the stored segment maxima).
 // Memory discipline (the L1 stalls on repeated requests to a line that is still in flight):
-//   * centre-side gathers (rc, segment max, tie-split gradient) are issued once per DISTINCT centre --
+//   * centre-side gathers (segment max, tie-split gradient) are issued once per DISTINCT centre --
 //     a detection's ~E/N consecutive edges share them;
-//   * the P tile is fetched once per workgroup (register prefetch one tile ahead -> LDS), not per wave;
-//   * the old d_pw values of the read-modify-write are prefetched at the top of the tile.
+//   * the old d_pw values of the read-modify-write are prefetched before the tile's stores.
 // 70.6 KB of LDS -> 2 independent workgroups per CU.
 constexpr int EB_T = 64;
 
+template <bool ACC>     // ACC: d_pw += (every block but the first one processed)
 __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sWpT = smem;                     // [64][36]  Wp^T  (layer 1; also the B operand of d P)
@@ -416,52 +421,55 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   // one-tile-ahead prefetch: indices of this wave's rows and this thread's two float4 of the P tile
   int nx_c = -1;
   float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
+  float4 hf0 = pf0, hf1 = pf0, hf2 = pf0, hf3 = pf0;               // h1 tile: thread -> (row tid>>4 + 16 i, float4 tid&15)
   const int prow0 = tid >> 3, pc4 = tid & 7;                        // P tile: thread -> (row, float4) x 2
+  const int hrow0 = tid >> 4, hc4 = tid & 15;
+#define EB_LOAD_TILES(tile_)                                                                           \
+  do {                                                                                                 \
+    const int last_ = a.n_edge - 1;                                                                    \
+    pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((tile_) * EB_T + prow0, last_) * D_E + 4 * pc4);      \
+    pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((tile_) * EB_T + 32 + prow0, last_) * D_E + 4 * pc4); \
+    /* rows past the end re-read the last real row: finite data (their d h2 rows are zero) */          \
+    hf0 = *reinterpret_cast<const float4*>(a.h1 + (size_t)min((tile_) * EB_T + hrow0, last_) * D_P + 4 * hc4);       \
+    hf1 = *reinterpret_cast<const float4*>(a.h1 + (size_t)min((tile_) * EB_T + hrow0 + 16, last_) * D_P + 4 * hc4);  \
+    hf2 = *reinterpret_cast<const float4*>(a.h1 + (size_t)min((tile_) * EB_T + hrow0 + 32, last_) * D_P + 4 * hc4);  \
+    hf3 = *reinterpret_cast<const float4*>(a.h1 + (size_t)min((tile_) * EB_T + hrow0 + 48, last_) * D_P + 4 * hc4);  \
+  } while (0)
   if (t0 < t1) {
     const int e = t0 * EB_T + 32 * mt + col;
     if (e < a.n_edge) nx_c = a.edge_c[e];
-    const int last = a.n_edge - 1;
-    pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + prow0, last) * D_E + 4 * pc4);
-    pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
+    EB_LOAD_TILES(t0);
   }
-  // neighbour rows rn[n] of the next tile and the centre-side values of its first centre are gathered
-  // in the middle of the current tile (hidden under its MFMA phases)
-  float rnv[16];
   // centre-side values of the first two segments (A = first centre of this wave's 32 rows, B = the next
   // distinct centre or the same): fetched unconditionally, wave-uniformly, one tile ahead
   int cA = -1, cB = -1, hiA = 32;
-  float rcA = 0.f, pmA = 0.f, dpA = 0.f, rcB = 0.f, pmB = 0.f, dpB = 0.f;
-  // neighbour indices of this lane's 16 rows: rows crow(r, half) = 8 (r>>2) + 4 half + (r&3) are four groups of
-  // four consecutive edges -> four 16-byte loads (edge buffers carry 64 entries of slack; clamped)
-  int4 nn4[4];
+  float pmA = 0.f, dpA = 0.f, pmB = 0.f, dpB = 0.f;
   const unsigned lane_b = (unsigned)(32 * nt + col) * 4u;           // byte offset of this lane's column in a 64-float row
-#define EB_LOAD_NN(tile_)                                                                              \
-  do {                                                                                                 \
-    const int4* np_ = reinterpret_cast<const int4*>(a.edge_nz + (size_t)(tile_) * EB_T + 32 * mt + 4 * half); \
-    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) nn4[g_] = np_[2 * g_];                            \
-  } while (0)
-#define EB_NN(r_) (((r_) & 3) == 0 ? nn4[(r_) >> 2].x : ((r_) & 3) == 1 ? nn4[(r_) >> 2].y : ((r_) & 3) == 2 ? nn4[(r_) >> 2].z : nn4[(r_) >> 2].w)
 #define EB_PREFETCH_NEXT()                                                                             \
   do {                                                                                                 \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
-      rnv[r] = ldg_b(a.rn, (unsigned)EB_NN(r) * (D_P * 4u) + lane_b);                                  \
     cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;                                      \
     const int prev_ = __shfl_up(nx_c, 1);                                                              \
     const unsigned hm_ = (unsigned)__ballot(half == 0 && col > 0 && nx_c != prev_ && nx_c >= 0);       \
     if (hm_) { hiA = __builtin_ctz(hm_); cB = __builtin_amdgcn_readlane(nx_c, hiA); }                  \
     const unsigned oa_ = (unsigned)max(cA, 0) * (D_P * 4u) + lane_b, ob_ = (unsigned)max(cB, 0) * (D_P * 4u) + lane_b; \
-    rcA = ldg_b(a.rc, oa_); pmA = __uint_as_float(ldg_b(pmw, 2 * oa_ + 4)); dpA = ldg_b(a.d_pc, oa_);   \
-    rcB = ldg_b(a.rc, ob_); pmB = __uint_as_float(ldg_b(pmw, 2 * ob_ + 4)); dpB = ldg_b(a.d_pc, ob_);   \
+    pmA = __uint_as_float(ldg_b(pmw, 2 * oa_ + 4)); dpA = ldg_b(a.d_pc, oa_);                          \
+    pmB = __uint_as_float(ldg_b(pmw, 2 * ob_ + 4)); dpB = ldg_b(a.d_pc, ob_);                          \
   } while (0)
-  EB_LOAD_NN(min(t0, max(ntiles - 1, 0)));
   EB_PREFETCH_NEXT();
+  drain_vmem_before_loop();
   __syncthreads();
-  for (int t = t0; t < t1; ++t) {
+  // The tile body exists twice: FULL tiles (all 64 edges exist) run in the loop with unconditional loads and
+  // stores, the one possibly partial tile of the launch runs after it.  Conditional (exec-masked or
+  // branched-around) memory operations inside the loop would shrink the guaranteed number of operations
+  // behind the tile prefetch to almost zero, and the compiler's wait for the prefetch would become a wait
+  // for the previous tile's stores (vmcnt is one in-order counter; see drain_vmem_before_loop).
+  auto tile_body = [&](const int t, auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
     const int e0 = t * EB_T + 32 * mt;                              // first edge of this wave's rows
     const int my_c = nx_c;
-    const int nrows = min(32, a.n_edge - e0);                       // may be <= 0 for the last tile
+    const int nrows = FULL ? 32 : min(32, a.n_edge - e0);           // may be <= 0 for the last tile
     const int thiA = hiA;
-    const float trcA = rcA, tpmA = pmA, tdpA = dpA, trcB = rcB, tpmB = pmB, tdpB = dpB;
+    const float tpmA = pmA, tdpA = dpA, tpmB = pmB, tdpB = dpB;
     int nseg;
     {
       const int prev = __shfl_up(my_c, 1);
@@ -470,59 +478,25 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     const bool simple = nseg <= 2;                                  // wave-uniform
     float* sAp = sA + (32 * mt + 4 * half) * LD64 + 32 * nt + col;   // + crow(r, 0) * LD64 = row crow(r, half)
     float* sBp = sB + (32 * mt + 4 * half) * LD64 + 32 * nt + col;
-    const int tvalid = min(EB_T, a.n_edge - t * EB_T) * D_E;        // valid floats of the d_pw tile
+    const int tvalid = FULL ? EB_T * D_E : min(EB_T, a.n_edge - t * EB_T) * D_E;   // valid floats of the d_pw tile
     float* dpw_tile = a.d_pw + (size_t)(t * EB_T) * D_E;
     *reinterpret_cast<float4*>(sP + prow0 * LD32 + 4 * pc4) = pf0;
     *reinterpret_cast<float4*>(sP + (32 + prow0) * LD32 + 4 * pc4) = pf1;
+    *reinterpret_cast<float4*>(sA + hrow0 * LD64 + 4 * hc4) = hf0;
+    *reinterpret_cast<float4*>(sA + (hrow0 + 16) * LD64 + 4 * hc4) = hf1;
+    *reinterpret_cast<float4*>(sA + (hrow0 + 32) * LD64 + 4 * hc4) = hf2;
+    *reinterpret_cast<float4*>(sA + (hrow0 + 48) * LD64 + 4 * hc4) = hf3;
     nx_c = -1;
     if (t + 1 < t1) {
-      EB_LOAD_NN(t + 1);
       const int e = e0 + EB_T + col;
       if (e < a.n_edge) nx_c = a.edge_c[e];
-      const int last = a.n_edge - 1;
-      pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + prow0, last) * D_E + 4 * pc4);
-      pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EB_T + 32 + prow0, last) * D_E + 4 * pc4);
+      EB_LOAD_TILES(t + 1);
     }
-    // ---- S1: h1 = relu(P . Wp + rc[c] + (c != n) rn[n]) for this wave's quadrant
-    // (self pairs read a zero row of rn through edge_nz: n_feats zeroed, network.py:371-374)
-    f32x16 h1;
-    if (nseg == 1) {                                                // one centre in this wave's 32 rows
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h1[r] = trcA + rnv[r];
-    } else if (simple) {                                            // centre rows were prefetched (A / B)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h1[r] = ((crow(r, half) < thiA) ? trcA : trcB) + rnv[r];
-    } else {                                                        // many short segments: gather per edge
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        h1[r] = a.rc[(unsigned)max(row_bcast(my_c, r, half), 0) * D_P + 32 * nt + col] + rnv[r];
-    }
-    __syncthreads();                                                // B0: P tile in LDS
-    {
-      const float* ap = sP + (32 * mt + col) * LD32 + 4 * half;
-      const float* bp = sWpT + (32 * nt + col) * LD32 + 4 * half;
-#pragma unroll
-      for (int k = 0; k < D_E; k += 8) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + k);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, h1, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, h1, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, h1, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, h1, 0, 0, 0);
-      }
-    }
-    // h1 stays in registers for the ReLU mask of g1 (every vector instruction costs MFMA time: the fp32
-    // MFMA runs on the same FP32 lanes -- tools/mfma_valu_overlap.hip -- so no bit masks are built)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      h1[r] = fmaxf(h1[r], 0.f);
-      sAp[crow(r, 0) * LD64] = h1[r];
-    }
-    __syncthreads();                                                // B1: h1 tile complete
+    __syncthreads();                                                // B1: P and h1 tiles in LDS
     // ---- S2: h2 = relu(h1 . W2 + b2); d h2 = SegmentMax tie split + ReLU mask
     f32x16 d2 = zero16();
     mma_abt<D_P>(d2, sA + 32 * mt * LD64, LD64, sW2T + 32 * nt * LD64, LD64, lane);
-    if (nseg == 1 && nrows >= 32) {
+    if (FULL && nseg == 1) {
       // relu(v) == max > 0  <=>  v == max: one compare per element against the maximum (NaN when the
       // maximum is 0: nothing passes the ReLU then)
       const float pmq = tpmA > 0.f ? tpmA : __builtin_nanf("");
@@ -556,6 +530,9 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
     __syncthreads();                                                // B2: d h2 tile complete
     // gathers of the NEXT tile (its indices arrived long ago): consumed at the top of the next iteration
     EB_PREFETCH_NEXT();
+    float h1[16];                                                   // this lane's h1 values: the ReLU mask of g1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[r] = sAp[crow(r, 0) * LD64];
     // ---- S3: d W2[mt-th row tile][nt-th column tile] += h1^T . d h2 over the 64 edges
     {
       const float* X = sA + 32 * mt + col;
@@ -581,25 +558,18 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       }
     }
     __syncthreads();                                                // B3: every read of h1 (sA) is done
-    // interior tiles (all 64 edges exist) take unconditional, constant-offset loads/stores
-    const bool full = tvalid == EB_T * D_E;
     float dold[8];                                                  // old d_pw values of the final RMW
-    if (full && a.accumulate_dpw) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dold[i] = dpw_tile[tid + 256 * i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + 256 * i;
-        dold[i] = (a.accumulate_dpw && idx < tvalid) ? dpw_tile[idx] : 0.f;
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      dold[i] = ACC ? ((FULL || idx < tvalid) ? dpw_tile[idx] : 0.f) : 0.f;
     }
     {
       // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order.
       // row crow(r, half) = crow(r, 0) + 4 half: per-lane base + compile-time row offsets
       float* g1t = a.d_g1 + (size_t)e0 * D_P;                       // uniform
       const unsigned g1o = (unsigned)(4 * half) * (D_P * 4u) + lane_b;
-      if (full) {
+      if (FULL) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = h1[r] > 0.f ? g1[r] : 0.f;
@@ -642,7 +612,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
       for (int r = 0; r < 16; ++r) part[(32 * mt + crow(r, half)) * D_E + col] = acc[r];
     }
     __syncthreads();                                                // B5: partials complete; sA, sP free
-    if (full) {
+    if (FULL) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = tid + 256 * i;
@@ -655,8 +625,11 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
         if (idx < tvalid) dpw_tile[idx] = dold[i] + (sB[idx] + sB[EB_T * D_E + idx]);
       }
     }
-    // (the next tile's S2 writes sB only behind its B0/B1, i.e. after every wave finished this loop)
-  }
+    // (the next tile's S2 writes sB only behind its B1, i.e. after every wave finished this tile)
+  };
+  const int t_full = max(t0, min(t1, a.n_edge / EB_T));             // tiles [t0, t_full) are complete
+  for (int t = t0; t < t_full; ++t) tile_body(t, std::true_type{});
+  if (t_full < t1) tile_body(t_full, std::false_type{});            // at most one partial tile per launch
   // ---- partial weight gradients of this workgroup
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
   store_acc(ar + a.o_w2 + (size_t)(32 * mt) * D_P + 32 * nt, D_P, aW2, lane);
@@ -936,7 +909,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
-  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->edge_nz) return GNET_ERR_INVALID;   // plan(training=1)
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_h1[1]) return GNET_ERR_INVALID;   // plan(training=1)
   hipStream_t s = (hipStream_t)stream;
   const ParamLayout L = make_layout(cfg);
   const int B = cfg->num_blocks;
@@ -960,7 +933,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
 
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
     attr_set = true;
   }
@@ -987,13 +961,13 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     if (E > 0) {
       EdgeBwdArgs e;
       e.n_edge = E; e.n_det = N; e.accumulate_dpw = b != B;
-      e.edge_c = buf->edge_c; e.edge_nz = buf->edge_nz; e.pw = buf->pw_feats;
-      e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b];
+      e.edge_c = buf->edge_c; e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b];
       e.pm = (const unsigned long long*)buf->blk_pm[b]; e.d_pc = buf->d_pc;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2; e.b2 = params + K.b2; e.w1 = params + K.w1; e.w2 = params + K.w2;
       e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
       e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
-      GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<<<g_edge, 256, kEdgeBwdSmem, s>>>(e));
+      if (e.accumulate_dpw) { GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<true><<<g_edge, 256, kEdgeBwdSmem, s>>>(e)); }
+      else { GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<false><<<g_edge, 256, kEdgeBwdSmem, s>>>(e)); }
     }
     GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sums<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, N,
                                                                               buf->d_rc, buf->d_rn));

@@ -157,6 +157,17 @@ __device__ __forceinline__ void stg_b(float* __restrict__ base, unsigned byte_of
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// vmcnt is ONE in-order counter for loads and stores, and the compiler's wait insertion merges the
+// pending-load state of a loop's preheader and latch conservatively: if the first tile's prefetch is
+// still "pending" when the loop is entered (followed by few memory operations), every iteration waits
+// as if equally few operations followed the prefetch -- i.e. for the previous tile's STORES to be
+// acknowledged by L2 (measured: 9 k of 27 k cycles per edge_bwd tile).  Draining the counter once before
+// the loop leaves only the latch state, and the in-loop wait becomes vmcnt(#operations issued after the
+// prefetch), which never covers a store.
+__device__ __forceinline__ void drain_vmem_before_loop() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
+}
+
 // Two row tiles (A0, A1) against the same Bt (B fetched once).
 template <int K>
 __device__ __forceinline__ void mma_abt2(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1,
@@ -284,35 +295,6 @@ __device__ __forceinline__ void pm_flush(unsigned long long* addr, float m, unsi
                                              __HIP_MEMORY_SCOPE_AGENT))
       return;
   }
-}
-
-// Asynchronous form: ONE returning 64-bit atomic max per flush; its result is inspected at the next
-// flush (a tile later), so the wave never waits for the round trip.  max() keeps the larger count of two
-// equal maxima; the exact tie semantics (counts add) are restored by pm_resolve: if the value that was
-// in memory had the same maximum, the smaller of the two counts is added while the maximum still
-// stands (if a larger maximum arrived meanwhile the tie is moot).  Any interleaving of several tied
-// partials sums to the total count (max(x,y) + min(x,y) = x + y at every step).
-struct PmPending {
-  unsigned long long* addr;
-  unsigned long long key, old;
-};
-__device__ __forceinline__ void pm_resolve(const PmPending& p) {
-  if (!p.addr) return;
-  const unsigned kb = (unsigned)(p.key >> 32);
-  if (kb == 0u || (unsigned)(p.old >> 32) != kb) return;          // no positive tie: nothing to repair
-  const unsigned long long delta = min((unsigned)p.old, (unsigned)p.key);
-  unsigned long long cur = __hip_atomic_load(p.addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  while ((unsigned)(cur >> 32) == kb) {
-    if (__hip_atomic_compare_exchange_strong(p.addr, &cur, cur + delta, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT))
-      return;
-  }
-}
-__device__ __forceinline__ void pm_flush_async(PmPending& p, unsigned long long* addr, float m, unsigned cnt) {
-  pm_resolve(p);
-  p.addr = addr;
-  p.key = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)cnt;
-  p.old = __hip_atomic_fetch_max(addr, p.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void atomic_add_f32(float* addr, float v) {

@@ -281,121 +281,10 @@ struct EdgeFwdArgs {
   unsigned long long* pm;        // [N,64], zeroed
   const int* row_ptr;            // [N+1]
   const int* edge_nz;            // [E+64] neighbour index, n_det (a zero row of rn) for self pairs and the tail
+  float* h1_out;                 // [E+64,64] relu(pw_fc1) kept for the backward pass (NULL at inference)
 };
 
-// One workgroup (4 waves) per 64-edge tile; wave (mt, nt) owns edge rows [32mt, 32mt+32) and feature
-// columns [32nt, 32nt+32).  48 MFMAs per wave and tile; 53 KB of LDS -> 3 independent workgroups per CU.
-// The centre row rc[c] is fetched once per distinct centre and the P tile once per workgroup (the L1
-// stalls on repeated requests to a line that is still in flight).
-constexpr int EF_T = 64;
-
-__global__ void __launch_bounds__(256, 3) edge_fwd(const EdgeFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float sWp[D_P * E_LD1];      // [64][36]  Wp^T
-  __shared__ __attribute__((aligned(16))) float sW2[D_P * E_LD2];      // [64][68]  W2^T
-  __shared__ __attribute__((aligned(16))) float sH1[EF_T * E_LD2];     // [64][68]
-  __shared__ __attribute__((aligned(16))) float sP[EF_T * E_LD1];      // [64][36]  P tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < D_P * D_E; i += 256) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
-  for (int i = tid; i < D_P * D_P; i += 256) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
-  const int col = lane & 31, half = lane >> 5;
-  const int mt = wave >> 1, nt = wave & 1;
-  const float bias = a.b2[32 * nt + col];
-  const int ntiles = (a.n_edge + EF_T - 1) / EF_T;
-  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-  const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
-  int nx_c = -1, nx_n = -1;
-  if (t0 < t1) {
-    const int e = t0 * EF_T + 32 * mt + col;
-    if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
-  }
-  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;          // P tile prefetch (one tile ahead)
-  const int prow0 = tid >> 3, pc4 = tid & 7;
-  if (t0 < t1) {
-    const int last = a.n_edge - 1;
-    pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EF_T + prow0, last) * D_E + 4 * pc4);
-    pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min(t0 * EF_T + 32 + prow0, last) * D_E + 4 * pc4);
-  }
-  int cur = -1; float mx = 0.f; unsigned cnt = 0;      // running (max, tie count) of this lane's column
-  unsigned long long* pm_col = a.pm + 32 * nt + col;
-  PmPending pend; pend.addr = nullptr; pend.key = 0; pend.old = 0;
-  // neighbour rows rn[n] of the next tile and rc of its first centre: gathered one tile ahead
-  float rnv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
-  int c_first = row_bcast(nx_c, 0, half);
-  float rc_first = a.rc[(unsigned)max(c_first, 0) * D_P + 32 * nt + col];
-  __syncthreads();
-  for (int t = t0; t < t1; ++t) {
-    const int e0 = t * EF_T + 32 * mt;
-    const int my_c = nx_c, my_n = nx_n;
-    const int nrows = min(32, a.n_edge - e0);
-    *reinterpret_cast<float4*>(sP + prow0 * E_LD1 + 4 * pc4) = pf0;
-    *reinterpret_cast<float4*>(sP + (32 + prow0) * E_LD1 + 4 * pc4) = pf1;
-    nx_c = -1; nx_n = -1;
-    if (t + 1 < t1) {
-      const int e = e0 + EF_T + col;
-      if (e < a.n_edge) { nx_c = a.edge_c[e]; nx_n = a.edge_n[e]; }
-      const int last = a.n_edge - 1;
-      pf0 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EF_T + prow0, last) * D_E + 4 * pc4);
-      pf1 = *reinterpret_cast<const float4*>(a.pw + (size_t)min((t + 1) * EF_T + 32 + prow0, last) * D_E + 4 * pc4);
-    }
-    // h1 = relu(P . Wp + rc[c] + (c != n) rn[n]): accumulator starts from the gathered per-node halves
-    f32x16 h1;
-    {
-      int cprev = c_first;
-      float rcv = rc_first;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = row_bcast(my_c, r, half), n = row_bcast(my_n, r, half);
-        if (c != cprev) { rcv = a.rc[(unsigned)max(c, 0) * D_P + 32 * nt + col]; cprev = c; }   // once per centre
-        h1[r] = (c != n) ? rcv + rnv[r] : rcv;                       // :371-374
-      }
-    }
-    __syncthreads();                                                 // P tile in LDS
-    {
-      const float* ap = sP + (32 * mt + col) * E_LD1 + 4 * half;
-      const float* bp = sWp + (32 * nt + col) * E_LD1 + 4 * half;
-#pragma unroll
-      for (int k = 0; k < D_E; k += 8) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + k);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, h1, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, h1, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, h1, 0, 0, 0);
-        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, h1, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sH1[(32 * mt + crow(r, half)) * E_LD2 + 32 * nt + col] = fmaxf(h1[r], 0.f);
-    __syncthreads();
-    // gathers of the NEXT tile, hidden under this tile's layer 2
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rnv[r] = a.rn[(unsigned)max(row_bcast(nx_n, r, half), 0) * D_P + 32 * nt + col];
-    c_first = row_bcast(nx_c, 0, half);
-    rc_first = a.rc[(unsigned)max(c_first, 0) * D_P + 32 * nt + col];
-    f32x16 h2 = zero16();
-    mma_abt<D_P>(h2, sH1 + 32 * mt * E_LD2, E_LD2, sW2 + 32 * nt * E_LD2, E_LD2, lane);
-    // streaming (max, tie count) per (centre, column); rows ascend, centres are sorted
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      const int c = row_bcast(my_c, r, half);
-      if (row >= nrows) continue;
-      const float v = fmaxf(h2[r] + bias, 0.f);
-      if (c != cur) {
-        if (cur >= 0) pm_flush_async(pend, pm_col + (size_t)cur * D_P, mx, cnt);
-        cur = c; mx = v; cnt = 1;
-      } else {
-        if (v > mx) { mx = v; cnt = 1; } else if (v == mx) { ++cnt; }
-      }
-    }
-    __syncthreads();      // h1 tile consumed before the next tile overwrites it
-  }
-  if (cur >= 0) pm_flush_async(pend, pm_col + (size_t)cur * D_P, mx, cnt);
-  pm_resolve(pend);
-}
-
-// Variant W: every wave owns whole 32-edge x 64-column tiles (96 MFMAs per tile), no workgroup barriers in
+// edge_fwd_w: every wave owns whole 32-edge x 64-column tiles (96 MFMAs per tile), no workgroup barriers in
 // the tile loop (h1 goes through a wave-private LDS tile), all gathers prefetched one tile ahead.
 // Segment handling is WAVE-UNIFORM: the rows of a tile are sorted by centre, a ballot yields the segment
 // heads, and per segment the wave reduces (max, tie count) over its rows, folds the two half-waves with
@@ -474,6 +363,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
   int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
   // does the first centre of this range start in the previous wave's range?
   bool head_shared = e_begin > 0 && a.edge_c[e_begin - 1] == cA;
+  drain_vmem_before_loop();
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * 32;
     const int my_c = nx_c;
@@ -547,6 +437,16 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
     for (int r = 0; r < 16; ++r) {
       const unsigned on = (unsigned)EF_NZ(r) * D_P + col;
       rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
+    }
+    if (a.h1_out) {
+      // 288 GB of HBM: the backward pass reads h1 back instead of recomputing pw_fc1 (16 of its 144 MFMAs
+      // per tile plus the rc/rn gathers).  Whole 256-byte rows, 16 B per lane; behind this tile's loads.
+      float* dst = a.h1_out + (size_t)e0 * D_P;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = 4 * q + (lane >> 4);
+        *reinterpret_cast<float4*>(dst + row * D_P + 4 * (lane & 15)) = *reinterpret_cast<const float4*>(sh + row * E_LD2 + 4 * (lane & 15));
+      }
     }
     {
       cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;
@@ -842,7 +742,6 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   }
 
   const int ntile_n = (N + 31) / 32;
-  const int egrid = max(1, min(768, (E + EF_T - 1) / EF_T));
   for (int b = 0; b <= B; ++b) {
     // node stage between edge kernels: finish block b (b >= 1), start block b+1 (b < B)
     NodeFwdArgs n;
@@ -872,20 +771,16 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
         e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
         e.edge_nz = buf->edge_nz;
-        // default: variant W (wave-owned tiles, 2 workgroups per CU); GNET_EDGE_FWD_W=0 selects the
-        // cooperative 64-edge-tile kernel (kept for A/B measurements)
-        static const int variant_w = getenv("GNET_EDGE_FWD_W") ? atoi(getenv("GNET_EDGE_FWD_W")) : 2;
-        if (variant_w) {
-          const int wg = max(1, min(variant_w * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
-          static bool attr_w = false;
-          if (!attr_w) {
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
-            attr_w = true;
-          }
-          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e));
-        } else {
-          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd<<<egrid, 256, 0, s>>>(e));
+        e.h1_out = training ? buf->blk_h1[b + 1] : nullptr;
+        // workgroups per CU (default 2): wave-owned tiles, contiguous tile ranges per wave
+        static const int wg_per_cu = getenv("GNET_EDGE_FWD_W") ? max(1, atoi(getenv("GNET_EDGE_FWD_W"))) : 2;
+        const int wg = max(1, min(wg_per_cu * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+        static bool attr_w = false;
+        if (!attr_w) {
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+          attr_w = true;
         }
+        GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e));
       }
     }
   }

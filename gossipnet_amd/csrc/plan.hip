@@ -55,6 +55,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.blk_rn[k] = c.take<float>(Np * D_P);
       b.blk_pm[k] = c.take<uint64_t>(Np * D_P);
       b.blk_q[k] = c.take<float>(Np * D_P);
+      b.blk_h1[k] = c.take<float>(Ep * D_P);
     }
     b.head1 = c.take<float>(Np * D_HEAD);
     b.head2 = c.take<float>(Np * D_HEAD);

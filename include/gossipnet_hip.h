@@ -99,6 +99,7 @@ typedef struct gnet_buffers {
   float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[64:96]             */
   uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count */
   float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
+  float* blk_h1[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] relu(pw_fc1) per edge, kept for the backward pass (training) */
   float* head1;       /* [n_det,128] predict/fc1 */
   float* head2;       /* [n_det,128] predict/fc2 */
   float* prediction;  /* [n_det] logits (Gnet.prediction) */
