@@ -696,30 +696,53 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   f32x16 aW3 = zero16();
   float gb2 = 0.f, gb3 = 0.f;
   const int ntiles = (a.n_edge + 31) / 32;
+  // Everything a tile reads from HBM is requested one tile ahead and BEFORE the tile's 16 d_h1 stores: the
+  // h1/h2 tiles by DMA into the other LDS buffer, the d_pw / pw values of the d3 tile into registers.  The
+  // wait at the top of a tile is then vmcnt(16): "everything but the 16 youngest operations", i.e. it never
+  // waits for the previous tile's stores to be acknowledged (vmcnt is one in-order counter for loads and
+  // stores).  W3 (the same for every tile) stays in registers for the same reason.
+  f32x4 w3f[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3 + (size_t)(32 * wave + col) * D_E + 4 * half + 8 * k);
+  float pq0 = 0.f, pq1 = 0.f, dq0 = 0.f, dq1 = 0.f;     // d3 tile sources: elements tid and tid + 512 of [32][32]
+#define PB_PREFETCH_D3(tile_)                                                                           \
+  do {                                                                                                  \
+    const long long el_ = (long long)a.n_edge * D_E - 1, o_ = (long long)(tile_) * 32 * D_E + tid;      \
+    pq0 = a.pw[min(o_, el_)]; dq0 = a.d_pw[min(o_, el_)];                                               \
+    pq1 = a.pw[min(o_ + 512, el_)]; dq1 = a.d_pw[min(o_ + 512, el_)];                                   \
+  } while (0)
   if ((int)blockIdx.x < ntiles) {
     dma_tile32(smem, a.h1, (long long)blockIdx.x * 32, a.n_edge, wave, lane);
     dma_tile32(smem + 32 * LD256, a.h2, (long long)blockIdx.x * 32, a.n_edge, wave, lane);
+    PB_PREFETCH_D3((int)blockIdx.x);
   }
+  drain_vmem_before_loop();
   int it = 0;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
     const long long e0 = (long long)t * 32;
     float* sH1 = smem + (it & 1) * (2 * 32 * LD256);
     float* sH2 = sH1 + 32 * LD256;        // fc2 output, then d(fc2 pre-activation)
     float* nH1 = smem + ((it & 1) ^ 1) * (2 * 32 * LD256);
-    for (int i = tid; i < 32 * D_E; i += 512) {
-      const int row = i >> 5, j = i & 31;
-      float v = 0.f;
-      if (e0 + row < a.n_edge) {
-        const size_t o = (size_t)(e0 + row) * D_E + j;
-        v = a.pw[o] > 0.f ? a.d_pw[o] : 0.f;              // ReLU of fc3
-      }
-      sD3[row * LD32 + j] = v;
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this tile's DMA and d3 sources (issued one tile ago) have landed
+    {
+      const int row0 = tid >> 5, j = tid & 31;            // rows past E: zero gradient
+      sD3[row0 * LD32 + j] = (e0 + row0 < a.n_edge && pq0 > 0.f) ? dq0 : 0.f;              // ReLU of fc3
+      sD3[(row0 + 16) * LD32 + j] = (e0 + row0 + 16 < a.n_edge && pq1 > 0.f) ? dq1 : 0.f;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's DMA (issued one tile ago) has landed
     __syncthreads();
     // d(fc2 pre) tile w = (d3 . W3^T) * (h2 > 0)
     f32x16 d2 = zero16();
-    mma_abt<D_E>(d2, sD3, LD32, a.w3 + (size_t)(32 * wave) * D_E, D_E, lane);
+    {
+      const float* ap = sD3 + col * LD32 + 4 * half;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w3f[k].x, d2, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w3f[k].y, d2, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w3f[k].z, d2, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w3f[k].w, d2, 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) d2[r] = sH2[crow(r, half) * LD256 + 32 * wave + col] > 0.f ? d2[r] : 0.f;
     // d W3 += h2^T . d3 (rows [32w, 32w+32) of W3)
@@ -741,6 +764,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     if (t + (int)gridDim.x < ntiles) {
       dma_tile32(nH1, a.h1, e0 + (long long)gridDim.x * 32, a.n_edge, wave, lane);
       dma_tile32(nH1 + 32 * LD256, a.h2, e0 + (long long)gridDim.x * 32, a.n_edge, wave, lane);
+      PB_PREFETCH_D3(t + (int)gridDim.x);
     }
     if (tid < D_H) gb2 += col_sum32(sH2, LD256, tid);
     // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)

@@ -438,16 +438,6 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
       const unsigned on = (unsigned)EF_NZ(r) * D_P + col;
       rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
     }
-    if (a.h1_out) {
-      // 288 GB of HBM: the backward pass reads h1 back instead of recomputing pw_fc1 (16 of its 144 MFMAs
-      // per tile plus the rc/rn gathers).  Whole 256-byte rows, 16 B per lane; behind this tile's loads.
-      float* dst = a.h1_out + (size_t)e0 * D_P;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int row = 4 * q + (lane >> 4);
-        *reinterpret_cast<float4*>(dst + row * D_P + 4 * (lane & 15)) = *reinterpret_cast<const float4*>(sh + row * E_LD2 + 4 * (lane & 15));
-      }
-    }
     {
       cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;
       const int prev = __shfl_up(nx_c, 1);
@@ -474,6 +464,16 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h2b, 0, 0, 0);
         h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h2a, 0, 0, 0);
         h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
+      }
+    }
+    if (a.h1_out) {
+      // 288 GB of HBM: the backward pass reads h1 back instead of recomputing pw_fc1 (16 of its 144 MFMAs
+      // per tile plus the rc/rn gathers).  Whole 256-byte rows, 16 B per lane; behind this tile's loads.
+      float* dst = a.h1_out + (size_t)e0 * D_P;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = 4 * q + (lane >> 4);
+        *reinterpret_cast<float4*>(dst + row * D_P + 4 * (lane & 15)) = *reinterpret_cast<const float4*>(sh + row * E_LD2 + 4 * (lane & 15));
       }
     }
     // pre-activations; relu is monotone, so max(relu(v)) = relu(max(v)): rectify once per segment.  The
