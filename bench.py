@@ -146,9 +146,22 @@ def main():
     for _ in range(args.warmup):
         step()
     E = sum(int(n_.num_edges) for n_ in nets)
+    # Per-kernel HIP events cost ~4% of the step when every launch is bracketed (~230 launches), so the timed
+    # region brackets only the DOMINANT kernel class (picked from one fully instrumented, untimed step);
+    # the complete per-class table is measured in a second, untimed pass after the timed region.
+    dominant = None
     if not args.no_kernel_timing:
         for n_ in nets:
-            n_.enable_kernel_timing(classes=None, capacity=(args.steps + 1) * 128)
+            n_.enable_kernel_timing(classes=None, capacity=512)
+        step()
+        torch.cuda.synchronize()
+        probe = {}
+        for n_ in nets:
+            for k_, (ms_, c_) in n_.read_kernel_timing().items():
+                probe[k_] = probe.get(k_, 0.0) + ms_
+        dominant = max(probe.items(), key=lambda kv: kv[1])[0]
+        for n_ in nets:
+            n_.enable_kernel_timing(classes=[dominant], capacity=(args.steps + 1) * 64)
 
     torch.cuda.synchronize()
     if dist is not None:
@@ -177,11 +190,22 @@ def main():
 
     roofline = None
     timing = {}
+    table = {}
     if not args.no_kernel_timing:
         for n_ in nets:
             for k_, (ms_, c_) in n_.read_kernel_timing().items():
                 pm_, pc_ = timing.get(k_, (0.0, 0))
                 timing[k_] = (pm_ + ms_, pc_ + c_)
+        # second pass (untimed): every class, for the kernel_ms_per_step table
+        table_steps = min(args.steps, 5)
+        for n_ in nets:
+            n_.enable_kernel_timing(classes=None, capacity=(table_steps + 1) * 256)
+        for _ in range(table_steps):
+            step()
+        torch.cuda.synchronize()
+        for n_ in nets:
+            for k_, (ms_, c_) in n_.read_kernel_timing().items():
+                table[k_] = table.get(k_, 0.0) + ms_ / table_steps
         N_local = args.dets * args.images
         dom = max(timing.items(), key=lambda kv: kv[1][0]) if timing else None
         if dom is not None:
@@ -215,7 +239,7 @@ def main():
             "whole_step": {"nominal_tflops": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * world * args.steps / elapsed / 1e12, 3),
                            "frac_fp32_mfma_peak": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * args.steps / elapsed / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roofline,
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(timing.items(), key=lambda kv: -kv[1][0])},
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(table.items(), key=lambda kv: -kv[1])},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(images, args.classes, args.blocks, args.cpu_seconds)
