@@ -261,13 +261,26 @@ __global__ void __launch_bounds__(256) gather_sums(const float* __restrict__ g1,
   const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
   const int eb = row_ptr[node], ee = row_ptr[node + 1];
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
-  for (int e = eb + sub; e < ee; e += 4) {
-    const float4 c = *reinterpret_cast<const float4*>(g1 + (size_t)e * D_P + 4 * f4);
-    sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
-    const int t = edge_n[e] != node ? edge_t[e] : -1;     // self pair: n_feats zeroed (network.py:371-374)
-    if (t >= 0) {
-      const float4 v = *reinterpret_cast<const float4*>(g1 + (size_t)t * D_P + 4 * f4);
-      sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
+  // 64 edges per pass: one coalesced load of the reversed-pair positions, then 16 independent row pairs per
+  // quarter-wave (no index -> row dependent chain per edge; the row loads of a pass are all in flight together)
+  for (int base = eb; base < ee; base += 64) {
+    const int el = base + lane;
+    int tt = -1;
+    if (el < ee) tt = edge_n[el] != node ? edge_t[el] : -1;   // self pair: n_feats zeroed (network.py:371-374)
+    const int cnt = min(64, ee - base);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int j = 4 * i + sub;                              // edge base + j, ascending per quarter-wave
+      if (4 * i >= cnt) break;                                // wave-uniform
+      const int t = __shfl(tt, j);
+      if (j < cnt) {
+        const float4 c = *reinterpret_cast<const float4*>(g1 + (size_t)(base + j) * D_P + 4 * f4);
+        sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+        if (t >= 0) {
+          const float4 v = *reinterpret_cast<const float4*>(g1 + (size_t)t * D_P + 4 * f4);
+          sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
+        }
+      }
     }
   }
 #pragma unroll
