@@ -282,6 +282,7 @@ struct EdgeFwdArgs {
   const int* row_ptr;            // [N+1]
   const int* edge_nz;            // [E+64] neighbour index, n_det (a zero row of rn) for self pairs and the tail
   float* h1_out;                 // [E+64,64] relu(pw_fc1) kept for the backward pass (NULL at inference)
+  unsigned long long* parg;      // [N,64] (max bits << 32) | first edge attaining it (training), zeroed
 };
 
 // edge_fwd_w: every wave owns whole 32-edge x 64-column tiles (96 MFMAs per tile), no workgroup barriers in
@@ -302,6 +303,7 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
 constexpr int EFW_WAVES = 4;      // waves per workgroup; 2 workgroups per CU.  (6 waves = 3 per SIMD measured 28% SLOWER)
 constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 32 * E_LD2) * sizeof(float);
 
+template <bool TRAIN>     // TRAIN: keep h1 and the arg-max edge of every (centre, column) for the backward pass
 __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sWp = smem;                           // [64][36]  Wp^T
@@ -361,6 +363,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
   float rcA0 = a.rc[(unsigned)max(cA, 0) * D_P + col], rcA1 = a.rc[(unsigned)max(cA, 0) * D_P + 32 + col];
   float rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col], rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
   int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
+  int g0 = 0, g1 = 0;                                                  // edge that first attains m0 / m1 (TRAIN)
   // does the first centre of this range start in the previous wave's range?
   bool head_shared = e_begin > 0 && a.edge_c[e_begin - 1] == cA;
   drain_vmem_before_loop();
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
       }
     }
-    if (a.h1_out) {
+    if (TRAIN) {
       // 288 GB of HBM: the backward pass reads h1 back instead of recomputing pw_fc1 (16 of its 144 MFMAs
       // per tile plus the rc/rn gathers).  Whole 256-byte rows, 16 B per lane; behind this tile's loads.
       float* dst = a.h1_out + (size_t)e0 * D_P;
@@ -490,6 +493,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
       const int hi = hleft ? __builtin_ctz(hleft) : nrows;
       const int cseg = __builtin_amdgcn_readlane(my_c, lo);
       float s0, s1; unsigned q0 = 0, q1 = 0;
+      int a0 = 0x7fffffff, a1 = 0x7fffffff;
       if (whole) {
         s0 = h2a[0]; s1 = h2b[0];
 #pragma unroll
@@ -498,6 +502,13 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         s1 = fmaxf(s1, __shfl_xor(s1, 32));
 #pragma unroll
         for (int r = 0; r < 16; ++r) { q0 += h2a[r] == s0 ? 1u : 0u; q1 += h2b[r] == s1 ? 1u : 0u; }
+        if (TRAIN) {
+#pragma unroll
+          for (int r = 15; r >= 0; --r) {              // rows ascend with r: the last hit is the first row
+            a0 = h2a[r] == s0 ? e0 + crow(r, half) : a0;
+            a1 = h2b[r] == s1 ? e0 + crow(r, half) : a1;
+          }
+        }
       } else {
         // rows [lo, hi) of the tile; this lane's row crow(r, half) is bit crow(r, 0) of `mine`
         const unsigned rowmask = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
@@ -518,11 +529,24 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
           q0 += (in && h2a[r] == s0) ? 1u : 0u;
           q1 += (in && h2b[r] == s1) ? 1u : 0u;
         }
+        if (TRAIN) {
+#pragma unroll
+          for (int r = 15; r >= 0; --r) {
+            const bool in = (mine >> crow(r, 0)) & 1u;
+            a0 = (in && h2a[r] == s0) ? e0 + crow(r, half) : a0;
+            a1 = (in && h2b[r] == s1) ? e0 + crow(r, half) : a1;
+          }
+        }
+      }
+      if (TRAIN) {
+        a0 = min(a0, __shfl_xor(a0, 32));
+        a1 = min(a1, __shfl_xor(a1, 32));
       }
       s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
       q0 += __shfl_xor(q0, 32);
       q1 += __shfl_xor(q1, 32);
       if (cseg == cur) {
+        if (TRAIN) { g0 = s0 > m0 ? a0 : g0; g1 = s1 > m1 ? a1 : g1; }   // equal maxima keep the earlier edge
         segmax_merge(m0, k0, s0, q0);
         segmax_merge(m1, k1, s1, q1);
       } else {
@@ -533,9 +557,15 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
           const float mm = half ? m1 : m0; const unsigned kk = half ? k1 : k0;
           if (!head_shared) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
           else pm_flush(dst, mm, kk);
+          if (TRAIN) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(mm) << 32) | (unsigned)(half ? g1 : g0);
+            unsigned long long* ad = a.parg + (size_t)cur * D_P + 32 * half + col;
+            if (!head_shared) *ad = key;
+            else __hip_atomic_fetch_max(ad, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           head_shared = false;
         }
-        cur = cseg; m0 = s0; k0 = q0; m1 = s1; k1 = q1;
+        cur = cseg; m0 = s0; k0 = q0; m1 = s1; k1 = q1; g0 = a0; g1 = a1;
       }
     }
   }
@@ -546,6 +576,14 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
     const float mm = half ? m1 : m0; const unsigned kk = half ? k1 : k0;
     if (!head_shared && !tail_shared) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
     else pm_flush(dst, mm, kk);
+    if (TRAIN) {
+      // shared centres: the larger maximum wins with its edge; equal positive maxima are ties (the dense
+      // backward handles those blocks, see tie_flags), so which edge survives does not matter
+      const unsigned long long key = ((unsigned long long)__float_as_uint(mm) << 32) | (unsigned)(half ? g1 : g0);
+      unsigned long long* ad = a.parg + (size_t)cur * D_P + 32 * half + col;
+      if (!head_shared && !tail_shared) *ad = key;
+      else __hip_atomic_fetch_max(ad, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #undef EF_LOAD_NZ
 #undef EF_NZ
@@ -562,6 +600,7 @@ struct NodeFwdArgs {
   int do_head;                   // after the last block: predict/fc1, fc2, logits
   int training;
   const unsigned long long* pm;  // [N,64] block b
+  int* tie_flag;                 // set when a positive maximum of block b is attained by 2+ edges (training)
   const float* x_prev;           // [N,128] block b input (NULL = zeros)
   const float* w3t; const float* b3;   // fc1 transposed [64][64]
   const float* w4t; const float* b4;   // fc2 transposed [128][64]
@@ -585,7 +624,9 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     for (int i = tid; i < 32 * D_P; i += 256) {
       const int row = i >> 6, ff = i & 63;
       const int node = min(row0 + row, a.n_det - 1);
-      sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(a.pm[(size_t)node * D_P + ff] >> 32));
+      const unsigned long long pv = a.pm[(size_t)node * D_P + ff];
+      sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(pv >> 32));
+      if (a.tie_flag && (unsigned)pv > 1u && (pv >> 32) != 0ull) *a.tie_flag = 1;    // benign race: same value
     }
     __syncthreads();
     f32x16 acc = zero16();
@@ -717,6 +758,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
 
   void* prof = buf->profiler;
   GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B));
+  if (training) HIP_CHECK_RET(hipMemsetAsync(buf->tie_flags, 0, (GNET_MAX_BLOCKS + 1) * sizeof(int32_t), s));
 
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
@@ -747,6 +789,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     NodeFwdArgs n;
     n.n_det = N; n.do_post = b >= 1; n.do_pre = b < B; n.do_head = b == B; n.training = training;
     n.pm = b >= 1 ? (const unsigned long long*)buf->blk_pm[b] : nullptr;
+    n.tie_flag = (training && b >= 1) ? buf->tie_flags + b : nullptr;
     n.x_prev = b >= 2 ? buf->block_feats[b - 1] : nullptr;
     if (b >= 1) {
       n.w3t = pt + L.blk[b].w3; n.b3 = params + L.blk[b].b3;
@@ -763,7 +806,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
     GNET_LAUNCH(prof, GNET_K_NODE_FWD, s, node_fwd<<<ntile_n, 256, 0, s>>>(n));
     if (b < B) {
-      HIP_CHECK_RET(hipMemsetAsync(buf->blk_pm[b + 1], 0, (size_t)N * D_P * sizeof(unsigned long long), s));
+      HIP_CHECK_RET(hipMemsetAsync(buf->blk_pm[b + 1], 0, (size_t)(training ? 2 * ((size_t)N + 32) : (size_t)N) * D_P * sizeof(unsigned long long), s));
       if (E > 0) {
         EdgeFwdArgs e;
         e.n_edge = E; e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
@@ -772,15 +815,18 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
         e.edge_nz = buf->edge_nz;
         e.h1_out = training ? buf->blk_h1[b + 1] : nullptr;
+        e.parg = training ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
         // workgroups per CU (default 2): wave-owned tiles, contiguous tile ranges per wave
         static const int wg_per_cu = getenv("GNET_EDGE_FWD_W") ? max(1, atoi(getenv("GNET_EDGE_FWD_W"))) : 2;
         const int wg = max(1, min(wg_per_cu * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
         static bool attr_w = false;
         if (!attr_w) {
-          HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
           attr_w = true;
         }
-        GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e));
+        if (training) { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<true><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
+        else { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<false><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
       }
     }
   }

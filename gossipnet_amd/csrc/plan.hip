@@ -53,7 +53,8 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.blk_r[k] = c.take<float>(Np * D_R);
       b.blk_rc[k] = c.take<float>(Np * D_P);
       b.blk_rn[k] = c.take<float>(Np * D_P);
-      b.blk_pm[k] = c.take<uint64_t>(Np * D_P);
+      b.blk_pm[k] = c.take<uint64_t>(2 * Np * D_P);      // pm, then parg (one memset clears both)
+      b.blk_parg[k] = b.blk_pm[k] + Np * D_P;
       b.blk_q[k] = c.take<float>(Np * D_P);
       b.blk_h1[k] = c.take<float>(Ep * D_P);
     }
@@ -74,6 +75,8 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_pw = c.take<float>(Ep * D_E);
     b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
+    b.emask = c.take<uint64_t>(Ep);
+    b.tie_flags = c.take<int32_t>(GNET_MAX_BLOCKS + 1);
     b.w1_s = c.take<float>(Np * D_H);
     b.w1_t = c.take<float>(Np * D_H);
     b.arena_floats = arena_floats(cfg, sh);

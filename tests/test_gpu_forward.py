@@ -51,3 +51,30 @@ def test_forward_multi_image_batch_equals_per_image():
         k = im["dets"].shape[0]
         assert rel_err(pred[off:off + k], ref["prediction"].detach().numpy()) < TOL
         off += k
+
+
+def test_argmax_edges_recorded_for_backward():
+    """Training forward keeps, per (detection, column), the first edge that attains the segment maximum
+    (the sparse backward routes the SegmentMax gradient through it; network.py:383-386)."""
+    net, orc = make_pair(80, 3)
+    batch = make_image(300, 80, seed=5)
+    net.run(batch)
+    torch.cuda.synchronize()
+    n, e = 300, net.num_edges
+    rp = net._view(net._buf.row_ptr, n + 1, torch.int32).cpu().numpy()
+    for blk in (1, 3):
+        pm = net._view(net._buf.blk_pm[blk], n * 64, torch.int64).view(n, 64).cpu().numpy()
+        pa = net._view(net._buf.blk_parg[blk], n * 64, torch.int64).view(n, 64).cpu().numpy()
+        h1 = net._view(net._buf.blk_h1[blk], e * 64, torch.float32).view(e, 64).cpu().numpy().astype(np.float64)
+        w2 = net.variables["gnet/block%d/pw_fc2/weights" % blk].cpu().numpy().astype(np.float64)
+        b2 = net.variables["gnet/block%d/pw_fc2/biases" % blk].cpu().numpy().astype(np.float64)
+        h2 = np.maximum(h1 @ w2 + b2, 0.0)
+        mx = (pm >> 32).astype(np.uint32).view(np.float32) if False else np.frombuffer((pm >> 32).astype(np.uint32).tobytes(), np.float32).reshape(n, 64)
+        assert np.array_equal(pm >> 32, pa >> 32)                     # same maxima in both records
+        arg = (pa & 0xffffffff).astype(np.int64)
+        pos = mx > 0
+        c_idx = np.repeat(np.arange(n)[:, None], 64, 1)
+        assert np.all(arg[pos] >= rp[c_idx[pos]]) and np.all(arg[pos] < rp[c_idx[pos] + 1])   # an edge of that detection
+        j_idx = np.repeat(np.arange(64)[None, :], n, 0)
+        assert np.abs(h2[arg[pos], j_idx[pos]] - mx[pos]).max() < 1e-5
+        assert int(net._view(net._buf.tie_flags, 17, torch.int32)[blk]) == 0
