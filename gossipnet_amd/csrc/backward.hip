@@ -672,6 +672,383 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
 constexpr size_t kEdgeBwdSmem = (size_t)(D_P * LD32 + D_P * LD64 + 2 * EB_T * LD64 + EB_T * LD32) * sizeof(float);
 
 // ------------------------------------------------------------------------------------------
+// Sparse SegmentMax backward.  The gradient of a segment max reaches, per (detection, column), only the edge
+// that attained the maximum: d h2 has at most 64 non-zeros per DETECTION, spread over W <= 64 "winner" edges
+// (measured: 23-28 % of the edges at E/N = 86, 42-51 % at E/N = 36).  Rows of d h2 that are zero give zero rows
+// of g1 and d P and contribute nothing to d W2 / d Wp, so the whole edge stage of the backward pass runs on
+// the winner rows only -- same sums, fewer zero terms.  The forward pass recorded the first winner of every
+// (detection, column) (blk_parg); a positive maximum attained by several edges (about one per block: fp32
+// coincidences) is resolved in winners_mark by recomputing that detection's pw_fc2 bit-exactly.  The dense
+// kernels above remain selectable (GNET_DENSE_BWD=1) as the reference implementation of the same stage.
+//
+//   winners_mark      emask[e] = columns for which edge e is the arg-max (0: no gradient through e)
+//   edge_bwd_sparse   compacts its edge range's winners into 64-row tiles: d h2 from (emask, d_pc), h1 / P
+//                     rows gathered, dW2 / g1 / dWp / dP as in the dense kernel (96 MFMAs per wave and tile),
+//                     d_pw[e] += dP and d_g1[e] = g1 on winner rows only
+//   gather_sparse     d_rc / d_rn from the winner rows of d_g1
+struct WinArgs {
+  int n_det;
+  const unsigned long long* pm;     // [N,64] (max bits << 32) | tie count
+  const unsigned long long* parg;   // [N,64] (max bits << 32) | first edge attaining it
+  unsigned long long* emask;        // [E], zeroed
+  // tie resolution only (a positive maximum attained by 2+ edges; about one (detection, column) per block):
+  const int* row_ptr; const float* h1; const float* w2t; const float* b2;
+};
+
+__global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 31, half = lane >> 5;
+  const int nwaves = gridDim.x * 4;
+  for (int node = blockIdx.x * 4 + (threadIdx.x >> 6); node < a.n_det; node += nwaves) {
+    const unsigned long long pv = a.parg[(size_t)node * D_P + lane];
+    const unsigned long long pc = a.pm[(size_t)node * D_P + lane];
+    const bool valid = (pv >> 32) != 0ull;                  // maximum > 0: the ReLU passes the gradient
+    const int arg = (int)(unsigned)pv;
+    const unsigned long long ties = __ballot(valid && (unsigned)pc > 1u);
+    unsigned long long todo = __ballot(valid);
+    while (todo) {                                          // one iteration per distinct winner edge
+      const int k = __builtin_ctzll(todo);
+      const int ak = __builtin_amdgcn_readlane(arg, k);
+      const unsigned long long m = __ballot(valid && arg == ak);
+      if (lane == k) {
+        if (ties) atomicOr(a.emask + ak, m);                // (the tie pass below ORs into the same words)
+        else a.emask[ak] = m;                               // every edge belongs to exactly one detection
+      }
+      todo &= ~m;
+    }
+    if (ties) {
+      // Rare: some column's maximum is attained by several edges, and the forward pass kept only the first.
+      // Recompute pw_fc2 for this detection's edges with the forward kernel's exact MFMA sequence (operand
+      // fragments and k order of edge_fwd_w, so the bits match) and mark every edge that attains a tied
+      // maximum; d_pc already carries the 1 / count split (network.py:383-386, TF SegmentMax gradient).
+      const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
+      const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
+      const float mx = __uint_as_float((unsigned)(pv >> 32));
+      for (int e0 = eb; e0 < ee; e0 += 32) {
+        const int nrows = min(32, ee - e0);
+        const float* ap = a.h1 + (size_t)min(e0 + col, ee - 1) * D_P + 4 * half;
+        const float* b0 = a.w2t + (size_t)col * D_P + 4 * half;
+        const float* b1 = b0 + 32 * D_P;
+        f32x16 h2a = zero16(), h2b = zero16();
+#pragma unroll 4
+        for (int k = 0; k < D_P; k += 8) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
+          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h2b, 0, 0, 0);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h2b, 0, 0, 0);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h2b, 0, 0, 0);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
+        }
+        unsigned long long tleft = ties;
+        while (tleft) {
+          const int j = __builtin_ctzll(tleft);
+          tleft &= tleft - 1;
+          const float mj = __shfl(mx, j);                   // lane j holds column j's maximum
+          if (col == (j & 31)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = j < 32 ? h2a[r] + bias0 : h2b[r] + bias1;
+              if (crow(r, half) < nrows && v == mj) atomicOr(a.emask + e0 + crow(r, half), 1ull << j);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+struct EdgeBwdSparseArgs {
+  int n_edge; int n_det;
+  const int* edge_c;
+  const unsigned long long* emask;
+  const float* pw; const float* h1; const float* d_pc;
+  const float* w1t; const float* w2t;
+  float* d_pw; float* d_g1;
+  float* arena; long long stride;
+  long long o_w1, o_w2, o_b2;
+};
+
+constexpr int EBS_RING = 512;
+constexpr size_t kEdgeBwdSparseSmem = kEdgeBwdSmem + (size_t)EBS_RING * (2 * sizeof(int) + sizeof(unsigned long long)) + 64;
+
+__global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sWpT = smem;                     // [64][36]  Wp^T (B operand of d P)
+  float* sW2T = sWpT + D_P * LD32;        // [64][68]  W2^T (B operand of g1, strided)
+  float* sA = sW2T + D_P * LD64;          // [64][68]  h1 rows of the winners, later g1
+  float* sB = sA + EB_T * LD64;           // [64][68]  d h2, later the K-split partials of d P
+  float* sP = sB + EB_T * LD64;           // [64][36]  P rows of the winners
+  unsigned long long* sLm = reinterpret_cast<unsigned long long*>(sP + EB_T * LD32);   // ring: winner masks
+  int* sLe = reinterpret_cast<int*>(sLm + EBS_RING);                                    // ring: winner edges
+  int* sLc = sLe + EBS_RING;                                                            // ring: their centres
+  int* sWc = sLc + EBS_RING;                                                            // [4] per-wave counts
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int mt = wave >> 1, nt = wave & 1;
+  f32x16 aW2 = zero16(), aWp = zero16();
+  float gb2 = 0.f;                         // column (tid & 63), rows [16 wave, 16 wave + 16) of every d h2 tile
+  for (int i = tid; i < D_P * D_E; i += 256) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 256) sW2T[(i >> 6) * LD64 + (i & 63)] = a.w2t[i];
+  // contiguous edge range of this workgroup (a multiple of 256 edges: one mask per thread and scan step)
+  const int per = ((a.n_edge + (int)gridDim.x - 1) / (int)gridDim.x + 255) & ~255;
+  const int r0 = min(a.n_edge, (int)blockIdx.x * per), r1 = min(a.n_edge, r0 + per);
+  const unsigned lane_b = (unsigned)(32 * nt + col) * 4u;
+  constexpr int RM = EBS_RING - 1;
+  // thread roles of the staging loads
+  const int hrow0 = tid >> 4, hc4 = tid & 15;      // h1 rows hrow0 + 16 i, one float4 each
+  const int prow0 = tid >> 3, pc4 = tid & 7;       // P rows prow0 + 32 i (also the d_pw rows of the final update)
+  const int drow = tid >> 2, dq = tid & 3;         // d h2 row drow, columns [16 dq, 16 dq + 16)
+  // scan state: masks / centres of the next 256 edges are requested one step ahead
+  int pos = r0;
+  unsigned long long m_pf = 0ull; int c_pf = 0;
+#define EBS_PREFETCH_SCAN()                                                                             \
+  do {                                                                                                  \
+    const int e_ = pos + tid;                                                                           \
+    m_pf = e_ < r1 ? a.emask[e_] : 0ull;                                                                \
+    c_pf = e_ < r1 ? a.edge_c[e_] : 0;                                                                  \
+  } while (0)
+  // append the winners of the prefetched 256-edge chunk to the ring at [wbase + wcnt, ...)
+#define EBS_SCAN_STEP(wbase, wcnt)                                                                      \
+  do {                                                                                                  \
+    const unsigned long long m_ = m_pf; const int c_ = c_pf; const int e_ = pos + tid;                  \
+    pos += 256;                                                                                         \
+    if (pos < r1) EBS_PREFETCH_SCAN();                                                                  \
+    const unsigned long long bm_ = __ballot(m_ != 0ull);                                                \
+    if (lane == 0) sWc[wave] = __popcll(bm_);                                                           \
+    __syncthreads();                                                                                    \
+    int base_ = (wcnt), total_ = 0;                                                                     \
+    _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) { const int n_ = sWc[w_]; base_ += w_ < wave ? n_ : 0; total_ += n_; } \
+    if (m_ != 0ull) {                                                                                   \
+      const int idx_ = ((wbase) + base_ + __popcll(bm_ & ((1ull << lane) - 1ull))) & RM;                \
+      sLe[idx_] = e_; sLm[idx_] = m_; sLc[idx_] = c_;                                                   \
+    }                                                                                                   \
+    (wcnt) += total_;                                                                                   \
+    __syncthreads();                                                                                    \
+  } while (0)
+  // staging registers of one tile (h1 rows, P rows, the d_pc rows its d h2 is cut from, old d_pw values)
+  float4 rh0, rh1, rh2, rh3, rp0, rp1, rd0, rd1, rd2, rd3, ro0, ro1;
+  unsigned rbits = 0;
+#define EBS_ISSUE_LOADS(tb, nt_)                                                                        \
+  do {                                                                                                  \
+    const int e0_ = sLe[((tb) + (hrow0 < (nt_) ? hrow0 : 0)) & RM];                                     \
+    const int e1_ = sLe[((tb) + (hrow0 + 16 < (nt_) ? hrow0 + 16 : 0)) & RM];                           \
+    const int e2_ = sLe[((tb) + (hrow0 + 32 < (nt_) ? hrow0 + 32 : 0)) & RM];                           \
+    const int e3_ = sLe[((tb) + (hrow0 + 48 < (nt_) ? hrow0 + 48 : 0)) & RM];                           \
+    rh0 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e0_ * D_P + 4 * hc4);                         \
+    rh1 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e1_ * D_P + 4 * hc4);                         \
+    rh2 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e2_ * D_P + 4 * hc4);                         \
+    rh3 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e3_ * D_P + 4 * hc4);                         \
+    const int q0_ = sLe[((tb) + (prow0 < (nt_) ? prow0 : 0)) & RM];                                     \
+    const int q1_ = sLe[((tb) + (prow0 + 32 < (nt_) ? prow0 + 32 : 0)) & RM];                           \
+    rp0 = *reinterpret_cast<const float4*>(a.pw + (size_t)q0_ * D_E + 4 * pc4);                         \
+    rp1 = *reinterpret_cast<const float4*>(a.pw + (size_t)q1_ * D_E + 4 * pc4);                         \
+    ro0 = *reinterpret_cast<const float4*>(a.d_pw + (size_t)q0_ * D_E + 4 * pc4);                       \
+    ro1 = *reinterpret_cast<const float4*>(a.d_pw + (size_t)q1_ * D_E + 4 * pc4);                       \
+    const int li_ = ((tb) + (drow < (nt_) ? drow : 0)) & RM;                                            \
+    rbits = drow < (nt_) ? (unsigned)(sLm[li_] >> (16 * dq)) & 0xffffu : 0u;                            \
+    const float* dp_ = a.d_pc + (size_t)sLc[li_] * D_P + 16 * dq;                                       \
+    rd0 = *reinterpret_cast<const float4*>(dp_); rd1 = *reinterpret_cast<const float4*>(dp_ + 4);       \
+    rd2 = *reinterpret_cast<const float4*>(dp_ + 8); rd3 = *reinterpret_cast<const float4*>(dp_ + 12);  \
+  } while (0)
+#define EBS_SEL4(v_, k_)                                                                                \
+  make_float4((rbits >> (4 * (k_) + 0)) & 1u ? (v_).x : 0.f, (rbits >> (4 * (k_) + 1)) & 1u ? (v_).y : 0.f, \
+              (rbits >> (4 * (k_) + 2)) & 1u ? (v_).z : 0.f, (rbits >> (4 * (k_) + 3)) & 1u ? (v_).w : 0.f)
+
+  int head = 0, ntile = 0;                 // current tile: ring [head, head + ntile)
+  int wcnt = 0;                            // winners collected beyond the current tile
+  if (pos < r1) EBS_PREFETCH_SCAN();
+  __syncthreads();
+  while (wcnt < EB_T && pos < r1) EBS_SCAN_STEP(head, wcnt);
+  ntile = min(wcnt, EB_T); wcnt -= ntile;
+  if (ntile > 0) EBS_ISSUE_LOADS(head, ntile);
+  while (ntile > 0) {
+    // ---- stage the tile from the registers requested during the previous tile
+    *reinterpret_cast<float4*>(sA + hrow0 * LD64 + 4 * hc4) = rh0;
+    *reinterpret_cast<float4*>(sA + (hrow0 + 16) * LD64 + 4 * hc4) = rh1;
+    *reinterpret_cast<float4*>(sA + (hrow0 + 32) * LD64 + 4 * hc4) = rh2;
+    *reinterpret_cast<float4*>(sA + (hrow0 + 48) * LD64 + 4 * hc4) = rh3;
+    *reinterpret_cast<float4*>(sP + prow0 * LD32 + 4 * pc4) = rp0;
+    *reinterpret_cast<float4*>(sP + (prow0 + 32) * LD32 + 4 * pc4) = rp1;
+    *reinterpret_cast<float4*>(sB + drow * LD64 + 16 * dq) = EBS_SEL4(rd0, 0);
+    *reinterpret_cast<float4*>(sB + drow * LD64 + 16 * dq + 4) = EBS_SEL4(rd1, 1);
+    *reinterpret_cast<float4*>(sB + drow * LD64 + 16 * dq + 8) = EBS_SEL4(rd2, 2);
+    *reinterpret_cast<float4*>(sB + drow * LD64 + 16 * dq + 12) = EBS_SEL4(rd3, 3);
+    const float4 old0 = ro0, old1 = ro1;   // d_pw rows of THIS tile (the next tile's overwrite ro0 / ro1 below)
+    __syncthreads();                                                // tiles complete
+    // ---- next tile: collect its winners and request its rows (hidden under this tile's MFMAs)
+    const int nhead = (head + ntile) & RM;
+    while (wcnt < EB_T && pos < r1) EBS_SCAN_STEP(nhead, wcnt);
+    const int nnext = min(wcnt, EB_T);
+    if (nnext > 0) EBS_ISSUE_LOADS(nhead, nnext);
+    float* sAp = sA + (32 * mt + 4 * half) * LD64 + 32 * nt + col;   // + crow(r, 0) * LD64 = row crow(r, half)
+    float h1[16];                                                   // this lane's h1 values: the ReLU mask of g1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[r] = sAp[crow(r, 0) * LD64];
+    {                                                               // bias gradient: column sums of d h2
+      const float* cp = sB + (16 * wave) * LD64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gb2 += cp[r * LD64];
+    }
+    // ---- d W2[mt-th row tile][nt-th column tile] += h1^T . d h2 over the 64 rows
+    {
+      const float* X = sA + 32 * mt + col;
+      const float* Y = sB + 32 * nt + col;
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) {
+        const int row = 2 * kk + half;
+        aW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(X[row * LD64], Y[row * LD64], aW2, 0, 0, 0);
+      }
+    }
+    // ---- g1 = (d h2 . W2^T) * (h1 > 0)
+    f32x16 g1 = zero16();
+    {
+      const float* ap = sB + (32 * mt + col) * LD64 + 4 * half;
+      const float* bp = sW2T + (4 * half) * LD64 + 32 * nt + col;
+#pragma unroll
+      for (int k = 0; k < D_P; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD64], g1, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD64], g1, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD64], g1, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD64], g1, 0, 0, 0);
+      }
+    }
+    __syncthreads();                                                // every read of h1 (sA) is done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * mt + crow(r, half);
+      const float v = h1[r] > 0.f ? g1[r] : 0.f;
+      sAp[crow(r, 0) * LD64] = v;
+      if (row < ntile) stg_b(a.d_g1, (unsigned)sLe[(head + row) & RM] * (D_P * 4u) + lane_b, v);
+    }
+    __syncthreads();                                                // g1 tile complete
+    // ---- d Wp[:, column tile nt] += P^T . g1 over row half mt
+    {
+      const float* X = sP + (32 * mt) * LD32 + col;
+      const float* Y = sA + (32 * mt) * LD64 + 32 * nt + col;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(X[(2 * kk + half) * LD32], Y[(2 * kk + half) * LD64], aWp, 0, 0, 0);
+    }
+    // ---- d P[rows mt] = g1 . Wp^T, K split over nt; partials through sB (d h2 is consumed)
+    {
+      f32x16 acc = zero16();
+      const float* ap = sA + (32 * mt + col) * LD64 + 32 * nt + 4 * half;
+      const float* bp = sWpT + (32 * nt + 4 * half) * LD32 + col;
+#pragma unroll
+      for (int k = 0; k < 32; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD32], acc, 0, 0, 0);
+      }
+      float* part = sB + nt * (EB_T * D_E);                          // [2][64][32]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(32 * mt + crow(r, half)) * D_E + col] = acc[r];
+    }
+    __syncthreads();                                                // partials complete; sA, sP free
+    // d_pw[e] += d P on the winner rows (an edge is a winner row of exactly one tile per block); this
+    // thread owns the float4 (row prow0 [+ 32], pc4) it fetched with the tile
+    {
+      const float4 x0 = *reinterpret_cast<const float4*>(sB + prow0 * D_E + 4 * pc4);
+      const float4 y0 = *reinterpret_cast<const float4*>(sB + EB_T * D_E + prow0 * D_E + 4 * pc4);
+      const float4 x1 = *reinterpret_cast<const float4*>(sB + (prow0 + 32) * D_E + 4 * pc4);
+      const float4 y1 = *reinterpret_cast<const float4*>(sB + EB_T * D_E + (prow0 + 32) * D_E + 4 * pc4);
+      if (prow0 < ntile)
+        *reinterpret_cast<float4*>(a.d_pw + (size_t)sLe[(head + prow0) & RM] * D_E + 4 * pc4) =
+            make_float4(old0.x + (x0.x + y0.x), old0.y + (x0.y + y0.y), old0.z + (x0.z + y0.z), old0.w + (x0.w + y0.w));
+      if (prow0 + 32 < ntile)
+        *reinterpret_cast<float4*>(a.d_pw + (size_t)sLe[(head + prow0 + 32) & RM] * D_E + 4 * pc4) =
+            make_float4(old1.x + (x1.x + y1.x), old1.y + (x1.y + y1.y), old1.z + (x1.z + y1.z), old1.w + (x1.w + y1.w));
+    }
+    head = nhead; ntile = nnext; wcnt -= nnext;
+    __syncthreads();                                                // sA / sB / sP reusable
+  }
+#undef EBS_PREFETCH_SCAN
+#undef EBS_SCAN_STEP
+#undef EBS_ISSUE_LOADS
+#undef EBS_SEL4
+  // ---- partial weight gradients of this workgroup
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  store_acc(ar + a.o_w2 + (size_t)(32 * mt) * D_P + 32 * nt, D_P, aW2, lane);
+  __syncthreads();
+  float* red = sA;
+  if (mt == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[nt * 1024 + r * 64 + lane] = aWp[r];
+  }
+  red[2048 + tid] = gb2;
+  __syncthreads();
+  if (mt == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aWp[r] += red[nt * 1024 + r * 64 + lane];
+    store_acc(ar + a.o_w1 + 32 * nt, D_P, aWp, lane);               // rows 0-31 of pw_fc1
+  }
+  if (tid < D_P) ar[a.o_b2 + tid] = (red[2048 + tid] + red[2048 + 64 + tid]) + (red[2048 + 128 + tid] + red[2048 + 192 + tid]);
+}
+
+// d_rc[i] = sum over i's winner edges of g1[e];  d_rn[i] = sum over i's edges e = (i, n), n != i, of
+// g1[reverse(e)] when the reversed pair is a winner of n.  Only winner rows of d_g1 are valid.
+__global__ void __launch_bounds__(256) gather_sparse(const float* __restrict__ g1, const int* __restrict__ row_ptr,
+                                                     const int* __restrict__ edge_n, const int* __restrict__ edge_t,
+                                                     const unsigned long long* __restrict__ emask,
+                                                     int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n_det) return;
+  const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
+  const int eb = row_ptr[node], ee = row_ptr[node + 1];
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
+  for (int base = eb; base < ee; base += 64) {
+    const int el = base + lane;
+    int tt = -1; bool own = false;
+    if (el < ee) {
+      own = emask[el] != 0ull;
+      if (edge_n[el] != node) {                               // self pair: n_feats zeroed (network.py:371-374)
+        const int t = edge_t[el];
+        tt = emask[t] != 0ull ? t : -1;
+      }
+    }
+    unsigned long long mo = __ballot(own), mr = __ballot(tt >= 0);
+    // winner rows only, four at a time (one per quarter-wave), ascending edge order
+    while (mo) {
+      int j = -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { if (mo) { const int b = __builtin_ctzll(mo); mo &= mo - 1; if (q == sub) j = b; } }
+      if (j >= 0) {
+        const float4 c = *reinterpret_cast<const float4*>(g1 + (size_t)(base + j) * D_P + 4 * f4);
+        sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+      }
+    }
+    while (mr) {
+      int j = -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if (q == sub) j = b; } }
+      const int t = __shfl(tt, j < 0 ? 0 : j);
+      if (j >= 0) {
+        const float4 v = *reinterpret_cast<const float4*>(g1 + (size_t)t * D_P + 4 * f4);
+        sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    sc.x += __shfl_xor(sc.x, o); sc.y += __shfl_xor(sc.y, o); sc.z += __shfl_xor(sc.z, o); sc.w += __shfl_xor(sc.w, o);
+    sn.x += __shfl_xor(sn.x, o); sn.y += __shfl_xor(sn.y, o); sn.z += __shfl_xor(sn.z, o); sn.w += __shfl_xor(sn.w, o);
+  }
+  if (sub == 0) {
+    *reinterpret_cast<float4*>(d_rc + (size_t)node * D_P + 4 * f4) = sc;
+    *reinterpret_cast<float4*>(d_rn + (size_t)node * D_P + 4 * f4) = sn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 struct PwBwdArgs {
   int n_edge;
   const float* pw; const float* d_pw; const float* h1; const float* h2;
@@ -946,7 +1323,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
-  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_h1[1]) return GNET_ERR_INVALID;   // plan(training=1)
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_h1[1] || !buf->blk_parg[1] || !buf->emask) return GNET_ERR_INVALID;   // plan(training=1)
   hipStream_t s = (hipStream_t)stream;
   const ParamLayout L = make_layout(cfg);
   const int B = cfg->num_blocks;
@@ -968,10 +1345,15 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (N + 3) / 4)) : 0;          // node-sum workgroups
   const int g_w1c = E > 0 ? max(1, min(128, 256 / (2 * L.cprime))) : 0;               // node chunks per class row
 
+  // GNET_DENSE_BWD=1 forces the dense edge stage for every block (A/B measurements, tests of the dense path)
+  static const bool g_force_dense = getenv("GNET_DENSE_BWD") && atoi(getenv("GNET_DENSE_BWD")) != 0;
+  // the edge stages accumulate into d_pw (the sparse one touches winner rows only)
+  if (E > 0) HIP_CHECK_RET(hipMemsetAsync(buf->d_pw, 0, (size_t)E * D_E * sizeof(float), s));
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSparseSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
     attr_set = true;
   }
@@ -995,19 +1377,39 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       p.arena = buf->arena; p.stride = stride; p.o_w4 = K.w4; p.o_b4 = K.b4; p.o_w3 = K.w3; p.o_b3 = K.b3;
       GNET_LAUNCH(prof, GNET_K_BLK_POST, s, blk_bwd_post<<<g_node, 256, 0, s>>>(p));
     }
-    if (E > 0) {
+    if (E > 0 && !g_force_dense) {
+      // ---- sparse edge stage: winner rows only
+      HIP_CHECK_RET(hipMemsetAsync(buf->emask, 0, (size_t)E * sizeof(unsigned long long), s));
+      WinArgs w;
+      w.n_det = N; w.pm = (const unsigned long long*)buf->blk_pm[b]; w.parg = (const unsigned long long*)buf->blk_parg[b];
+      w.emask = (unsigned long long*)buf->emask;
+      w.row_ptr = buf->row_ptr; w.h1 = buf->blk_h1[b]; w.w2t = pt + K.w2; w.b2 = params + K.b2;
+      GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<min((N + 3) / 4, 2048), 256, 0, s>>>(w));
+      EdgeBwdSparseArgs e;
+      e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (const unsigned long long*)buf->emask;
+      e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b]; e.d_pc = buf->d_pc;
+      e.w1t = pt + K.w1; e.w2t = pt + K.w2;
+      e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
+      e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
+      GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_sparse<<<g_edge, 256, kEdgeBwdSparseSmem, s>>>(e));
+      GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sparse<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t,
+                                                                                 (const unsigned long long*)buf->emask, N, buf->d_rc, buf->d_rn));
+    } else if (E > 0) {
+      // ---- dense edge stage (every edge row; GNET_DENSE_BWD=1)
       EdgeBwdArgs e;
-      e.n_edge = E; e.n_det = N; e.accumulate_dpw = b != B;
+      e.n_edge = E; e.n_det = N; e.accumulate_dpw = 1;
       e.edge_c = buf->edge_c; e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b];
       e.pm = (const unsigned long long*)buf->blk_pm[b]; e.d_pc = buf->d_pc;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2; e.b2 = params + K.b2; e.w1 = params + K.w1; e.w2 = params + K.w2;
       e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
       e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
-      if (e.accumulate_dpw) { GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<true><<<g_edge, 256, kEdgeBwdSmem, s>>>(e)); }
-      else { GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<false><<<g_edge, 256, kEdgeBwdSmem, s>>>(e)); }
+      GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<true><<<g_edge, 256, kEdgeBwdSmem, s>>>(e));
+      GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sums<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t,
+                                                                                N, buf->d_rc, buf->d_rn));
+    } else {
+      HIP_CHECK_RET(hipMemsetAsync(buf->d_rc, 0, (size_t)N * D_P * sizeof(float), s));
+      HIP_CHECK_RET(hipMemsetAsync(buf->d_rn, 0, (size_t)N * D_P * sizeof(float), s));
     }
-    GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sums<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, N,
-                                                                              buf->d_rc, buf->d_rn));
     {
       BlkPreArgs p;
       p.n_det = N; p.write_dx = b > 1;

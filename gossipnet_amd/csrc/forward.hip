@@ -577,8 +577,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
     if (!head_shared && !tail_shared) *dst = ((unsigned long long)__float_as_uint(mm) << 32) | kk;
     else pm_flush(dst, mm, kk);
     if (TRAIN) {
-      // shared centres: the larger maximum wins with its edge; equal positive maxima are ties (the dense
-      // backward handles those blocks, see tie_flags), so which edge survives does not matter
+      // shared centres: the larger maximum wins with its edge; for equal positive maxima (ties) any of the tied
+      // edges may survive -- winners_mark finds all of them from the tie count
       const unsigned long long key = ((unsigned long long)__float_as_uint(mm) << 32) | (unsigned)(half ? g1 : g0);
       unsigned long long* ad = a.parg + (size_t)cur * D_P + 32 * half + col;
       if (!head_shared && !tail_shared) *ad = key;
@@ -600,7 +600,6 @@ struct NodeFwdArgs {
   int do_head;                   // after the last block: predict/fc1, fc2, logits
   int training;
   const unsigned long long* pm;  // [N,64] block b
-  int* tie_flag;                 // set when a positive maximum of block b is attained by 2+ edges (training)
   const float* x_prev;           // [N,128] block b input (NULL = zeros)
   const float* w3t; const float* b3;   // fc1 transposed [64][64]
   const float* w4t; const float* b4;   // fc2 transposed [128][64]
@@ -624,9 +623,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     for (int i = tid; i < 32 * D_P; i += 256) {
       const int row = i >> 6, ff = i & 63;
       const int node = min(row0 + row, a.n_det - 1);
-      const unsigned long long pv = a.pm[(size_t)node * D_P + ff];
-      sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(pv >> 32));
-      if (a.tie_flag && (unsigned)pv > 1u && (pv >> 32) != 0ull) *a.tie_flag = 1;    // benign race: same value
+      sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(a.pm[(size_t)node * D_P + ff] >> 32));
     }
     __syncthreads();
     f32x16 acc = zero16();
@@ -758,7 +755,6 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
 
   void* prof = buf->profiler;
   GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B));
-  if (training) HIP_CHECK_RET(hipMemsetAsync(buf->tie_flags, 0, (GNET_MAX_BLOCKS + 1) * sizeof(int32_t), s));
 
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
@@ -789,7 +785,6 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     NodeFwdArgs n;
     n.n_det = N; n.do_post = b >= 1; n.do_pre = b < B; n.do_head = b == B; n.training = training;
     n.pm = b >= 1 ? (const unsigned long long*)buf->blk_pm[b] : nullptr;
-    n.tie_flag = (training && b >= 1) ? buf->tie_flags + b : nullptr;
     n.x_prev = b >= 2 ? buf->block_feats[b - 1] : nullptr;
     if (b >= 1) {
       n.w3t = pt + L.blk[b].w3; n.b3 = params + L.blk[b].b3;

@@ -76,7 +76,6 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
     b.emask = c.take<uint64_t>(Ep);
-    b.tie_flags = c.take<int32_t>(GNET_MAX_BLOCKS + 1);
     b.w1_s = c.take<float>(Np * D_H);
     b.w1_t = c.take<float>(Np * D_H);
     b.arena_floats = arena_floats(cfg, sh);

@@ -77,4 +77,3 @@ def test_argmax_edges_recorded_for_backward():
         assert np.all(arg[pos] >= rp[c_idx[pos]]) and np.all(arg[pos] < rp[c_idx[pos] + 1])   # an edge of that detection
         j_idx = np.repeat(np.arange(64)[None, :], n, 0)
         assert np.abs(h2[arg[pos], j_idx[pos]] - mx[pos]).max() < 1e-5
-        assert int(net._view(net._buf.tie_flags, 17, torch.int32)[blk]) == 0
