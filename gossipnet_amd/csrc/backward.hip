@@ -766,6 +766,7 @@ struct EdgeBwdSparseArgs {
   int n_edge; int n_det;
   const int* edge_c;
   const unsigned long long* emask;
+  unsigned long long* ewin;         // [E/64] out: bit e = edge e is a winner (for gather_sparse; by-product of the scan)
   const float* pw; const float* h1; const float* d_pc;
   const float* w1t; const float* w2t;
   float* d_pw; float* d_g1;
@@ -820,7 +821,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     pos += 256;                                                                                         \
     if (pos < r1) EBS_PREFETCH_SCAN();                                                                  \
     const unsigned long long bm_ = __ballot(m_ != 0ull);                                                \
-    if (lane == 0) sWc[wave] = __popcll(bm_);                                                           \
+    if (lane == 0) { sWc[wave] = __popcll(bm_); a.ewin[(e_ >> 6)] = bm_; }                              \
     __syncthreads();                                                                                    \
     int base_ = (wcnt), total_ = 0;                                                                     \
     _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) { const int n_ = sWc[w_]; base_ += w_ < wave ? n_ : 0; total_ += n_; } \
@@ -998,7 +999,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
 // g1[reverse(e)] when the reversed pair is a winner of n.  Only winner rows of d_g1 are valid.
 __global__ void __launch_bounds__(256) gather_sparse(const float* __restrict__ g1, const int* __restrict__ row_ptr,
                                                      const int* __restrict__ edge_n, const int* __restrict__ edge_t,
-                                                     const unsigned long long* __restrict__ emask,
+                                                     const unsigned long long* __restrict__ ewin,
                                                      int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
   const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= n_det) return;
@@ -1009,10 +1010,10 @@ __global__ void __launch_bounds__(256) gather_sparse(const float* __restrict__ g
     const int el = base + lane;
     int tt = -1; bool own = false;
     if (el < ee) {
-      own = emask[el] != 0ull;
+      own = (ewin[el >> 6] >> (el & 63)) & 1ull;            // the 1-bit-per-edge winner map stays in L2 (E / 8 bytes)
       if (edge_n[el] != node) {                               // self pair: n_feats zeroed (network.py:371-374)
         const int t = edge_t[el];
-        tt = emask[t] != 0ull ? t : -1;
+        tt = (ewin[t >> 6] >> (t & 63)) & 1ull ? t : -1;
       }
     }
     unsigned long long mo = __ballot(own), mr = __ballot(tt >= 0);
@@ -1388,12 +1389,13 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       EdgeBwdSparseArgs e;
       e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (const unsigned long long*)buf->emask;
       e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b]; e.d_pc = buf->d_pc;
+      e.ewin = (unsigned long long*)buf->emask + (((size_t)E + 64 + 63) & ~(size_t)63);   // tail of the emask buffer
       e.w1t = pt + K.w1; e.w2t = pt + K.w2;
       e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
       e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
       GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_sparse<<<g_edge, 256, kEdgeBwdSparseSmem, s>>>(e));
       GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sparse<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t,
-                                                                                 (const unsigned long long*)buf->emask, N, buf->d_rc, buf->d_rn));
+                                                                                 (const unsigned long long*)e.ewin, N, buf->d_rc, buf->d_rn));
     } else if (E > 0) {
       // ---- dense edge stage (every edge row; GNET_DENSE_BWD=1)
       EdgeBwdArgs e;

@@ -75,7 +75,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_pw = c.take<float>(Ep * D_E);
     b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
-    b.emask = c.take<uint64_t>(Ep);
+    b.emask = c.take<uint64_t>(Ep + 64 + Ep / 64 + 64);   // per-edge masks, then the 1-bit-per-edge winner map
     b.w1_s = c.take<float>(Np * D_H);
     b.w1_t = c.take<float>(Np * D_H);
     b.arena_floats = arena_floats(cfg, sh);
