@@ -796,9 +796,12 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
   float gb2 = 0.f;                         // column (tid & 63), rows [16 wave, 16 wave + 16) of every d h2 tile
   for (int i = tid; i < D_P * D_E; i += 256) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
   for (int i = tid; i < D_P * D_P; i += 256) sW2T[(i >> 6) * LD64 + (i & 63)] = a.w2t[i];
-  // contiguous edge range of this workgroup (a multiple of 256 edges: one mask per thread and scan step)
-  const int per = ((a.n_edge + (int)gridDim.x - 1) / (int)gridDim.x + 255) & ~255;
-  const int r0 = min(a.n_edge, (int)blockIdx.x * per), r1 = min(a.n_edge, r0 + per);
+  // this workgroup scans the 256-edge chunks blockIdx.x, blockIdx.x + gridDim.x, ... (one mask per thread and
+  // scan step).  Round-robin chunks: the winner density varies from image to image (measured 462..1080
+  // winners per contiguous range), the interleave gives every workgroup the same mix -- statically, so the
+  // summation order of the weight gradients stays reproducible.
+  const int r1 = a.n_edge;
+  const int pstep = 256 * (int)gridDim.x;
   const unsigned lane_b = (unsigned)(32 * nt + col) * 4u;
   constexpr int RM = EBS_RING - 1;
   // thread roles of the staging loads
@@ -806,7 +809,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
   const int prow0 = tid >> 3, pc4 = tid & 7;       // P rows prow0 + 32 i (also the d_pw rows of the final update)
   const int drow = tid >> 2, dq = tid & 3;         // d h2 row drow, columns [16 dq, 16 dq + 16)
   // scan state: masks / centres of the next 256 edges are requested one step ahead
-  int pos = r0;
+  int pos = 256 * (int)blockIdx.x;
   unsigned long long m_pf = 0ull; int c_pf = 0;
 #define EBS_PREFETCH_SCAN()                                                                             \
   do {                                                                                                  \
@@ -818,7 +821,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
 #define EBS_SCAN_STEP(wbase, wcnt)                                                                      \
   do {                                                                                                  \
     const unsigned long long m_ = m_pf; const int c_ = c_pf; const int e_ = pos + tid;                  \
-    pos += 256;                                                                                         \
+    pos += pstep;                                                                                       \
     if (pos < r1) EBS_PREFETCH_SCAN();                                                                  \
     const unsigned long long bm_ = __ballot(m_ != 0ull);                                                \
     if (lane == 0) { sWc[wave] = __popcll(bm_); a.ewin[(e_ >> 6)] = bm_; }                              \
@@ -889,8 +892,13 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     if (nnext > 0) EBS_ISSUE_LOADS(nhead, nnext);
     float* sAp = sA + (32 * mt + 4 * half) * LD64 + 32 * nt + col;   // + crow(r, 0) * LD64 = row crow(r, half)
     float h1[16];                                                   // this lane's h1 values: the ReLU mask of g1
+    unsigned go[16];                                                // byte offsets of this lane's g1 rows in d_g1
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h1[r] = sAp[crow(r, 0) * LD64];
+    for (int r = 0; r < 16; ++r) {
+      h1[r] = sAp[crow(r, 0) * LD64];
+      const int row = 32 * mt + crow(r, half);                      // rows past the tile go to the slack row E
+      go[r] = (unsigned)(row < ntile ? sLe[(head + row) & RM] : a.n_edge) * (D_P * 4u) + lane_b;
+    }
     {                                                               // bias gradient: column sums of d h2
       const float* cp = sB + (16 * wave) * LD64 + lane;
 #pragma unroll
@@ -923,10 +931,9 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     __syncthreads();                                                // every read of h1 (sA) is done
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = 32 * mt + crow(r, half);
       const float v = h1[r] > 0.f ? g1[r] : 0.f;
       sAp[crow(r, 0) * LD64] = v;
-      if (row < ntile) stg_b(a.d_g1, (unsigned)sLe[(head + row) & RM] * (D_P * 4u) + lane_b, v);
+      stg_b(a.d_g1, go[r], v);
     }
     __syncthreads();                                                // g1 tile complete
     // ---- d Wp[:, column tile nt] += P^T . g1 over row half mt
