@@ -706,15 +706,17 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
     const int arg = (int)(unsigned)pv;
     const unsigned long long ties = __ballot(valid && (unsigned)pc > 1u);
     unsigned long long todo = __ballot(valid);
+    unsigned long long mine = 0ull;                         // set on the first lane of every distinct winner edge
     while (todo) {                                          // one iteration per distinct winner edge
       const int k = __builtin_ctzll(todo);
       const int ak = __builtin_amdgcn_readlane(arg, k);
       const unsigned long long m = __ballot(valid && arg == ak);
-      if (lane == k) {
-        if (ties) atomicOr(a.emask + ak, m);                // (the tie pass below ORs into the same words)
-        else a.emask[ak] = m;                               // every edge belongs to exactly one detection
-      }
+      mine = lane == k ? m : mine;
       todo &= ~m;
+    }
+    if (mine != 0ull) {                                     // one store instruction per detection
+      if (ties) atomicOr(a.emask + arg, mine);              // (the tie pass below ORs into the same words)
+      else a.emask[arg] = mine;                             // every edge belongs to exactly one detection
     }
     if (ties) {
       // Rare: some column's maximum is attained by several edges, and the forward pass kept only the first.
@@ -1392,7 +1394,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       w.n_det = N; w.pm = (const unsigned long long*)buf->blk_pm[b]; w.parg = (const unsigned long long*)buf->blk_parg[b];
       w.emask = (unsigned long long*)buf->emask;
       w.row_ptr = buf->row_ptr; w.h1 = buf->blk_h1[b]; w.w2t = pt + K.w2; w.b2 = params + K.b2;
-      GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<min((N + 3) / 4, 2048), 256, 0, s>>>(w));
+      GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<(N + 3) / 4, 256, 0, s>>>(w));
       EdgeBwdSparseArgs e;
       e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (const unsigned long long*)buf->emask;
       e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b]; e.d_pc = buf->d_pc;
