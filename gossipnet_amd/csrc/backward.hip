@@ -769,6 +769,7 @@ struct EdgeBwdSparseArgs {
   const int* edge_c;
   const unsigned long long* emask;
   unsigned long long* ewin;         // [E/64] out: bit e = edge e is a winner (for gather_sparse; by-product of the scan)
+  unsigned long long* eany;         // [E/64] |= ewin over the blocks: edges that carry any gradient into the pw-MLP
   const float* pw; const float* h1; const float* d_pc;
   const float* w1t; const float* w2t;
   float* d_pw; float* d_g1;
@@ -826,7 +827,10 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     pos += pstep;                                                                                       \
     if (pos < r1) EBS_PREFETCH_SCAN();                                                                  \
     const unsigned long long bm_ = __ballot(m_ != 0ull);                                                \
-    if (lane == 0) { sWc[wave] = __popcll(bm_); a.ewin[(e_ >> 6)] = bm_; }                              \
+    if (lane == 0) {                                                                                    \
+      sWc[wave] = __popcll(bm_); a.ewin[(e_ >> 6)] = bm_;                                               \
+      if (bm_) __hip_atomic_fetch_or(a.eany + (e_ >> 6), bm_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    }                                                                                                   \
     __syncthreads();                                                                                    \
     int base_ = (wcnt), total_ = 0;                                                                     \
     _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) { const int n_ = sWc[w_]; base_ += w_ < wave ? n_ : 0; total_ += n_; } \
@@ -1059,8 +1063,74 @@ __global__ void __launch_bounds__(256) gather_sparse(const float* __restrict__ g
 }
 
 // ------------------------------------------------------------------------------------------
+// Rows of the pw-MLP backward: only edges that were a winner row in at least one block have a non-zero
+// d_pw row (72 % of the edges at E/N = 86); the others contribute exact zeros to every sum.  rowlist_* turn
+// the bitmap into an ascending list (count -> exclusive_scan -> fill: deterministic order).
+__device__ __forceinline__ unsigned long long rowlist_word(const unsigned long long* __restrict__ bits, int w, int n_words, int n_edge) {
+  if (w >= n_words) return 0ull;
+  unsigned long long b = bits[w];
+  if (w == n_words - 1 && (n_edge & 63)) b &= (1ull << (n_edge & 63)) - 1ull;     // bits past the last edge
+  return b;
+}
+
+__global__ void __launch_bounds__(256) rowlist_count(const unsigned long long* __restrict__ bits, int n_words, int n_edge, int* __restrict__ wg_count) {
+  __shared__ int red[4];
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  int c = __popcll(rowlist_word(bits, w, n_words, n_edge));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) wg_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) rowlist_fill(const unsigned long long* __restrict__ bits, int n_words, int n_edge,
+                                                    const int* __restrict__ wg_off, int* __restrict__ rows) {
+  __shared__ int part[256];
+  const int t = threadIdx.x, w = blockIdx.x * 256 + t;
+  unsigned long long b = rowlist_word(bits, w, n_words, n_edge);
+  const int c = __popcll(b);
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int pos = wg_off[blockIdx.x] + part[t] - c;
+  while (b) {
+    const int j = __builtin_ctzll(b);
+    b &= b - 1;
+    rows[pos++] = 64 * w + j;
+  }
+}
+
+// exclusive scan of cnt[0..n) into out[0..n], out[n] = total.  One workgroup.
+__global__ void __launch_bounds__(1024) rowlist_scan(const int* __restrict__ cnt, int n, int* __restrict__ out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per, e = min(n, b + per);
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += cnt[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int i = b; i < e; ++i) { const int d = cnt[i]; out[i] = run; run += d; }
+  if (t == 1023) out[n] = part[1023];
+}
+
 struct PwBwdArgs {
   int n_edge;
+  const int* rows;           // ascending edge indices with a non-zero d_pw row
+  const int* n_rows;         // their number (device)
   const float* pw; const float* d_pw; const float* h1; const float* h2;
   const float* w2; const float* w3;          // natural [256,256], [256,32]
   float* d_h1;
@@ -1084,6 +1154,19 @@ __device__ __forceinline__ void dma_tile32(float* sdst, const float* __restrict_
   }
 }
 
+// the same copy for rows given by an index list (rows past the list re-read its last row)
+__device__ __forceinline__ void dma_rows32(float* sdst, const float* __restrict__ g, const int* __restrict__ rows, int p0,
+                                           int n_rows, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wave * 4 + q;
+    const int er = rows[min(p0 + row, n_rows - 1)];
+    const float* src = g + (size_t)er * D_H + 4 * lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sdst + row * LD256), 16, 0, 0);
+  }
+}
+
 __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // two tile buffers {h1 [32][260], h2 [32][260]} filled by DMA one tile ahead, + d3 [32][36]
@@ -1095,7 +1178,9 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   for (int j = 0; j < 8; ++j) aW2[0][j] = zero16();
   f32x16 aW3 = zero16();
   float gb2 = 0.f, gb3 = 0.f;
-  const int ntiles = (a.n_edge + 31) / 32;
+  __shared__ int sRows[2][32];              // edge index of the tile's rows (this tile / the next one)
+  const int n_rows = *a.n_rows;
+  const int ntiles = (n_rows + 31) / 32;
   // Everything a tile reads from HBM is requested one tile ahead and BEFORE the tile's 16 d_h1 stores: the
   // h1/h2 tiles by DMA into the other LDS buffer, the d_pw / pw values of the d3 tile into registers.  The
   // wait at the top of a tile is then vmcnt(16): "everything but the 16 youngest operations", i.e. it never
@@ -1105,29 +1190,42 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3 + (size_t)(32 * wave + col) * D_E + 4 * half + 8 * k);
   float pq0 = 0.f, pq1 = 0.f, dq0 = 0.f, dq1 = 0.f;     // d3 tile sources: elements tid and tid + 512 of [32][32]
-#define PB_PREFETCH_D3(tile_)                                                                           \
+  // rows past the list re-read its last row (finite data); their d3 rows are zero
+#define PB_ROW(tile_, r_) a.rows[min((tile_) * 32 + (r_), n_rows - 1)]
+  // the row indices themselves are fetched one tile earlier still (ra / rb / rs), so the d3 source requests
+  // never wait for an index
+  int ra = 0, rb = 0, rs = 0, rs_tile = 0;
+#define PB_LOAD_ROWIDS(tile_)                                                                           \
   do {                                                                                                  \
-    const long long el_ = (long long)a.n_edge * D_E - 1, o_ = (long long)(tile_) * 32 * D_E + tid;      \
-    pq0 = a.pw[min(o_, el_)]; dq0 = a.d_pw[min(o_, el_)];                                               \
-    pq1 = a.pw[min(o_ + 512, el_)]; dq1 = a.d_pw[min(o_ + 512, el_)];                                   \
+    ra = PB_ROW(tile_, tid >> 5); rb = PB_ROW(tile_, (tid >> 5) + 16);                                  \
+    rs = (tile_) * 32 + (tid & 31) < n_rows ? a.rows[(tile_) * 32 + (tid & 31)] : a.n_edge;   /* slack row */ \
+  } while (0)
+#define PB_PREFETCH_D3()                                                                                \
+  do {                                                                                                  \
+    pq0 = a.pw[(size_t)ra * D_E + (tid & 31)]; dq0 = a.d_pw[(size_t)ra * D_E + (tid & 31)];             \
+    pq1 = a.pw[(size_t)rb * D_E + (tid & 31)]; dq1 = a.d_pw[(size_t)rb * D_E + (tid & 31)];             \
+    rs_tile = rs;                                                                                       \
   } while (0)
   if ((int)blockIdx.x < ntiles) {
-    dma_tile32(smem, a.h1, (long long)blockIdx.x * 32, a.n_edge, wave, lane);
-    dma_tile32(smem + 32 * LD256, a.h2, (long long)blockIdx.x * 32, a.n_edge, wave, lane);
-    PB_PREFETCH_D3((int)blockIdx.x);
+    PB_LOAD_ROWIDS((int)blockIdx.x);
+    dma_rows32(smem, a.h1, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
+    dma_rows32(smem + 32 * LD256, a.h2, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
+    PB_PREFETCH_D3();
+    if ((int)(blockIdx.x + gridDim.x) < ntiles) PB_LOAD_ROWIDS((int)(blockIdx.x + gridDim.x));
   }
   drain_vmem_before_loop();
   int it = 0;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
-    const long long e0 = (long long)t * 32;
+    const int e0 = t * 32;                 // first list position of the tile
     float* sH1 = smem + (it & 1) * (2 * 32 * LD256);
     float* sH2 = sH1 + 32 * LD256;        // fc2 output, then d(fc2 pre-activation)
     float* nH1 = smem + ((it & 1) ^ 1) * (2 * 32 * LD256);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this tile's DMA and d3 sources (issued one tile ago) have landed
+    if (tid < 32) sRows[it & 1][tid] = rs_tile;
     {
-      const int row0 = tid >> 5, j = tid & 31;            // rows past E: zero gradient
-      sD3[row0 * LD32 + j] = (e0 + row0 < a.n_edge && pq0 > 0.f) ? dq0 : 0.f;              // ReLU of fc3
-      sD3[(row0 + 16) * LD32 + j] = (e0 + row0 + 16 < a.n_edge && pq1 > 0.f) ? dq1 : 0.f;
+      const int row0 = tid >> 5, j = tid & 31;            // rows past the list: zero gradient
+      sD3[row0 * LD32 + j] = (e0 + row0 < n_rows && pq0 > 0.f) ? dq0 : 0.f;                // ReLU of fc3
+      sD3[(row0 + 16) * LD32 + j] = (e0 + row0 + 16 < n_rows && pq1 > 0.f) ? dq1 : 0.f;
     }
     __syncthreads();
     // d(fc2 pre) tile w = (d3 . W3^T) * (h2 > 0)
@@ -1162,9 +1260,10 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     // next tile's h1/h2 -> the other buffer (last read during the previous tile).  Issued here: the
     // d W2 phase below touches only LDS, so the in-order vmcnt never waits on this copy.
     if (t + (int)gridDim.x < ntiles) {
-      dma_tile32(nH1, a.h1, e0 + (long long)gridDim.x * 32, a.n_edge, wave, lane);
-      dma_tile32(nH1 + 32 * LD256, a.h2, e0 + (long long)gridDim.x * 32, a.n_edge, wave, lane);
-      PB_PREFETCH_D3(t + (int)gridDim.x);
+      dma_rows32(nH1, a.h1, a.rows, e0 + (int)gridDim.x * 32, n_rows, wave, lane);
+      dma_rows32(nH1 + 32 * LD256, a.h2, a.rows, e0 + (int)gridDim.x * 32, n_rows, wave, lane);
+      PB_PREFETCH_D3();
+      if (t + 2 * (int)gridDim.x < ntiles) PB_LOAD_ROWIDS(t + 2 * (int)gridDim.x);
     }
     if (tid < D_H) gb2 += col_sum32(sH2, LD256, tid);
     // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
@@ -1173,11 +1272,12 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     {
       f32x16 acc = zero16();
       mma_abt_gB<D_H, 6>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
-      // rows past E land in the buffer's slack (their d3 rows are zero anyway)
-      float* dp = a.d_h1 + (size_t)(e0 + 4 * half) * D_H + 32 * wave + col;
+      // d_h1 rows go back to their edge positions (rows past the list: the slack row E); exactly 16 stores
+      const int* rp = sRows[it & 1] + 4 * half;
       const float* hp = sH1 + (4 * half) * LD256 + 32 * wave + col;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dp[crow(r, 0) * D_H] = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
+      for (int r = 0; r < 16; ++r)
+        a.d_h1[(size_t)rp[crow(r, 0)] * D_H + 32 * wave + col] = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
     }
   }
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
@@ -1200,6 +1300,7 @@ struct PwW1Args {
   int n_det; int cprime; int multiclass;
   const int* row_ptr; const int* edge_t; const float* geo; const float* d_h1;
   const float* scores; const int* classes;
+  const unsigned long long* eany;   // bit e: d_h1 row e is valid (edges without gradient were never written)
   float* w1_s; float* w1_t;
   float* arena; long long stride;
   long long o_w1, o_b1;
@@ -1216,29 +1317,50 @@ __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
   for (int node = blockIdx.x * 4 + wave; node < a.n_det; node += nwaves) {
     const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
     float4 S = make_float4(0.f, 0.f, 0.f, 0.f), T = S;
-    for (int e = eb; e < ee; e += 2) {
-      const int e1 = min(e + 1, ee - 1);
-      const bool two = e + 1 < ee;
-      const float4 d0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e * D_H + 4 * lane);
-      float4 d1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e1 * D_H + 4 * lane);
-      const float4 t0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)a.edge_t[e] * D_H + 4 * lane);
-      float4 t1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)a.edge_t[e1] * D_H + 4 * lane);
-      const float4 ga0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
-      const float4 gc0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
-      float4 ga1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8);
-      float4 gc1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8 + 4);
-      if (!two) { d1 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = d1; }
+#define W1_BIT(e_) ((a.eany[(e_) >> 6] >> ((e_) & 63)) & 1ull)
 #define ACC4(dst, s, v) dst.x = fmaf(s, v.x, dst.x); dst.y = fmaf(s, v.y, dst.y); dst.z = fmaf(s, v.z, dst.z); dst.w = fmaf(s, v.w, dst.w)
-      S.x += d0.x; S.y += d0.y; S.z += d0.z; S.w += d0.w;
-      T.x += t0.x; T.y += t0.y; T.z += t0.z; T.w += t0.w;
-      ACC4(g[0], ga0.x, d0); ACC4(g[1], ga0.y, d0); ACC4(g[2], ga0.z, d0); ACC4(g[3], ga0.w, d0);
-      ACC4(g[4], gc0.x, d0); ACC4(g[5], gc0.y, d0); ACC4(g[6], gc0.z, d0);
-      S.x += d1.x; S.y += d1.y; S.z += d1.z; S.w += d1.w;
-      T.x += t1.x; T.y += t1.y; T.z += t1.z; T.w += t1.w;
-      ACC4(g[0], ga1.x, d1); ACC4(g[1], ga1.y, d1); ACC4(g[2], ga1.z, d1); ACC4(g[3], ga1.w, d1);
-      ACC4(g[4], gc1.x, d1); ACC4(g[5], gc1.y, d1); ACC4(g[6], gc1.z, d1);
-#undef ACC4
+    // 64 edges per pass: reversed-pair positions and the "carries gradient" bits of both the own and the
+    // reversed rows arrive in coalesced / L2-resident loads; only rows that carry gradient are read (the
+    // others were never written: exact zeros), two at a time, ascending edge order
+    for (int base = eb; base < ee; base += 64) {
+      const int el = base + lane;
+      const bool in = el < ee;
+      const int tt = in ? a.edge_t[el] : 0;
+      unsigned long long mo = __ballot(in && W1_BIT(el));
+      unsigned long long mr = __ballot(in && W1_BIT(tt));
+      while (mo) {
+        const int j0 = __builtin_ctzll(mo); mo &= mo - 1;
+        const bool two = mo != 0ull;
+        const int j1 = two ? __builtin_ctzll(mo) : j0; mo &= mo - 1;      // (mo == 0 stays 0)
+        const int e = base + j0, e1 = base + j1;
+        const float4 d0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e * D_H + 4 * lane);
+        const float4 d1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e1 * D_H + 4 * lane);
+        const float4 ga0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
+        const float4 gc0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
+        const float4 ga1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8);
+        const float4 gc1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8 + 4);
+        S.x += d0.x; S.y += d0.y; S.z += d0.z; S.w += d0.w;
+        ACC4(g[0], ga0.x, d0); ACC4(g[1], ga0.y, d0); ACC4(g[2], ga0.z, d0); ACC4(g[3], ga0.w, d0);
+        ACC4(g[4], gc0.x, d0); ACC4(g[5], gc0.y, d0); ACC4(g[6], gc0.z, d0);
+        if (two) {
+          S.x += d1.x; S.y += d1.y; S.z += d1.z; S.w += d1.w;
+          ACC4(g[0], ga1.x, d1); ACC4(g[1], ga1.y, d1); ACC4(g[2], ga1.z, d1); ACC4(g[3], ga1.w, d1);
+          ACC4(g[4], gc1.x, d1); ACC4(g[5], gc1.y, d1); ACC4(g[6], gc1.z, d1);
+        }
+      }
+      while (mr) {
+        const int j0 = __builtin_ctzll(mr); mr &= mr - 1;
+        const bool two = mr != 0ull;
+        const int j1 = two ? __builtin_ctzll(mr) : j0; mr &= mr - 1;
+        const int r0 = __builtin_amdgcn_readlane(tt, j0), r1 = __builtin_amdgcn_readlane(tt, j1);
+        const float4 t0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r0 * D_H + 4 * lane);
+        const float4 t1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r1 * D_H + 4 * lane);
+        T.x += t0.x; T.y += t0.y; T.z += t0.z; T.w += t0.w;
+        if (two) { T.x += t1.x; T.y += t1.y; T.z += t1.z; T.w += t1.w; }
+      }
     }
+#undef W1_BIT
+#undef ACC4
     gb.x += S.x; gb.y += S.y; gb.z += S.z; gb.w += S.w;                 // bias: sum of d_h1 over all edges
     *reinterpret_cast<float4*>(a.w1_s + (size_t)node * D_H + 4 * lane) = S;
     *reinterpret_cast<float4*>(a.w1_t + (size_t)node * D_H + 4 * lane) = T;
@@ -1333,7 +1455,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
-  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_h1[1] || !buf->blk_parg[1] || !buf->emask) return GNET_ERR_INVALID;   // plan(training=1)
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_h1[1] || !buf->blk_parg[1] || !buf->emask || !buf->pw_rows) return GNET_ERR_INVALID;   // plan(training=1)
   hipStream_t s = (hipStream_t)stream;
   const ParamLayout L = make_layout(cfg);
   const int B = cfg->num_blocks;
@@ -1359,6 +1481,12 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   static const bool g_force_dense = getenv("GNET_DENSE_BWD") && atoi(getenv("GNET_DENSE_BWD")) != 0;
   // the edge stages accumulate into d_pw (the sparse one touches winner rows only)
   if (E > 0) HIP_CHECK_RET(hipMemsetAsync(buf->d_pw, 0, (size_t)E * D_E * sizeof(float), s));
+  // winner bitmaps behind the per-edge masks: ewin (this block), eany (OR over the blocks)
+  const size_t n_words = ((size_t)E + 63) / 64;
+  const size_t bm_stride = (n_words + 256 + 63) & ~(size_t)63;            // whole 256-word scan chunks
+  unsigned long long* ewin = (unsigned long long*)buf->emask + (((size_t)E + 64 + 63) & ~(size_t)63);
+  unsigned long long* eany = ewin + bm_stride;
+  if (E > 0) HIP_CHECK_RET(hipMemsetAsync(eany, g_force_dense ? 0xff : 0, bm_stride * sizeof(unsigned long long), s));
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
@@ -1398,13 +1526,13 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       EdgeBwdSparseArgs e;
       e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (const unsigned long long*)buf->emask;
       e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b]; e.d_pc = buf->d_pc;
-      e.ewin = (unsigned long long*)buf->emask + (((size_t)E + 64 + 63) & ~(size_t)63);   // tail of the emask buffer
+      e.ewin = ewin; e.eany = eany;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2;
       e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
       e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
       GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_sparse<<<g_edge, 256, kEdgeBwdSparseSmem, s>>>(e));
       GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sparse<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t,
-                                                                                 (const unsigned long long*)e.ewin, N, buf->d_rc, buf->d_rn));
+                                                                                 (const unsigned long long*)ewin, N, buf->d_rc, buf->d_rn));
     } else if (E > 0) {
       // ---- dense edge stage (every edge row; GNET_DENSE_BWD=1)
       EdgeBwdArgs e;
@@ -1432,7 +1560,16 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     }
   }
   if (E > 0) {
+    // rows of the pw-MLP backward = edges with a non-zero d_pw row
+    int* rl_count = buf->scratch_i;                     // [n_wg], then offsets [n_wg + 1] (total last)
+    const int n_wg = (int)((n_words + 255) / 256);
+    int* rl_off = rl_count + n_wg;
+    if (2 * n_wg + 1 > N + 1024) return GNET_ERR_WORKSPACE;
+    rowlist_count<<<n_wg, 256, 0, s>>>(eany, (int)n_words, E, rl_count);
+    rowlist_scan<<<1, 1024, 0, s>>>(rl_count, n_wg, rl_off);
+    rowlist_fill<<<n_wg, 256, 0, s>>>(eany, (int)n_words, E, rl_off, buf->pw_rows);
     PwBwdArgs p;
+    p.rows = buf->pw_rows; p.n_rows = rl_off + n_wg;
     p.n_edge = E; p.pw = buf->pw_feats; p.d_pw = buf->d_pw; p.h1 = buf->pw_h1; p.h2 = buf->pw_h2;
     p.w2 = params + L.pw2; p.w3 = params + L.pw3; p.d_h1 = buf->d_h1;
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
@@ -1440,7 +1577,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     PwW1Args w;
     w.n_det = N; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;
     w.row_ptr = buf->row_ptr; w.edge_t = buf->edge_t; w.geo = buf->geo; w.d_h1 = buf->d_h1;
-    w.scores = in->det_scores; w.classes = in->det_classes;
+    w.scores = in->det_scores; w.classes = in->det_classes; w.eany = eany;
     w.w1_s = buf->w1_s; w.w1_t = buf->w1_t;
     w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1; w.nchunks = g_w1c;
     GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_w1_nodesums<<<g_w1, 256, 0, s>>>(w));
