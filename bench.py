@@ -236,7 +236,8 @@ def main():
                        "num_blocks": args.blocks, "edges_per_step_all_gpus": e_total,
                        "edges_per_det": round(e_total / dets_per_step, 2), "parallelism": "dp%d" % world, "lanes_per_gpu": args.lanes,
                        "step": "graph build + fwd + matching/loss + bwd" + (" + RCCL all-reduce" if world > 1 else "")},
-            "whole_step": {"nominal_tflops": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * world * args.steps / elapsed / 1e12, 3),
+            "whole_step": {"note": "nominal = FLOPs of the reference's dense algorithm (SURVEY 8d); the sparse SegmentMax backward executes fewer",
+                           "nominal_tflops": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * world * args.steps / elapsed / 1e12, 3),
                            "frac_fp32_mfma_peak": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * args.steps / elapsed / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roofline,
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(table.items(), key=lambda kv: -kv[1])},

@@ -1,5 +1,5 @@
 import csv, collections, sys
-names=["edge_bwd","edge_fwd","pw_bwd_main","pw_bwd_w1","pw_fwd","gather_sums","blk_bwd_pre","blk_bwd_post","node_fwd","reduce_partials","graph_sweep","head_bwd"]
+names=["edge_bwd","edge_fwd","pw_bwd_main","pw_w1_nodesums","pw_w1_classrows","pw_fwd","gather_sparse","gather_sums","winners_mark","blk_bwd_pre","blk_bwd_post","node_fwd","reduce_partials","graph_sweep","head_bwd","match_greedy"]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter(); dur=collections.defaultdict(float); seen=set()
 for row in csv.DictReader(open(sys.argv[1])):
     k = next((x for x in names if x in row["Kernel_Name"]), None)
