@@ -385,7 +385,6 @@ __global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
 // ------------------------------------------------------------------------------------------
 struct EdgeBwdArgs {
   int n_edge; int n_det;
-  int accumulate_dpw;               // 0 for the first block processed (writes), 1 afterwards (adds)
   const int* edge_c;
   const float* pw;                  // [E,32] pairwise features P
   const float* h1;                  // [E+64,64] relu(pw_fc1) stored by the forward pass
@@ -410,7 +409,6 @@ struct EdgeBwdArgs {
 // 70.6 KB of LDS -> 2 independent workgroups per CU.
 constexpr int EB_T = 64;
 
-template <bool ACC>     // ACC: d_pw += (every block but the first one processed)
 __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sWpT = smem;                     // [64][36]  Wp^T  (layer 1; also the B operand of d P)
@@ -575,7 +573,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd(const EdgeBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + 256 * i;
-      dold[i] = ACC ? ((FULL || idx < tvalid) ? dpw_tile[idx] : 0.f) : 0.f;
+      dold[i] = (FULL || idx < tvalid) ? dpw_tile[idx] : 0.f;     // d_pw is zeroed once per step: always +=
     }
     {
       // g1 goes to HBM: gather_sums turns it into the centre / neighbour sums in a fixed order.
@@ -1489,8 +1487,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   if (E > 0) HIP_CHECK_RET(hipMemsetAsync(eany, g_force_dense ? 0xff : 0, bm_stride * sizeof(unsigned long long), s));
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSparseSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
     attr_set = true;
@@ -1536,13 +1533,13 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     } else if (E > 0) {
       // ---- dense edge stage (every edge row; GNET_DENSE_BWD=1)
       EdgeBwdArgs e;
-      e.n_edge = E; e.n_det = N; e.accumulate_dpw = 1;
+      e.n_edge = E; e.n_det = N;
       e.edge_c = buf->edge_c; e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b];
       e.pm = (const unsigned long long*)buf->blk_pm[b]; e.d_pc = buf->d_pc;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2; e.b2 = params + K.b2; e.w1 = params + K.w1; e.w2 = params + K.w2;
       e.d_pw = buf->d_pw; e.d_g1 = buf->d_g1;
       e.arena = buf->arena; e.stride = stride; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
-      GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<true><<<g_edge, 256, kEdgeBwdSmem, s>>>(e));
+      GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd<<<g_edge, 256, kEdgeBwdSmem, s>>>(e));
       GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_sums<<<(N + 3) / 4, 256, 0, s>>>(buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t,
                                                                                 N, buf->d_rc, buf->d_rn));
     } else {

@@ -1,3 +1,13 @@
+"""Per-phase s_memtime stamps of one workgroup of a tile-loop kernel (how the DESIGN.md 4 phase tables were made).
+
+The kernels in the tree carry no instrumentation.  To time the phases of a kernel, temporarily
+  * add `long long* dbg` to its argument struct, set from the environment variable GNET_DBG_PTR at the launch site
+    (`strtoull(getenv("GNET_DBG_PTR"), 0, 10)`),
+  * define `#define STAMP(k) do { if (a.dbg && blockIdx.x == 8 && tid == 0 && it < 40) a.dbg[it * 16 + (k)] = clock64(); } while (0)`
+    and put STAMP(0..K-1) at the phase boundaries of the tile loop (`it` = tile counter of the workgroup),
+  * rebuild and run  NSTAMP=K python tools/phase_stamps.py  on the GPU.
+clock64() is s_memtime = core clock cycles (calibrated against a pure-MFMA loop in tools/mfma_valu_overlap.hip).
+"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dbg = torch.zeros(40 * 16, dtype=torch.int64, device="cuda")
