@@ -78,12 +78,16 @@ __global__ void __launch_bounds__(256) match_cand(const float* __restrict__ iou,
   k1[d] = b1; k2[d] = b2; ncand[d] = nc; cfirst[d] = cf;
 }
 
+// order[lo + rank] = d with rank = number of detections of the image that sort before d (score descending,
+// ties by index descending -- the stable argsort of det_matching.cc:95-100 read backwards).  Four adjacent lanes
+// share a detection and take interleaved columns of the LDS score tile; 64 detections per workgroup.
 __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ score, const int* __restrict__ det_off,
                                                   int n_det, int n_img, int* __restrict__ order) {
   __shared__ float ss[1024];
-  const int d = blockIdx.x * 256 + threadIdx.x;
+  const int q = threadIdx.x & 3;
+  const int d = blockIdx.x * 64 + (threadIdx.x >> 2);
   const int dd = min(d, n_det - 1);
-  const int b0 = blockIdx.x * 256, b1 = min(n_det, b0 + 256) - 1;
+  const int b0 = blockIdx.x * 64, b1 = min(n_det, b0 + 64) - 1;
   const int cmin = det_off[image_of(det_off, n_img, b0)];
   const int cmax = det_off[image_of(det_off, n_img, b1) + 1];
   const int img = image_of(det_off, n_img, dd);
@@ -96,12 +100,14 @@ __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ scor
     for (int i = threadIdx.x; i < tn; i += 256) ss[i] = score[c0 + i];
     __syncthreads();
     const int jlo = max(lo, c0), jhi = min(hi, c0 + tn);
-    for (int j = jlo; j < jhi; ++j) {
+    for (int j = jlo + q; j < jhi; j += 4) {
       const float t = ss[j - c0];
       rank += (t > s || (t == s && j > dd)) ? 1 : 0;
     }
   }
-  if (d < n_det) order[lo + rank] = d;
+  rank += __shfl_xor(rank, 1);
+  rank += __shfl_xor(rank, 2);
+  if (q == 0 && d < n_det) order[lo + rank] = d;
 }
 
 // One wave per image.  matched GT flags live in a per-lane bitmask: GT g -> lane g & 63, bit g >> 6
@@ -119,29 +125,40 @@ __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou
   const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
   const float* ibase = iou + anno_off[img];
   unsigned matched = 0;   // bit b of lane l: GT (b*64 + l) is taken
+  // the records of the next 64 detections (two dependent loads: order -> k1/k2/ncand/cfirst) are requested
+  // before the sequential loop over the current ones
+  int n_det_ = d0 + lane < d1 ? order[d0 + lane] : -1;
+  unsigned long long n_c1 = n_det_ >= 0 ? k1[n_det_] : 0ull, n_c2 = n_det_ >= 0 ? k2[n_det_] : 0ull;
+  int n_nc = n_det_ >= 0 ? ncand[n_det_] : 0, n_cf = n_det_ >= 0 ? cfirst[n_det_] : -1;
   for (int p0 = d0; p0 < d1; p0 += 64) {
     const int p = p0 + lane;
     const bool act = p < d1;
-    const int det = act ? order[p] : -1;
-    const unsigned long long c1 = act ? k1[det] : 0ull, c2 = act ? k2[det] : 0ull;
-    const int nc = act ? ncand[det] : 0;
-    const int cf = act ? cfirst[det] : -1;
+    const int det = n_det_;
+    const unsigned long long c1 = n_c1, c2 = n_c2;
+    const int nc = n_nc, cf = n_cf;
+    {
+      const int pn = p0 + 64 + lane;
+      n_det_ = pn < d1 ? order[pn] : -1;
+      n_c1 = n_det_ >= 0 ? k1[n_det_] : 0ull; n_c2 = n_det_ >= 0 ? k2[n_det_] : 0ull;
+      n_nc = n_det_ >= 0 ? ncand[n_det_] : 0; n_cf = n_det_ >= 0 ? cfirst[n_det_] : -1;
+    }
+    const unsigned c1lo = (unsigned)c1, c2lo = (unsigned)c2;
     int res = (act && nc == 0) ? cf : -1;     // no regular candidate: state-independent
     unsigned long long todo = __ballot(act && nc > 0);
     while (todo) {
-      const int l = __builtin_ctzll(todo);
+      const int l = __builtin_ctzll(todo);    // wave-uniform: broadcasts below are v_readlane, not LDS permutes
       todo &= todo - 1;
-      const int ga = (int)(unsigned)__shfl(c1, l);
-      const int nl = __shfl(nc, l);
+      const int ga = (int)__builtin_amdgcn_readlane(c1lo, l);
+      const int nl = __builtin_amdgcn_readlane(nc, l);
       int mt = -1;
-      if (!((__shfl(matched, ga & 63) >> (ga >> 6)) & 1u)) {
+      if (!((__builtin_amdgcn_readlane(matched, ga & 63) >> (ga >> 6)) & 1u)) {
         mt = ga;
       } else if (nl >= 2) {
-        const int gb = (int)(unsigned)__shfl(c2, l);
-        if (!((__shfl(matched, gb & 63) >> (gb >> 6)) & 1u)) mt = gb;
+        const int gb = (int)__builtin_amdgcn_readlane(c2lo, l);
+        if (!((__builtin_amdgcn_readlane(matched, gb & 63) >> (gb >> 6)) & 1u)) mt = gb;
         else if (nl > 2) {
           // rare: more than two candidates and the best two are taken -> scan the row
-          const int dl = __shfl(det, l);
+          const int dl = __builtin_amdgcn_readlane(det, l);
           const float* row = ibase + (long long)(dl - d0) * m;
           unsigned long long best = 0;
           for (int gbase = 0; gbase < m; gbase += 64) {
@@ -166,7 +183,7 @@ __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou
       if (mt >= 0) {
         if (lane == (mt & 63)) matched |= 1u << (mt >> 6);
       } else {
-        mt = __shfl(cf, l);    // fall through to the crowd GTs (det_matching.cc:134-148)
+        mt = __builtin_amdgcn_readlane(cf, l);    // fall through to the crowd GTs (det_matching.cc:134-148)
       }
       if (lane == l) res = mt;
     }
@@ -246,7 +263,7 @@ int run_matching(const float* iou, const long long* anno_off, const int* det_off
   const MatchWs w = carve_match(ws, n_det);
   const int grid = (n_det + 255) / 256;
   match_cand<<<grid, 256, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, n_det, n_img, w.k1, w.k2, w.ncand, w.cfirst);
-  match_rank<<<grid, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
+  match_rank<<<(n_det + 63) / 64, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
   match_greedy<<<n_img, 64, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
                                     labels, weights, assign);
   return launch_status();
