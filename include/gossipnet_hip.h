@@ -172,7 +172,12 @@ int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inp
 int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
               const float* class_weights, float grad_scale, gnet_buffers* buf, gnet_stream_t stream);
 
-/* ---- backward: d loss / d params -> grads[param_count] (overwritten). */
+/* ---- backward: d loss / d params -> grads[param_count] (overwritten).
+ * Reproducible: no float atomics, fixed summation order (per-workgroup partials, summed in index order).
+ * The gradient of the SegmentMax (network.py:383-386) reaches one edge per (detection, column); the edge
+ * stage and the pw-MLP backward therefore run on the edges that carry gradient only -- the same sums as the
+ * dense algorithm minus exact zeros.  Environment GNET_DENSE_BWD=1 (read once per process) selects the
+ * dense implementation of the edge stage instead. */
 int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                   const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream);
 
