@@ -848,21 +848,21 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     const int e1_ = sLe[((tb) + (hrow0 + 16 < (nt_) ? hrow0 + 16 : 0)) & RM];                           \
     const int e2_ = sLe[((tb) + (hrow0 + 32 < (nt_) ? hrow0 + 32 : 0)) & RM];                           \
     const int e3_ = sLe[((tb) + (hrow0 + 48 < (nt_) ? hrow0 + 48 : 0)) & RM];                           \
-    rh0 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e0_ * D_P + 4 * hc4);                         \
-    rh1 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e1_ * D_P + 4 * hc4);                         \
-    rh2 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e2_ * D_P + 4 * hc4);                         \
-    rh3 = *reinterpret_cast<const float4*>(a.h1 + (size_t)e3_ * D_P + 4 * hc4);                         \
+    rh0 = ldg4_b(a.h1, (unsigned)e0_ * (D_P * 4u) + 16u * hc4);                                         \
+    rh1 = ldg4_b(a.h1, (unsigned)e1_ * (D_P * 4u) + 16u * hc4);                                         \
+    rh2 = ldg4_b(a.h1, (unsigned)e2_ * (D_P * 4u) + 16u * hc4);                                         \
+    rh3 = ldg4_b(a.h1, (unsigned)e3_ * (D_P * 4u) + 16u * hc4);                                         \
     const int q0_ = sLe[((tb) + (prow0 < (nt_) ? prow0 : 0)) & RM];                                     \
     const int q1_ = sLe[((tb) + (prow0 + 32 < (nt_) ? prow0 + 32 : 0)) & RM];                           \
-    rp0 = *reinterpret_cast<const float4*>(a.pw + (size_t)q0_ * D_E + 4 * pc4);                         \
-    rp1 = *reinterpret_cast<const float4*>(a.pw + (size_t)q1_ * D_E + 4 * pc4);                         \
-    ro0 = *reinterpret_cast<const float4*>(a.d_pw + (size_t)q0_ * D_E + 4 * pc4);                       \
-    ro1 = *reinterpret_cast<const float4*>(a.d_pw + (size_t)q1_ * D_E + 4 * pc4);                       \
+    rp0 = ldg4_b(a.pw, (unsigned)q0_ * (D_E * 4u) + 16u * pc4);                                         \
+    rp1 = ldg4_b(a.pw, (unsigned)q1_ * (D_E * 4u) + 16u * pc4);                                         \
+    ro0 = ldg4_b(a.d_pw, (unsigned)q0_ * (D_E * 4u) + 16u * pc4);                                       \
+    ro1 = ldg4_b(a.d_pw, (unsigned)q1_ * (D_E * 4u) + 16u * pc4);                                       \
     const int li_ = ((tb) + (drow < (nt_) ? drow : 0)) & RM;                                            \
     rbits = drow < (nt_) ? (unsigned)(sLm[li_] >> (16 * dq)) & 0xffffu : 0u;                            \
-    const float* dp_ = a.d_pc + (size_t)sLc[li_] * D_P + 16 * dq;                                       \
-    rd0 = *reinterpret_cast<const float4*>(dp_); rd1 = *reinterpret_cast<const float4*>(dp_ + 4);       \
-    rd2 = *reinterpret_cast<const float4*>(dp_ + 8); rd3 = *reinterpret_cast<const float4*>(dp_ + 12);  \
+    const unsigned do_ = (unsigned)sLc[li_] * (D_P * 4u) + 64u * dq;                                    \
+    rd0 = ldg4_b(a.d_pc, do_); rd1 = ldg4_b(a.d_pc, do_ + 16u);                                         \
+    rd2 = ldg4_b(a.d_pc, do_ + 32u); rd3 = ldg4_b(a.d_pc, do_ + 48u);                                   \
   } while (0)
 #define EBS_SEL4(v_, k_)                                                                                \
   make_float4((rbits >> (4 * (k_) + 0)) & 1u ? (v_).x : 0.f, (rbits >> (4 * (k_) + 1)) & 1u ? (v_).y : 0.f, \
@@ -1464,6 +1464,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     return GNET_OK;
   }
   if ((size_t)GNET_ARENA_PARTIALS * (size_t)L.total > buf->arena_floats) return GNET_ERR_WORKSPACE;
+  if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into the [E,64] fp32 arrays
   const float* pt = buf->packed_t;
   void* prof = buf->profiler;
   const long long stride = L.total;

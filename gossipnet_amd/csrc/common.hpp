@@ -153,6 +153,9 @@ __device__ __forceinline__ float ldg_b(const float* __restrict__ base, unsigned 
 __device__ __forceinline__ unsigned ldg_b(const unsigned* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+__device__ __forceinline__ float4 ldg4_b(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 __device__ __forceinline__ void stg_b(float* __restrict__ base, unsigned byte_off, float v) {
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
