@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
       const int hi = hleft ? __builtin_ctz(hleft) : nrows;
       const int cseg = __builtin_amdgcn_readlane(my_c, lo);
       float s0, s1; unsigned q0 = 0, q1 = 0;
-      int a0 = 0x7fffffff, a1 = 0x7fffffff;
+      int a0 = 16, a1 = 16;                             // accumulator slot of the first row attaining the maximum
       if (whole) {
         s0 = h2a[0]; s1 = h2b[0];
 #pragma unroll
@@ -501,13 +501,10 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         s0 = fmaxf(s0, __shfl_xor(s0, 32));
         s1 = fmaxf(s1, __shfl_xor(s1, 32));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { q0 += h2a[r] == s0 ? 1u : 0u; q1 += h2b[r] == s1 ? 1u : 0u; }
-        if (TRAIN) {
-#pragma unroll
-          for (int r = 15; r >= 0; --r) {              // rows ascend with r: the last hit is the first row
-            a0 = h2a[r] == s0 ? e0 + crow(r, half) : a0;
-            a1 = h2b[r] == s1 ? e0 + crow(r, half) : a1;
-          }
+        for (int r = 15; r >= 0; --r) {                // one compare feeds the tie count and the arg-max slot
+          const bool h0 = h2a[r] == s0, h1_ = h2b[r] == s1;
+          q0 += h0 ? 1u : 0u; q1 += h1_ ? 1u : 0u;
+          if (TRAIN) { a0 = h0 ? r : a0; a1 = h1_ ? r : a1; }   // rows ascend with r: the last hit is the first row
         }
       } else {
         // rows [lo, hi) of the tile; this lane's row crow(r, half) is bit crow(r, 0) of `mine`
@@ -524,21 +521,17 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         s0 = fmaxf(s0, __shfl_xor(s0, 32));
         s1 = fmaxf(s1, __shfl_xor(s1, 32));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 15; r >= 0; --r) {
           const bool in = (mine >> crow(r, 0)) & 1u;
-          q0 += (in && h2a[r] == s0) ? 1u : 0u;
-          q1 += (in && h2b[r] == s1) ? 1u : 0u;
-        }
-        if (TRAIN) {
-#pragma unroll
-          for (int r = 15; r >= 0; --r) {
-            const bool in = (mine >> crow(r, 0)) & 1u;
-            a0 = (in && h2a[r] == s0) ? e0 + crow(r, half) : a0;
-            a1 = (in && h2b[r] == s1) ? e0 + crow(r, half) : a1;
-          }
+          const bool h0 = in && h2a[r] == s0, h1_ = in && h2b[r] == s1;
+          q0 += h0 ? 1u : 0u; q1 += h1_ ? 1u : 0u;
+          if (TRAIN) { a0 = h0 ? r : a0; a1 = h1_ ? r : a1; }
         }
       }
       if (TRAIN) {
+        // accumulator slot r -> edge: row crow(r, half) of the tile; no hit in this half-wave: INT_MAX
+        a0 = a0 < 16 ? e0 + 8 * (a0 >> 2) + 4 * half + (a0 & 3) : 0x7fffffff;
+        a1 = a1 < 16 ? e0 + 8 * (a1 >> 2) + 4 * half + (a1 & 3) : 0x7fffffff;
         a0 = min(a0, __shfl_xor(a0, 32));
         a1 = min(a1, __shfl_xor(a1, 32));
       }
