@@ -153,6 +153,11 @@ __device__ __forceinline__ float ldg_b(const float* __restrict__ base, unsigned 
 __device__ __forceinline__ unsigned ldg_b(const unsigned* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// relu as a signed-integer max on the bit pattern: one VALU op.  fmaxf() of an MFMA result costs two (the
+// compiler canonicalises a possibly-signalling NaN first); negative floats are negative integers, -0 -> +0.
+__device__ __forceinline__ float relu_bits(float v) {
+  return __int_as_float(max(__float_as_int(v), 0));
+}
 __device__ __forceinline__ float4 ldg4_b(const float* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
 }

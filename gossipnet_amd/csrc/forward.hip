@@ -350,8 +350,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
   float rn0[16], rn1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const unsigned on = (unsigned)EF_NZ(r) * D_P + col;
-    rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
+    const unsigned on = (unsigned)EF_NZ(r) * (D_P * 4u) + 4u * col;
+    rn0[r] = ldg_b(a.rn, on); rn1[r] = ldg_b(a.rn, on + 128u);
   }
   // centre rows of the first two segments of the next tile (A = first centre, B = second or the same)
   int cA = __builtin_amdgcn_readfirstlane(nx_c), cB = cA, hiA = 32;
@@ -431,15 +431,15 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
       float* hp = sh + (4 * half) * E_LD2 + col;         // + crow(r, 0) * E_LD2: compile-time offsets
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        hp[crow(r, 0) * E_LD2] = fmaxf(h1a[r], 0.f);
-        hp[crow(r, 0) * E_LD2 + 32] = fmaxf(h1b[r], 0.f);
+        hp[crow(r, 0) * E_LD2] = relu_bits(h1a[r]);
+        hp[crow(r, 0) * E_LD2 + 32] = relu_bits(h1b[r]);
       }
     }
     wave_lds_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned on = (unsigned)EF_NZ(r) * D_P + col;
-      rn0[r] = a.rn[on]; rn1[r] = a.rn[on + 32];
+      const unsigned on = (unsigned)EF_NZ(r) * (D_P * 4u) + 4u * col;
+      rn0[r] = ldg_b(a.rn, on); rn1[r] = ldg_b(a.rn, on + 128u);
     }
     {
       cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;
