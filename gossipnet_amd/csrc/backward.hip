@@ -10,10 +10,14 @@
 //   head_bwd       predict/logits, fc2, fc1                       -> d_x (grad wrt block_feats[B])
 //   per block b = B..1:
 //     blk_bwd_post  shortcut ReLU, fc2, fc1                       -> d_x := dz, d_pc = dp / tie count
-//     edge_bwd      recompute h1,h2; pw_fc2, pw_fc1               -> d_pw (+=), d_g1
-//     gather_sums   centre segment sums / neighbour reversed-edge sums of d_g1 -> d_rc, d_rn
+//     edge stage, on the edges that attain a segment maximum only (default):
+//       winners_mark     arg-max record of the forward pass -> per-edge column masks (ties resolved)
+//       edge_bwd_sparse  pw_fc2, pw_fc1 on 64-row tiles of winners  -> d_pw (+=), d_g1 (winner rows)
+//       gather_sparse    centre / reversed-edge sums of those rows   -> d_rc, d_rn
+//     or on every edge (GNET_DENSE_BWD=1): edge_bwd (recomputes pw_fc2) + gather_sums
 //     blk_bwd_pre   per-node halves of pw_fc1, reduce_dim         -> d_x := dz + drpre . Wr^T
-//   pw_bwd_main    pw_feats fc3, fc2 (+ d_h1 = grad wrt fc1 pre-activation)
+//   rowlist_*      ascending list of the edges with a non-zero d_pw row (winners of any block)
+//   pw_bwd_main    pw_feats fc3, fc2 (+ d_h1 = grad wrt fc1 pre-activation), on the listed rows
 //   pw_w1_nodesums + pw_w1_classrows   pw_feats fc1 (score columns via per-detection sums, 7 geometry rows)
 //   reduce_partials  sums the per-workgroup partial weight gradients in a fixed order
 // Weight gradients are accumulated in MFMA accumulators across a workgroup's tiles and written once
