@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
 struct EdgeBwdSparseArgs {
   int n_edge; int n_det;
   const int* edge_c;
-  const unsigned long long* emask;
+  unsigned long long* emask;        // consumed: every non-zero mask is cleared again, the buffer stays all-zero between blocks
   unsigned long long* ewin;         // [E/64] out: bit e = edge e is a winner (for gather_sparse; by-product of the scan)
   unsigned long long* eany;         // [E/64] |= ewin over the blocks: edges that carry any gradient into the pw-MLP
   const float* pw; const float* h1; const float* d_pc;
@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     if (m_ != 0ull) {                                                                                   \
       const int idx_ = ((wbase) + base_ + __popcll(bm_ & ((1ull << lane) - 1ull))) & RM;                \
       sLe[idx_] = e_; sLm[idx_] = m_; sLc[idx_] = c_;                                                   \
+      a.emask[e_] = 0ull;                                                                               \
     }                                                                                                   \
     (wcnt) += total_;                                                                                   \
     __syncthreads();                                                                                    \
@@ -1490,6 +1491,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   unsigned long long* ewin = (unsigned long long*)buf->emask + (((size_t)E + 64 + 63) & ~(size_t)63);
   unsigned long long* eany = ewin + bm_stride;
   if (E > 0) HIP_CHECK_RET(hipMemsetAsync(eany, g_force_dense ? 0xff : 0, bm_stride * sizeof(unsigned long long), s));
+  if (E > 0 && !g_force_dense) HIP_CHECK_RET(hipMemsetAsync(buf->emask, 0, (size_t)E * sizeof(unsigned long long), s));
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
@@ -1518,15 +1520,15 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       GNET_LAUNCH(prof, GNET_K_BLK_POST, s, blk_bwd_post<<<g_node, 256, 0, s>>>(p));
     }
     if (E > 0 && !g_force_dense) {
-      // ---- sparse edge stage: winner rows only
-      HIP_CHECK_RET(hipMemsetAsync(buf->emask, 0, (size_t)E * sizeof(unsigned long long), s));
+      // ---- sparse edge stage: winner rows only (emask is zero here: cleared below once per call, and every
+      // block's edge_bwd_sparse clears the masks it consumes)
       WinArgs w;
       w.n_det = N; w.pm = (const unsigned long long*)buf->blk_pm[b]; w.parg = (const unsigned long long*)buf->blk_parg[b];
       w.emask = (unsigned long long*)buf->emask;
       w.row_ptr = buf->row_ptr; w.h1 = buf->blk_h1[b]; w.w2t = pt + K.w2; w.b2 = params + K.b2;
       GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<(N + 3) / 4, 256, 0, s>>>(w));
       EdgeBwdSparseArgs e;
-      e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (const unsigned long long*)buf->emask;
+      e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (unsigned long long*)buf->emask;
       e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b]; e.d_pc = buf->d_pc;
       e.ewin = ewin; e.eany = eany;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2;
