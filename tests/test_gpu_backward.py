@@ -207,3 +207,17 @@ def test_sparse_backward_equals_dense_backward(tmp_path):
     scale = np.abs(outs["1"]).max()
     assert scale > 0
     assert np.abs(outs["0"] - outs["1"]).max() <= 2e-6 * scale
+
+
+def test_gradients_bitwise_reproducible():
+    """No float atomics and a fixed summation order everywhere (static chunk assignment of the sparse edge
+    stage, per-workgroup partials summed in index order): repeated runs give bit-identical outputs."""
+    net, _ = make_pair(80, 4)
+    batch = [make_image(500, 80, seed=21), make_image(120, 80, seed=22)]
+    runs = []
+    for _ in range(3):
+        net.run(batch)
+        torch.cuda.synchronize()
+        runs.append((net.grads.clone(), net.prediction.clone(), net.image_losses.clone()))
+    for g, p, l in runs[1:]:
+        assert torch.equal(g, runs[0][0]) and torch.equal(p, runs[0][1]) and torch.equal(l, runs[0][2])
