@@ -600,6 +600,10 @@ struct NodeFwdArgs {
   const float* wrt; const float* br;   // next block reduce_dim transposed [32][128]
   const float* w1t; const float* b1;   // next block pw_fc1 transposed [64][96]
   float* r; float* rc; float* rn;
+  // segment-max records of the NEXT block: rows of detections whose edges are split between two waves of
+  // edge_fwd_w (combined atomically there) or that have no edge at all start from zero; every other row is
+  // written by a plain store.  edge_span = edges per wave range of edge_fwd_w.
+  unsigned long long* pm_next; unsigned long long* parg_next; const int* row_ptr; int edge_span;
   const float* hw1t; const float* hb1; const float* hw2t; const float* hb2; const float* hwl; const float* hbl;
   float* head1; float* head2; float* pred;
 };
@@ -655,6 +659,18 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     __syncthreads();
   }
   if (a.do_pre) {
+    if (a.pm_next) {
+      for (int i = tid; i < 32 * D_P; i += 256) {
+        const int node = row0 + (i >> 6);
+        if (node < a.n_det) {
+          const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
+          if (ee == eb || eb / a.edge_span != (ee - 1) / a.edge_span) {
+            a.pm_next[(size_t)node * D_P + (i & 63)] = 0ull;
+            if (a.parg_next) a.parg_next[(size_t)node * D_P + (i & 63)] = 0ull;
+          }
+        }
+      }
+    }
     // r = relu(x . Wr + br): K = 128 split over the 4 waves
     {
       f32x16 acc = zero16();
@@ -773,6 +789,11 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   }
 
   const int ntile_n = (N + 31) / 32;
+  // edge_fwd_w partition (workgroups per CU: default 2): wave-owned contiguous tile ranges
+  static const int wg_per_cu = getenv("GNET_EDGE_FWD_W") ? max(1, atoi(getenv("GNET_EDGE_FWD_W"))) : 2;
+  const int ef_wg = max(1, min(wg_per_cu * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+  const int ef_tiles = (E + 31) / 32, ef_waves = ef_wg * EFW_WAVES;
+  const int ef_span = max(1, (ef_tiles + ef_waves - 1) / ef_waves) * 32;       // edges per wave range
   for (int b = 0; b <= B; ++b) {
     // node stage between edge kernels: finish block b (b >= 1), start block b+1 (b < B)
     NodeFwdArgs n;
@@ -789,12 +810,14 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
       n.w1t = pt + L.blk[b + 1].w1; n.b1 = params + L.blk[b + 1].b1;
       n.r = buf->blk_r[b + 1]; n.rc = buf->blk_rc[b + 1]; n.rn = buf->blk_rn[b + 1];
     } else { n.wrt = n.br = n.w1t = n.b1 = nullptr; n.r = n.rc = n.rn = nullptr; }
+    n.pm_next = b < B ? (unsigned long long*)buf->blk_pm[b + 1] : nullptr;
+    n.parg_next = (b < B && training) ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
+    n.row_ptr = buf->row_ptr; n.edge_span = ef_span;
     n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
     n.hwl = params + L.hwl; n.hbl = params + L.hbl;
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
     GNET_LAUNCH(prof, GNET_K_NODE_FWD, s, node_fwd<<<ntile_n, 256, 0, s>>>(n));
     if (b < B) {
-      HIP_CHECK_RET(hipMemsetAsync(buf->blk_pm[b + 1], 0, (size_t)(training ? 2 * ((size_t)N + 32) : (size_t)N) * D_P * sizeof(unsigned long long), s));
       if (E > 0) {
         EdgeFwdArgs e;
         e.n_edge = E; e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
@@ -804,9 +827,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.edge_nz = buf->edge_nz;
         e.h1_out = training ? buf->blk_h1[b + 1] : nullptr;
         e.parg = training ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
-        // workgroups per CU (default 2): wave-owned tiles, contiguous tile ranges per wave
-        static const int wg_per_cu = getenv("GNET_EDGE_FWD_W") ? max(1, atoi(getenv("GNET_EDGE_FWD_W"))) : 2;
-        const int wg = max(1, min(wg_per_cu * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+        const int wg = ef_wg;
         static bool attr_w = false;
         if (!attr_w) {
           HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
