@@ -153,6 +153,22 @@ __device__ __forceinline__ float ldg_b(const float* __restrict__ base, unsigned 
 __device__ __forceinline__ unsigned ldg_b(const unsigned* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// Fold a value over the two half-waves (lanes l and l ^ 32) with v_permlane32_swap (gfx950): one VALU
+// instruction yields "lower half everywhere" and "upper half everywhere" -- no LDS round trip as with
+// __shfl_xor(x, 32) (ds_bpermute), which sat on the critical path of the per-segment reductions.
+__device__ __forceinline__ void half_bcast(unsigned x, unsigned& lo, unsigned& hi) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  lo = r[0]; hi = r[1];
+}
+__device__ __forceinline__ float half_fmax(float x) {
+  unsigned lo, hi; half_bcast(__float_as_uint(x), lo, hi);
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__uint_as_float(lo)), "v"(__uint_as_float(hi)));   // no canonicalising pre-ops
+  return r;
+}
+__device__ __forceinline__ unsigned half_add(unsigned x) { unsigned lo, hi; half_bcast(x, lo, hi); return lo + hi; }
+__device__ __forceinline__ int half_min(int x) { unsigned lo, hi; half_bcast((unsigned)x, lo, hi); return min((int)lo, (int)hi); }
+
 // relu as a signed-integer max on the bit pattern: one VALU op.  fmaxf() of an MFMA result costs two (the
 // compiler canonicalises a possibly-signalling NaN first); negative floats are negative integers, -0 -> +0.
 __device__ __forceinline__ float relu_bits(float v) {

@@ -498,8 +498,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         s0 = h2a[0]; s1 = h2b[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) { s0 = fmaxf(s0, h2a[r]); s1 = fmaxf(s1, h2b[r]); }
-        s0 = fmaxf(s0, __shfl_xor(s0, 32));
-        s1 = fmaxf(s1, __shfl_xor(s1, 32));
+        s0 = half_fmax(s0);
+        s1 = half_fmax(s1);
 #pragma unroll
         for (int r = 15; r >= 0; --r) {                // one compare feeds the tie count and the arg-max slot
           const bool h0 = h2a[r] == s0, h1_ = h2b[r] == s1;
@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
           s0 = fmaxf(s0, in ? h2a[r] : ninf);
           s1 = fmaxf(s1, in ? h2b[r] : ninf);
         }
-        s0 = fmaxf(s0, __shfl_xor(s0, 32));
-        s1 = fmaxf(s1, __shfl_xor(s1, 32));
+        s0 = half_fmax(s0);
+        s1 = half_fmax(s1);
 #pragma unroll
         for (int r = 15; r >= 0; --r) {
           const bool in = (mine >> crow(r, 0)) & 1u;
@@ -532,12 +532,12 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         // accumulator slot r -> edge: row crow(r, half) of the tile; no hit in this half-wave: INT_MAX
         a0 = a0 < 16 ? e0 + 8 * (a0 >> 2) + 4 * half + (a0 & 3) : 0x7fffffff;
         a1 = a1 < 16 ? e0 + 8 * (a1 >> 2) + 4 * half + (a1 & 3) : 0x7fffffff;
-        a0 = min(a0, __shfl_xor(a0, 32));
-        a1 = min(a1, __shfl_xor(a1, 32));
+        a0 = half_min(a0);
+        a1 = half_min(a1);
       }
       s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
-      q0 += __shfl_xor(q0, 32);
-      q1 += __shfl_xor(q1, 32);
+      q0 = half_add(q0);
+      q1 = half_add(q1);
       if (cseg == cur) {
         if (TRAIN) { g0 = s0 > m0 ? a0 : g0; g1 = s1 > m1 ? a1 : g1; }   // equal maxima keep the earlier edge
         segmax_merge(m0, k0, s0, q0);
