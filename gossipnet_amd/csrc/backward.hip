@@ -688,22 +688,29 @@ constexpr size_t kEdgeBwdSmem = (size_t)(D_P * LD32 + D_P * LD64 + 2 * EB_T * LD
 //                     rows gathered, dW2 / g1 / dWp / dP as in the dense kernel (96 MFMAs per wave and tile),
 //                     d_pw[e] += dP and d_g1[e] = g1 on winner rows only
 //   gather_sparse     d_rc / d_rn from the winner rows of d_g1
+// One launch for all blocks (blockIdx.y = block - 1): the masks depend on the forward pass only, so they are
+// off the backward pass's critical chain (16 dependent ~25 us launches otherwise).
 struct WinArgs {
   int n_det;
-  const unsigned long long* pm;     // [N,64] (max bits << 32) | tie count
-  const unsigned long long* parg;   // [N,64] (max bits << 32) | first edge attaining it
-  unsigned long long* emask;        // [E], zeroed
+  long long emask_stride;           // words between the blocks' mask arrays
+  unsigned long long* emask;        // [B][emask_stride], zeroed
+  const int* row_ptr;
+  const unsigned long long* pm[GNET_MAX_BLOCKS];     // [N,64] (max bits << 32) | tie count
+  const unsigned long long* parg[GNET_MAX_BLOCKS];   // [N,64] (max bits << 32) | first edge attaining it
   // tie resolution only (a positive maximum attained by 2+ edges; about one (detection, column) per block):
-  const int* row_ptr; const float* h1; const float* w2t; const float* b2;
+  const float* h1[GNET_MAX_BLOCKS]; const float* w2t[GNET_MAX_BLOCKS]; const float* b2[GNET_MAX_BLOCKS];
 };
 
 __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
   const int nwaves = gridDim.x * 4;
+  const int blk = blockIdx.y;
+  unsigned long long* emask = a.emask + (size_t)blk * a.emask_stride;
+  const float* h1p = a.h1[blk]; const float* w2tp = a.w2t[blk]; const float* b2p = a.b2[blk];
   for (int node = blockIdx.x * 4 + (threadIdx.x >> 6); node < a.n_det; node += nwaves) {
-    const unsigned long long pv = a.parg[(size_t)node * D_P + lane];
-    const unsigned long long pc = a.pm[(size_t)node * D_P + lane];
+    const unsigned long long pv = a.parg[blk][(size_t)node * D_P + lane];
+    const unsigned long long pc = a.pm[blk][(size_t)node * D_P + lane];
     const bool valid = (pv >> 32) != 0ull;                  // maximum > 0: the ReLU passes the gradient
     const int arg = (int)(unsigned)pv;
     const unsigned long long ties = __ballot(valid && (unsigned)pc > 1u);
@@ -717,8 +724,8 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
       todo &= ~m;
     }
     if (mine != 0ull) {                                     // one store instruction per detection
-      if (ties) atomicOr(a.emask + arg, mine);              // (the tie pass below ORs into the same words)
-      else a.emask[arg] = mine;                             // every edge belongs to exactly one detection
+      if (ties) atomicOr(emask + arg, mine);                // (the tie pass below ORs into the same words)
+      else emask[arg] = mine;                               // every edge belongs to exactly one detection
     }
     if (ties) {
       // Rare: some column's maximum is attained by several edges, and the forward pass kept only the first.
@@ -726,12 +733,12 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
       // fragments and k order of edge_fwd_w, so the bits match) and mark every edge that attains a tied
       // maximum; d_pc already carries the 1 / count split (network.py:383-386, TF SegmentMax gradient).
       const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
-      const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
+      const float bias0 = b2p[col], bias1 = b2p[32 + col];
       const float mx = __uint_as_float((unsigned)(pv >> 32));
       for (int e0 = eb; e0 < ee; e0 += 32) {
         const int nrows = min(32, ee - e0);
-        const float* ap = a.h1 + (size_t)min(e0 + col, ee - 1) * D_P + 4 * half;
-        const float* b0 = a.w2t + (size_t)col * D_P + 4 * half;
+        const float* ap = h1p + (size_t)min(e0 + col, ee - 1) * D_P + 4 * half;
+        const float* b0 = w2tp + (size_t)col * D_P + 4 * half;
         const float* b1 = b0 + 32 * D_P;
         f32x16 h2a = zero16(), h2b = zero16();
 #pragma unroll 4
@@ -757,7 +764,7 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float v = j < 32 ? h2a[r] + bias0 : h2b[r] + bias1;
-              if (crow(r, half) < nrows && v == mj) atomicOr(a.emask + e0 + crow(r, half), 1ull << j);
+              if (crow(r, half) < nrows && v == mj) atomicOr(emask + e0 + crow(r, half), 1ull << j);
             }
           }
         }
@@ -769,7 +776,7 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
 struct EdgeBwdSparseArgs {
   int n_edge; int n_det;
   const int* edge_c;
-  unsigned long long* emask;        // consumed: every non-zero mask is cleared again, the buffer stays all-zero between blocks
+  const unsigned long long* emask;
   unsigned long long* ewin;         // [E/64] out: bit e = edge e is a winner (for gather_sparse; by-product of the scan)
   unsigned long long* eany;         // [E/64] |= ewin over the blocks: edges that carry any gradient into the pw-MLP
   const float* pw; const float* h1; const float* d_pc;
@@ -839,7 +846,6 @@ __global__ void __launch_bounds__(256, 2) edge_bwd_sparse(const EdgeBwdSparseArg
     if (m_ != 0ull) {                                                                                   \
       const int idx_ = ((wbase) + base_ + __popcll(bm_ & ((1ull << lane) - 1ull))) & RM;                \
       sLe[idx_] = e_; sLm[idx_] = m_; sLc[idx_] = c_;                                                   \
-      a.emask[e_] = 0ull;                                                                               \
     }                                                                                                   \
     (wcnt) += total_;                                                                                   \
     __syncthreads();                                                                                    \
@@ -1488,10 +1494,21 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   // winner bitmaps behind the per-edge masks: ewin (this block), eany (OR over the blocks)
   const size_t n_words = ((size_t)E + 63) / 64;
   const size_t bm_stride = (n_words + 256 + 63) & ~(size_t)63;            // whole 256-word scan chunks
-  unsigned long long* ewin = (unsigned long long*)buf->emask + (((size_t)E + 64 + 63) & ~(size_t)63);
+  const size_t em_stride = ((size_t)E + 128 + 63) & ~(size_t)63;         // per-block mask arrays
+  unsigned long long* ewin = (unsigned long long*)buf->emask + (size_t)B * em_stride;
   unsigned long long* eany = ewin + bm_stride;
   if (E > 0) HIP_CHECK_RET(hipMemsetAsync(eany, g_force_dense ? 0xff : 0, bm_stride * sizeof(unsigned long long), s));
-  if (E > 0 && !g_force_dense) HIP_CHECK_RET(hipMemsetAsync(buf->emask, 0, (size_t)E * sizeof(unsigned long long), s));
+  if (E > 0 && !g_force_dense) {
+    // per-edge column masks of ALL blocks in one launch (they depend on the forward pass only)
+    HIP_CHECK_RET(hipMemsetAsync(buf->emask, 0, (size_t)B * em_stride * sizeof(unsigned long long), s));
+    WinArgs w;
+    w.n_det = N; w.emask_stride = (long long)em_stride; w.emask = (unsigned long long*)buf->emask; w.row_ptr = buf->row_ptr;
+    for (int b = 1; b <= B; ++b) {
+      w.pm[b - 1] = (const unsigned long long*)buf->blk_pm[b]; w.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
+      w.h1[b - 1] = buf->blk_h1[b]; w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
+    }
+    GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
+  }
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdSmem));
@@ -1520,15 +1537,9 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       GNET_LAUNCH(prof, GNET_K_BLK_POST, s, blk_bwd_post<<<g_node, 256, 0, s>>>(p));
     }
     if (E > 0 && !g_force_dense) {
-      // ---- sparse edge stage: winner rows only (emask is zero here: cleared below once per call, and every
-      // block's edge_bwd_sparse clears the masks it consumes)
-      WinArgs w;
-      w.n_det = N; w.pm = (const unsigned long long*)buf->blk_pm[b]; w.parg = (const unsigned long long*)buf->blk_parg[b];
-      w.emask = (unsigned long long*)buf->emask;
-      w.row_ptr = buf->row_ptr; w.h1 = buf->blk_h1[b]; w.w2t = pt + K.w2; w.b2 = params + K.b2;
-      GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<(N + 3) / 4, 256, 0, s>>>(w));
+      // ---- sparse edge stage: winner rows only (masks: winners_mark above)
       EdgeBwdSparseArgs e;
-      e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (unsigned long long*)buf->emask;
+      e.n_edge = E; e.n_det = N; e.edge_c = buf->edge_c; e.emask = (const unsigned long long*)buf->emask + (size_t)(b - 1) * em_stride;
       e.pw = buf->pw_feats; e.h1 = buf->blk_h1[b]; e.d_pc = buf->d_pc;
       e.ewin = ewin; e.eany = eany;
       e.w1t = pt + K.w1; e.w2t = pt + K.w2;

@@ -75,7 +75,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_pw = c.take<float>(Ep * D_E);
     b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
-    b.emask = c.take<uint64_t>(Ep + 128 + 2 * (Ep / 64 + 384));   // per-edge masks, then two 1-bit-per-edge maps (this block / any block)
+    b.emask = c.take<uint64_t>(B * (Ep + 128) + 2 * (Ep / 64 + 384));   // per-edge masks of every block, then two 1-bit-per-edge maps (this block / any block)
     b.pw_rows = c.take<int32_t>(Ep);
     b.w1_s = c.take<float>(Np * D_H);
     b.w1_t = c.take<float>(Np * D_H);

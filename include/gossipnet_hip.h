@@ -119,7 +119,7 @@ typedef struct gnet_buffers {
   float* d_pw;        /* [n_edge,32] grad wrt pw_feats */
   float* d_h1;        /* [n_edge,256] grad wrt pre-activation of pw_feats/fc1 */
   float* d_g1;        /* [n_edge,64]  grad wrt pre-activation of block pw_fc1 (per block, transient) */
-  uint64_t* emask;    /* [n_edge+64] per edge: columns of the block's segment max it attains (0 = no gradient flows through it); followed by two bitmaps */
+  uint64_t* emask;    /* [num_blocks][n_edge+128] per block and edge: columns of the block's segment max it attains (0 = no gradient flows through it); followed by two bitmaps */
   int32_t* pw_rows;   /* [n_edge+64] ascending indices of the edges with a non-zero d_pw row (rows of the pw-MLP backward) */
   float* w1_s;        /* [n_det,256] sum of d_h1 over the detection's own pairs (centre role)      */
   float* w1_t;        /* [n_det,256] sum of d_h1 over the reversed pairs (neighbour role)          */
