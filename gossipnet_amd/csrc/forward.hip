@@ -318,7 +318,11 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
   const int ntiles = (a.n_edge + 31) / 32;
   const int nwaves = gridDim.x * EFW_WAVES;
   const int per = (ntiles + nwaves - 1) / nwaves;
-  const int gw = blockIdx.x * EFW_WAVES + wave;
+  // XCD-aware range assignment: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
+  // own L2.  Giving XCD x the x-th contiguous eighth of the edge list keeps the rc / rn rows it gathers (one
+  // image's worth when the batch has 8 images) resident in that XCD's L2 instead of all images in every L2.
+  const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int gw = lb * EFW_WAVES + wave;
   const int t0 = gw * per, t1 = min(ntiles, t0 + per);
   float* sh = sHw + wave * (32 * E_LD2);
   if (t0 >= t1) return;
