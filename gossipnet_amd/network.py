@@ -196,6 +196,9 @@ class Gnet(object):
         self._row_ptr_tmp = None
         self._scratch_tmp = None
         self.grad_scale = 1.0
+        # tests / debugging: keep the per-block pw_fc1 activations [E,64] in HBM (Gnet.debug_view("blk_h1", ...));
+        # the default training path recomputes them for the rows the backward pass needs
+        self.keep_edge_activations = False
         self._profiler = None
         self._batch = batch
         if batch is not None:

@@ -195,10 +195,54 @@ class _SegmentMax(torch.autograd.Function):
         return torch.where(sel, weighted[ids], torch.zeros_like(x)), None, None
 
 
-def _fc(x, params, scope, relu, stats=None):
+class _PinnedRelu(torch.autograd.Function):
+    """relu whose BACKWARD uses a caller-supplied mask instead of (out > 0).  Test device: the loss is
+    piecewise smooth, and two fp32 implementations whose pre-activations differ by 1e-7 can sit on different
+    sides of a ReLU kink.  Feeding the masks of the implementation under test makes both sides differentiate
+    the SAME smooth piece (TF's ReluGrad is g * (out > 0); the mask is that predicate evaluated on the other
+    implementation's `out`)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask.to(g.dtype), None
+
+
+class _PinnedSegmentMaxRelu(torch.autograd.Function):
+    """relu + tf.segment_max (network.py:385-388) whose BACKWARD routes the gradient to the caller-supplied
+    winner set `sel` [E, F] (True where the edge attains a POSITIVE segment maximum; ties all True) with TF's
+    even split dx = sel ? (dout / segment_sum(sel))[ids] : 0.  Forward values are this oracle's own."""
+
+    @staticmethod
+    def forward(ctx, x, ids, n_seg, sel):
+        h = torch.relu(x)
+        out = torch.zeros(n_seg, x.shape[1], dtype=x.dtype)
+        idx = ids.view(-1, 1).expand_as(h)
+        out = out.scatter_reduce(0, idx, h, reduce="amax", include_self=False)
+        ctx.save_for_backward(ids, sel)
+        ctx.n_seg = n_seg
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, sel = ctx.saved_tensors
+        self_f = sel.to(g.dtype)
+        cnt = torch.zeros(ctx.n_seg, sel.shape[1], dtype=g.dtype).index_add_(0, ids, self_f)
+        weighted = g / torch.clamp(cnt, min=1.0)
+        return weighted[ids] * self_f, None, None, None
+
+
+def _fc(x, params, scope, relu, stats=None, pin=None):
     y = x @ params[scope + "/weights"] + params[scope + "/biases"]
     if relu and stats is not None and y.numel():
         stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float(y.detach().abs().min()))
+    if relu and pin is not None:
+        return _PinnedRelu.apply(y, pin)
     return torch.relu(y) if relu else y
 
 
@@ -280,9 +324,14 @@ class GnetOracle:
         self.class_weights = torch.tensor(np.asarray(class_weights), dtype=dtype)
         self.matching_fn = matching_fn or detection_matching_py
 
-    def forward(self, batch, with_loss=True, keep=False, stats=None):
+    def forward(self, batch, with_loss=True, keep=False, stats=None, pins=None):
         """stats (optional dict) collects the conditioning of the non-smooth points:
-        relu_margin = min |pre-activation| over every ReLU, max_gap = min top-2 gap of segment_max."""
+        relu_margin = min |pre-activation| over every ReLU, max_gap = min top-2 gap of segment_max.
+        pins (optional dict, tests only) fixes the smooth piece the BACKWARD pass differentiates -- the ReLU
+        masks and segment-max winner sets of another implementation's forward pass (bool arrays):
+          "pw": [3] masks of pw_feats/fc1..3;  "r"/"h1"/"sel"/"q"/"x": [num_blocks] masks of reduce_dim,
+          pw_fc1, the segment-max winners (of relu(pw_fc2)), fc1 and the block output.
+        Forward values are unaffected."""
         P = self.params
         npd = self.npdtype
         C = self.num_classes
@@ -302,8 +351,12 @@ class GnetOracle:
         n_idx = torch.from_numpy(pairs[:, 1].copy())
         f = torch.from_numpy(raw).to(self.dtype)          # stop_gradient (:454), multiplyer 1.0 (:199-200)
         # _pw_feats_fc network.py:324-342
+        pin = (lambda key, i: None) if pins is None else (lambda key, i: torch.as_tensor(np.asarray(pins[key][i])))
+        own = {"pw": [], "r": [], "h1": [], "sel": [], "q": [], "x": []}   # this forward's own smooth piece (keep=True)
+        note = (lambda key, t: own[key].append((t.detach() > 0).numpy())) if keep else (lambda key, t: None)
         for i in range(1, NUM_PWFEAT_FC + 1):
-            f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats)
+            f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats, pin("pw", i - 1))
+            note("pw", f)
         pw = f
         out["pw_feats"] = pw
         x = torch.zeros(N, SHORTCUT_DIM, dtype=self.dtype)   # network.py:241-246
@@ -311,22 +364,34 @@ class GnetOracle:
         is_id = (c_idx == n_idx).view(-1, 1)
         for b in range(1, self.num_blocks + 1):             # _block network.py:344-409
             s = "gnet/block%d/" % b
-            r = _fc(x, P, s + "reduce_dim", True, stats if b > 1 else None)
+            r = _fc(x, P, s + "reduce_dim", True, stats if b > 1 else None, pin("r", b - 1))
+            note("r", r)
             cf = r[c_idx]
             nf = torch.where(is_id, torch.zeros((), dtype=self.dtype), r[n_idx])
             h = torch.cat([pw, cf, nf], 1)
-            h = _fc(h, P, s + "pw_fc1", True, stats)
-            h = _fc(h, P, s + "pw_fc2", True, stats)
-            if stats is not None:
-                stats["max_gap"] = min(stats.get("max_gap", float("inf")), _segmax_gap(h, c_idx, N))
-            p = _SegmentMax.apply(h, c_idx, N)
-            q = _fc(p, P, s + "fc1", True, stats)
+            h = _fc(h, P, s + "pw_fc1", True, stats, pin("h1", b - 1))
+            note("h1", h)
+            if pins is None:
+                h = _fc(h, P, s + "pw_fc2", True, stats)
+                if stats is not None:
+                    stats["max_gap"] = min(stats.get("max_gap", float("inf")), _segmax_gap(h, c_idx, N))
+                p = _SegmentMax.apply(h, c_idx, N)
+                if keep:
+                    own["sel"].append(((h == p[c_idx]) & (h > 0)).detach().numpy())
+            else:
+                h = _fc(h, P, s + "pw_fc2", False)
+                p = _PinnedSegmentMaxRelu.apply(h, c_idx, N, pin("sel", b - 1))
+            q = _fc(p, P, s + "fc1", True, stats, pin("q", b - 1))
+            note("q", q)
             y = _fc(q, P, s + "fc2", False)
             if stats is not None and N:
                 stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float((x + y).detach().abs().min()))
-            x = torch.relu(x + y)
+            x = torch.relu(x + y) if pins is None else _PinnedRelu.apply(x + y, pin("x", b - 1))
+            note("x", x)
             block_feats.append(x)
         out["block_feats"] = block_feats
+        if keep and pins is None:
+            out["pins"] = own
         h = x                                                 # head network.py:258-273
         h = _fc(h, P, "gnet/predict/fc1/fully_connected", False)
         h = _fc(h, P, "gnet/predict/fc2/fully_connected", False)
@@ -355,10 +420,10 @@ class GnetOracle:
         out["loss"] = (out["loss_normed"] if self.normalize_loss else out["loss_unnormed"]) * self.loss_multiplyer
         return out
 
-    def forward_backward(self, batch, stats=None):
+    def forward_backward(self, batch, stats=None, pins=None, keep=False):
         for p in self.params.values():
             p.grad = None
-        out = self.forward(batch, stats=stats)
+        out = self.forward(batch, stats=stats, pins=pins, keep=keep)
         out["loss"].backward()
         grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()
                  for k, p in self.params.items()}

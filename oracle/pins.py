@@ -1,0 +1,50 @@
+"""TEST INFRASTRUCTURE (like everything under oracle/): helpers that compare the HIP backward pass with the
+oracle on the SAME smooth piece of the piecewise-smooth loss.  Imported by tests/ and __graft_entry__.smoke()."""
+import numpy as np
+import torch
+
+from . import gnet_oracle as go
+
+
+def grad_errors(net, gref, c, b):
+    """Per-tensor max |g_hip - g_ref| / max |g_ref| (TF variable name -> error)."""
+    g = net.grads.cpu().numpy()
+    off, errs = 0, {}
+    for name, shape in go.param_spec(c, b):
+        k = int(np.prod(shape))
+        gr = np.asarray(gref[name], np.float64).reshape(-1)
+        m = np.abs(gr).max() if k else 0.0
+        errs[name] = float(np.abs(g[off:off + k] - gr).max() / m) if m > 0 else float(np.abs(g[off:off + k]).max())
+        off += k
+    return errs
+
+
+def gpu_pins(net, image=None):
+    """The smooth piece the HIP backward differentiated: ReLU masks (out > 0 on the HIP forward's own
+    activations, TF ReluGrad) and the segment-max winner sets (per-edge column masks of winners_mark, ties
+    included) -- in the layout GnetOracle.forward(pins=...) takes.  The Gnet must have been run with
+    net.keep_edge_activations = True (block pw_fc1 activations kept in HBM).  image = index inside a
+    multi-image batch (rows / edges of that image only)."""
+    E, N, B = int(net.num_edges), int(net.num_dets), net.num_blocks
+    dv = net.debug_view
+    d0, d1, e0, e1 = 0, N, 0, E
+    if image is not None:
+        db = net._dbatch
+        d0, d1 = int(db.det_off_h[image]), int(db.det_off_h[image + 1])
+        rp = net.row_ptr.cpu().numpy()
+        e0, e1 = int(rp[d0]), int(rp[d1])
+    cpu = lambda t: t.cpu().numpy()
+    pins = {"pw": [cpu(dv("pw_h1", E * 256).view(E, 256)[e0:e1] > 0), cpu(dv("pw_h2", E * 256).view(E, 256)[e0:e1] > 0),
+                   cpu(net.pw_feats[e0:e1] > 0)],
+            "r": [], "h1": [], "sel": [], "q": [], "x": []}
+    em_stride = ((E + 128 + 63) // 64) * 64
+    emask = dv("emask", B * em_stride, dtype=torch.int64).view(B, em_stride)
+    shifts = torch.arange(64, device=emask.device, dtype=torch.int64).view(1, 64)
+    bf = net.block_feats
+    for b in range(1, B + 1):
+        pins["r"].append(cpu(dv("blk_r", N * 32, index=b).view(N, 32)[d0:d1] > 0))
+        pins["h1"].append(cpu(dv("blk_h1", E * 64, index=b).view(E, 64)[e0:e1] > 0))
+        pins["sel"].append(cpu(((emask[b - 1, e0:e1].view(-1, 1) >> shifts) & 1) != 0))
+        pins["q"].append(cpu(dv("blk_q", N * 64, index=b).view(N, 64)[d0:d1] > 0))
+        pins["x"].append(cpu(bf[b][d0:d1] > 0))
+    return pins

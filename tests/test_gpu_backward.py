@@ -2,30 +2,29 @@
 
 The loss is piecewise smooth (ReLU masks, segment-max arg-max): two fp32 implementations whose
 forward values differ by 1e-7 can sit on different sides of a kink, which changes single gradient
-entries by O(1).  So: (i) small, well-conditioned cases must agree to 2e-5 on at least 3 of 4 seeds
-(every seed to 5e-2); (ii) large cases are judged against the distance between the oracle and its own
-fp64 twin, which crosses the same kinks."""
+entries by O(1).  The acceptance test therefore PINS the smooth piece: the oracle's backward pass takes
+the ReLU masks and the segment-max winner sets of the HIP forward pass (tests/util.gpu_pins ->
+GnetOracle.forward(pins=...)), so that both sides differentiate the same piece, and then EVERY parameter
+tensor of EVERY seed must agree to 1e-5 of its max |gradient| (TF semantics: ReluGrad = g * (out > 0),
+_SegmentMinOrMaxGrad tie split; network.py:387-388).  The unpinned comparison is kept as a diagnostic:
+every one of its > 2e-5 outliers has to disappear under pinning."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import gnet_oracle as go
-from tests.util import make_pair, rel_err, make_image
+from tests.util import make_pair, rel_err, make_image, grad_errors, gpu_pins
 
 pytestmark = pytest.mark.gpu
 
-TIGHT, LOOSE = 2e-5, 5e-2
+TIGHT = 2e-5      # unpinned agreement that counts as "no kink was crossed"
+PINNED = 1e-5     # acceptance bar of the mask-pinned comparison, per parameter tensor
 
 
-def grad_errors(net, gref, c, b):
-    g = net.grads.cpu().numpy()
-    off, errs = 0, {}
-    for name, shape in go.param_spec(c, b):
-        k = int(np.prod(shape))
-        gr = np.asarray(gref[name], np.float64).reshape(-1)
-        errs[name] = float(np.abs(g[off:off + k] - gr).max() / max(np.abs(gr).max(), 1e-20)) if np.abs(gr).max() > 0 else float(np.abs(g[off:off + k]).max())
-        off += k
-    return errs
+def pinned_errors(net, orc, batch, c, b, image=None):
+    """Per-tensor gradient errors against the oracle differentiating the HIP forward's smooth piece."""
+    _, gpin = orc.forward_backward(batch, pins=gpu_pins(net, image))
+    return grad_errors(net, gpin, c, b)
 
 
 def check_outputs(net, ref):
@@ -38,15 +37,17 @@ def check_outputs(net, ref):
     assert abs(float(net.loss_normed) - float(ref["loss_normed"])) <= 1e-5 * max(1.0, abs(float(ref["loss_normed"])))
 
 
-@pytest.mark.parametrize("bias,need", [(0.01, 3), (0.5, 5)])
+@pytest.mark.parametrize("bias", [0.01, 0.5])
 @pytest.mark.parametrize("n,c,b", [(6, 1, 1), (20, 1, 1), (33, 1, 2), (64, 1, 2), (64, 80, 1), (64, 80, 2), (200, 1, 1),
                                    (150, 80, 3)])
-def test_backward_parity_small(n, c, b, bias, need):
-    """bias 0.01 = the experiments' init (kinks at ReLU pre-activations near 0 do occur: at least half of
-    the seeds must be tight); bias 0.5 keeps most units active (fewer kinks: 5 of 6 tight)."""
+def test_backward_parity_small(n, c, b, bias):
+    """bias 0.01 = the experiments' init (ReLU pre-activations near 0 do occur); bias 0.5 keeps most units
+    active.  Every seed, every parameter tensor: <= 1e-5 against the oracle on the same smooth piece; the
+    unpinned comparison may only differ where a kink was crossed (its outliers vanish under pinning)."""
     cw = np.linspace(0.5, 1.5, c + 1).astype(np.float32)
     net, orc = make_pair(c, b, class_weights=cw, bias=bias)
-    worst = []
+    net.keep_edge_activations = True
+    n_tight = 0
     for seed in range(6):
         batch = make_image(n, c, seed=seed)
         ref, gref = orc.forward_backward(batch)
@@ -54,24 +55,83 @@ def test_backward_parity_small(n, c, b, bias, need):
         torch.cuda.synchronize()
         check_outputs(net, ref)
         assert not np.isnan(net.grads.cpu().numpy()).any()
-        worst.append(max(grad_errors(net, gref, c, b).values()))
-    assert max(worst) < LOOSE, worst
-    assert sum(w < TIGHT for w in worst) >= need, worst
+        unpinned = grad_errors(net, gref, c, b)
+        pinned = pinned_errors(net, orc, batch, c, b)
+        assert max(pinned.values()) <= PINNED, (seed, max(pinned.items(), key=lambda kv: kv[1]))
+        outliers = [k for k, v in unpinned.items() if v > TIGHT]
+        assert all(pinned[k] <= PINNED for k in outliers)
+        n_tight += not outliers
+    assert n_tight >= 1      # kink crossings are the exception, not the rule
 
 
-@pytest.mark.parametrize("n,c,b,seed", [(300, 80, 16, 0), (1000, 1, 16, 0)])
-def test_backward_parity_vs_fp64_yardstick(n, c, b, seed):
+@pytest.mark.parametrize("n,c,b,seed", [(300, 80, 16, 0), (300, 80, 16, 1), (1000, 1, 16, 0)])
+def test_backward_parity_pinned_16_blocks(n, c, b, seed):
     net, orc = make_pair(c, b)
+    net.keep_edge_activations = True
     batch = make_image(n, c, seed=seed)
-    ref, g32 = orc.forward_backward(batch)
-    o64 = go.GnetOracle(c, b, params={k: v.detach().numpy() for k, v in orc.params.items()}, dtype=torch.float64)
-    _, g64 = o64.forward_backward(batch)
+    ref = orc.forward(batch)
     net.run(batch)
     torch.cuda.synchronize()
     check_outputs(net, ref)
-    e_gpu = grad_errors(net, g32, c, b)
-    yard = max(float(np.abs(g32[k].astype(np.float64) - g64[k]).max() / max(np.abs(g64[k]).max(), 1e-20)) for k in g32)
-    assert max(e_gpu.values()) <= 20 * yard + TIGHT, (max(e_gpu.values()), yard)
+    pinned = pinned_errors(net, orc, batch, c, b)
+    assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
+
+
+def test_headline_config_single_image():
+    """BASELINE configs[2] at full size: N = 2000, 80 classes, 16 blocks, one image (the reference's step
+    shape, train.py:115).  Integer results bit-exact; fp32 tensors <= 1e-5; gradients <= 1e-5 on the pinned piece."""
+    n, c, b = 2000, 80, 16
+    net, orc = make_pair(c, b)
+    net.keep_edge_activations = True
+    batch = make_image(n, c, seed=0)
+    ref = orc.forward(batch, keep=True)
+    net.run(batch)
+    torch.cuda.synchronize()
+    pairs = net.neighbor_pair_idxs.cpu().numpy()
+    assert np.array_equal(pairs, ref["neighbor_pair_idxs"])
+    assert np.array_equal(net.edge_iou.cpu().numpy(), ref["det_det_iou"][pairs[:, 0], pairs[:, 1]])
+    check_outputs(net, ref)
+    assert rel_err(net.pw_feats.cpu().numpy(), ref["pw_feats"].detach().numpy()) < 1e-5
+    bf = net.block_feats
+    for k in range(1, b + 1):
+        assert rel_err(bf[k].cpu().numpy(), ref["block_feats"][k].detach().numpy()) < 1e-5, "block %d" % k
+    pinned = pinned_errors(net, orc, batch, c, b)
+    assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
+
+
+def test_headline_bench_batch_8_images():
+    """The batch bench.py times: 8 images x N = 2000, C = 80, B = 16 as one block-diagonal graph
+    (E ~ 1.44 M: the XCD-aware range mapping and the 32-bit byte offsets are live at this size).
+    Per image: edges / det_anno_iou / assignments bit-exact, activations and logits <= 1e-5; the batch
+    gradient <= 1e-5 against the sum of the per-image oracle gradients on the pinned piece."""
+    n, c, b, k_img = 2000, 80, 16, 8
+    net, orc = make_pair(c, b)
+    net.keep_edge_activations = True
+    imgs = [make_image(n, c, seed=i) for i in range(k_img)]
+    net.run(imgs)
+    torch.cuda.synchronize()
+    pairs_all = net.neighbor_pair_idxs.cpu().numpy()
+    rp = net.row_ptr.cpu().numpy()
+    pred = net.prediction.cpu().numpy(); assign = net.det_gt_matching.cpu().numpy(); labels = net.labels.cpu().numpy()
+    pw = net.pw_feats.cpu().numpy(); bf = [None] + [x.cpu().numpy() for x in net.block_feats[1:]]
+    anno = net.det_anno_iou
+    losses = net.image_losses[:, 0].cpu().numpy()
+    gsum = None
+    for i, im in enumerate(imgs):
+        d0, d1 = i * n, (i + 1) * n
+        e0, e1 = rp[d0], rp[d1]
+        out, g = orc.forward_backward(im, pins=gpu_pins(net, image=i))
+        assert np.array_equal(pairs_all[e0:e1] - d0, out["neighbor_pair_idxs"]), "image %d" % i
+        assert np.array_equal(anno[i].cpu().numpy(), out["det_anno_iou"])
+        assert np.array_equal(assign[d0:d1], out["det_gt_matching"]) and np.array_equal(labels[d0:d1], out["labels"])
+        assert rel_err(pw[e0:e1], out["pw_feats"].detach().numpy()) < 1e-5
+        for k in range(1, b + 1):
+            assert rel_err(bf[k][d0:d1], out["block_feats"][k].detach().numpy()) < 1e-5
+        assert rel_err(pred[d0:d1], out["prediction"].detach().numpy()) < 1e-5
+        assert abs(losses[i] - float(out["loss"])) <= 1e-5 * max(1.0, abs(float(out["loss"])))
+        gsum = g if gsum is None else {k_: gsum[k_] + g[k_] for k_ in g}
+    errs = grad_errors(net, gsum, c, b)
+    assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
 
 
 def test_normalize_loss_and_multiplier():
@@ -105,6 +165,7 @@ def test_batch_gradient_is_sum_of_image_gradients():
 def test_no_gt_image():
     """n_gt = 0: every detection is a negative with weight 1 (det_matching.cc, network.py:286-293)."""
     net, orc = make_pair(80, 1)
+    net.keep_edge_activations = True
     batch = make_image(30, 80, seed=0)
     batch["gt_boxes"] = np.zeros((0, 4), np.float32)
     batch["gt_crowd"] = np.zeros(0, bool)
@@ -114,7 +175,7 @@ def test_no_gt_image():
     torch.cuda.synchronize()
     assert net.det_gt_matching.cpu().tolist() == [-1] * 30
     assert abs(float(net.loss) - float(ref["loss"])) < 1e-4
-    assert max(grad_errors(net, gref, 80, 1).values()) < LOOSE
+    assert max(pinned_errors(net, orc, batch, 80, 1).values()) <= PINNED
 
 
 def test_weight_reg_gradient():
@@ -127,7 +188,8 @@ def test_weight_reg_gradient():
     net.run(batch)
     diff = (g1 - net.grads)
     expect = 0.0005 * net.params * net._reg_mask
-    # the neighbour scatter uses float atomics: two runs differ by rounding
+    # (gradients are bitwise reproducible, test_gradients_bitwise_reproducible: diff is the regulariser only,
+    #  up to the rounding of g + wd*w - g)
     assert float((diff - expect).abs().max()) < 2e-6 * float(net.grads.abs().max())
 
 
@@ -136,7 +198,7 @@ def test_exact_ties_from_duplicate_detections():
     ties and TF splits the gradient evenly among them.  Exercises the tie counting of the
     streaming (max, count) combine, including its deferred tie repair across waves."""
     net, orc = make_pair(80, 2, bias=0.5)
-    ok = 0
+    net.keep_edge_activations = True
     for seed in range(3):
         base = make_image(60, 80, seed=seed)
         rep = np.repeat(np.arange(60), 3)                       # every detection three times
@@ -151,10 +213,8 @@ def test_exact_ties_from_duplicate_detections():
         pm = net.debug_view("blk_pm", 180 * 64, dtype=torch.int64, index=1).cpu().numpy()
         assert (((pm & 0xffffffff) > 1) & ((pm >> 32) > 0)).any(), "test must contain positive ties"
         assert rel_err(net.prediction.cpu().numpy(), ref["prediction"].detach().numpy()) < 1e-5
-        worst = max(grad_errors(net, gref, 80, 2).values())
-        assert worst < LOOSE, worst
-        ok += worst < TIGHT
-    assert ok >= 2
+        pinned = pinned_errors(net, orc, batch, 80, 2)
+        assert max(pinned.values()) <= PINNED, (seed, max(pinned.items(), key=lambda kv: kv[1]))
 
 
 def test_batch_with_empty_image_and_image_without_gt():
@@ -162,6 +222,7 @@ def test_batch_with_empty_image_and_image_without_gt():
     block-diagonal batch; the reference feeds one image at a time and skips images without detections,
     train.py:141-142)."""
     net, orc = make_pair(80, 2)
+    net.keep_edge_activations = True
     empty = {"dets": np.zeros((0, 4), np.float32), "det_scores": np.zeros(0, np.float32),
              "det_classes": np.zeros(0, np.int32), "gt_boxes": np.zeros((0, 4), np.float32),
              "gt_crowd": np.zeros(0, bool), "gt_classes": np.zeros(0, np.int32)}
@@ -173,13 +234,13 @@ def test_batch_with_empty_image_and_image_without_gt():
     torch.cuda.synchronize()
     losses = net.image_losses[:, 0].cpu().numpy()
     assert losses[0] == 0.0
-    r1, g1 = orc.forward_backward(nogt)
-    r2, g2 = orc.forward_backward(normal)
+    r1, g1 = orc.forward_backward(nogt, pins=gpu_pins(net, image=1))
+    r2, g2 = orc.forward_backward(normal, pins=gpu_pins(net, image=2))
     assert abs(losses[1] - float(r1["loss"])) < 1e-4 and abs(losses[2] - float(r2["loss"])) < 1e-4
     assert np.array_equal(net.det_gt_matching.cpu().numpy()[:40], np.full(40, -1))
     assert np.array_equal(net.det_gt_matching.cpu().numpy()[40:], r2["det_gt_matching"])
     gsum = {k: g1[k] + g2[k] for k in g1}
-    assert max(grad_errors(net, gsum, 80, 2).values()) < LOOSE
+    assert max(grad_errors(net, gsum, 80, 2).values()) <= PINNED
     # a batch of only an empty image
     net.run([empty])
     assert float(net.grads.abs().max()) == 0.0 and net.num_edges == 0

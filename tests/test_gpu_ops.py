@@ -135,6 +135,23 @@ def test_graph_build_dense_10000():
     assert np.isfinite(net.prediction.cpu().numpy()).all()
 
 
+def test_config4_dense_10000_forward_16_blocks():
+    """BASELINE config 4 at full depth: N = 10000, C = 80, B = 16 (E ~ 3.4 M): edges bit-exact (previous test),
+    pw_feats, block_feats[16] and the logits <= 1e-5 against the oracle's forward pass."""
+    from tests.util import make_pair, make_image, rel_err
+    net, orc = make_pair(80, 16)
+    batch = make_image(10000, 80, seed=0)
+    infer = {k: batch[k] for k in ("dets", "det_scores", "det_classes")}
+    net.run(infer)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = orc.forward(batch, with_loss=False)
+    assert np.array_equal(net.neighbor_pair_idxs.cpu().numpy(), ref["neighbor_pair_idxs"])
+    assert rel_err(net.pw_feats.cpu().numpy(), ref["pw_feats"].numpy()) < 1e-5
+    assert rel_err(net.block_feats[16].cpu().numpy(), ref["block_feats"][16].numpy()) < 1e-5
+    assert rel_err(net.prediction.cpu().numpy(), ref["prediction"].numpy()) < 1e-5
+
+
 def test_config4_dense_10000_forward_backward_runs():
     """BASELINE config 4 end to end (N = 10000, E ~ 3.2 M): finite logits, loss and gradients; the gradient
     of the image equals the gradient of the same image inside a two-image batch (block-diagonal property)."""

@@ -24,3 +24,6 @@ def make_pair(num_classes, num_blocks, seed_params=42, class_weights=None, norma
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b))))) if a.size else 0.0
+
+
+from oracle.pins import grad_errors, gpu_pins  # noqa: E402,F401

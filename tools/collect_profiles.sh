@@ -12,7 +12,7 @@ cp $(find $R/kt -name "*kernel_stats.csv" | head -1) $R/kernel_stats.csv
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   set -- $pass; name=$1; shift
   rocprofv3 --pmc "$@" -d $R/pmc_$name -o pmc --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-kernel-timing > $R/pmc_$name.log 2>&1
-  python tools/scripts_pmc_sum.py $(find $R/pmc_$name -name "*counter_collection.csv" | head -1) > $R/pmc_$name.txt 2>&1
+  python tools/pmc_sum.py $(find $R/pmc_$name -name "*counter_collection.csv" | head -1) > $R/pmc_$name.txt 2>&1
 done
 rm -rf $R/kt $R/pmc_fetch $R/pmc_write $R/pmc_sq
 ls -la $R; cat $R/bench.json | cut -c1-300; cat $R/pmc_fetch.txt | head -8; cat $R/pmc_write.txt | head -8; cat $R/pmc_sq.txt | head -8

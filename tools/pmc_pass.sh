@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_pmc.sh <outdir> <counters...>   (run on the GPU box via gpurun)
+# usage: pmc_pass.sh <outdir> <counters...>   (run on the GPU box via gpurun)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=$1; shift
 mkdir -p gpurun_out/$out
