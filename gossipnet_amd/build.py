@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgossipnet_hip.so")
-SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "roi_pool.hip", "optim.hip", "plan.hip"]
+SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 
@@ -20,7 +20,8 @@ def _hipcc():
 
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "gossipnet_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "backward_edge.hpp"),
+                   os.path.join(HERE, "..", "include", "gossipnet_hip.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hdr_mtime = max(os.path.getmtime(d) for d in deps[len(srcs):])

@@ -1,0 +1,754 @@
+// Edge stage of the backward pass of a _block (network.py:367-388, TF autodiff): build_context gathers,
+// pw_fc1, pw_fc2 and the SegmentMax.
+//
+// The gradient of tf.segment_max reaches, per (detection, column), only the edge that attained the maximum
+// (ties: all of them, split evenly -- _SegmentMinOrMaxGrad).  d h2 is therefore 96 % zeros even on the
+// "winner" edges (64 non-zeros per detection spread over ~23 winner rows at E/N = 90), and every product with
+// it is done sparsely here instead of as a dense GEMM on zeros:
+//
+//   winners_mark    (all blocks, one launch) arg-max record of the forward pass -> 1-bit-per-edge winner map
+//                   + a per-detection "has a tied maximum" flag
+//   winners_ties    exact positive ties (rare: duplicate boxes, fp32 coincidences) are resolved by recomputing
+//                   the flagged detection's pw_fc1/pw_fc2 with the forward kernel's exact MFMA sequence ->
+//                   per-edge extra-winner masks
+//   winner_lists    bitmap -> ascending list of winner edges + per-word prefix counts (count / scan / fill,
+//                   all blocks in one launch each; the OR over the blocks gives the rows of the pw-MLP backward)
+//   winner_positions  list position of every (detection, column)'s arg-max edge
+//   edge_bwd_w      every wave owns whole 32-winner tiles, no workgroup barriers in the tile loop:
+//                     h1   = relu(P.Wp + rc[c] + rn[n])   recomputed (32 MFMAs) -- the forward pass keeps no
+//                            per-edge activations (16 x 0.37 GB of stores and 5.9 GB of workspace gone)
+//                     dW2 += d_pc[c][j] * h1[arg(c,j)]    per (detection, column), lane = column: 64 FMAs
+//                     g1   = (h1 > 0) * (d h2 . W2^T)     64 MFMAs, d h2 built in A-operand registers
+//                     dP   = g1 . Wp^T, dWp += P^T . g1   (32 + 32 MFMAs)
+//                   160 MFMAs per 32 rows instead of 224 for the dense-on-winner-rows formulation.
+//   gather_winners  d_rc / d_rn: centre sums (a contiguous range of the compact g1 rows) and reversed-pair sums
+// No float atomics, static work assignment: gradients stay bitwise reproducible.
+#include "common.hpp"
+#include "backward_edge.hpp"
+
+namespace {
+
+constexpr int LD32 = D_E + 4;    // 36
+constexpr int LD64 = D_P + 4;    // 68
+
+__device__ __forceinline__ unsigned long long low_mask(int bit) { return bit ? (~0ull >> (64 - bit)) : 0ull; }
+
+// position of edge e in the ascending winner list = number of winner edges before it
+__device__ __forceinline__ int winner_pos(const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix, int e) {
+  const int w = e >> 6;
+  return wprefix[w] + __popcll(ewin[w] & low_mask(e & 63));
+}
+
+// ------------------------------------------------------------------------------------------
+struct WinArgs {
+  int n_det;
+  long long bm_stride, xm_stride, tf_stride;
+  unsigned long long* ewin;         // [B][bm_stride] zeroed
+  unsigned long long* xmask;        // [B][xm_stride] extra winners of tied columns (valid on rows of flagged detections only)
+  unsigned char* tflag;             // [B][tf_stride] detection has a tied column in this block
+  const int* row_ptr; const int* edge_nz; const float* pw;
+  const unsigned long long* pm[GNET_MAX_BLOCKS];     // [N,64] (max bits << 32) | tie count
+  const unsigned long long* parg[GNET_MAX_BLOCKS];   // [N,64] (max bits << 32) | first edge attaining it
+  const float* rc[GNET_MAX_BLOCKS]; const float* rn[GNET_MAX_BLOCKS];
+  const float* w1t[GNET_MAX_BLOCKS]; const float* w2t[GNET_MAX_BLOCKS]; const float* b2[GNET_MAX_BLOCKS];
+};
+
+constexpr int WM_WORDS = 8;   // bitmap words a detection's edges may span on the fast path (<= 449 edges)
+
+__global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
+  __shared__ unsigned long long sbm[4][WM_WORDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  const int blk = blockIdx.y;
+  unsigned long long* ewin = a.ewin + (size_t)blk * a.bm_stride;
+  unsigned char* tflag = a.tflag + (size_t)blk * a.tf_stride;
+  if (lane < WM_WORDS) sbm[wave][lane] = 0ull;
+  wave_lds_sync();
+  for (int node = blockIdx.x * 4 + wave; node < a.n_det; node += nwaves) {
+    const unsigned long long pv = a.parg[blk][(size_t)node * D_P + lane];
+    const unsigned long long pc = a.pm[blk][(size_t)node * D_P + lane];
+    const bool valid = (pv >> 32) != 0ull;                  // maximum > 0: the ReLU passes the gradient
+    const int arg = (int)(unsigned)pv;
+    const unsigned long long ties = __ballot(valid && (unsigned)pc > 1u);
+    const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
+    const int w0 = eb >> 6;
+    const bool fits = ((ee - 1) >> 6) - w0 < WM_WORDS;      // wave-uniform
+    // winner bits: combined per bitmap word in LDS, one global atomic per word (words at the row boundaries are
+    // shared with the neighbouring detections)
+    if (valid) {
+      const unsigned long long bit = 1ull << (arg & 63);
+      if (fits) atomicOr(&sbm[wave][(arg >> 6) - w0], bit);
+      else atomicOr(ewin + (arg >> 6), bit);
+    }
+    wave_lds_sync();
+    if (fits && lane < WM_WORDS) {
+      const unsigned long long m = sbm[wave][lane];
+      if (m) { atomicOr(ewin + w0 + lane, m); sbm[wave][lane] = 0ull; }
+    }
+    wave_lds_sync();
+    if (lane == 0) tflag[node] = ties ? 1 : 0;
+  }
+}
+
+// Rare (about one detection per block: duplicate boxes, fp32 coincidences): some column's maximum is attained by
+// several edges, and the forward pass recorded only the first.  Recompute pw_fc1 / pw_fc2 for the flagged
+// detection's edges with the forward kernel's exact operation sequence (edge_fwd_w: accumulator initialised with
+// rc + rn, operand fragments and k order of its MFMAs, so the bits match) and mark every OTHER edge that attains
+// a tied maximum; d_pc already carries the 1 / count split (network.py:387-388, TF SegmentMax gradient).
+// A kernel of its own: its registers must not cost winners_mark its occupancy.
+__global__ void __launch_bounds__(256) winners_ties(const WinArgs a) {
+  __shared__ __attribute__((aligned(16))) float sh_all[4][32 * LD64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int nwaves = gridDim.x * 4;
+  const int blk = blockIdx.y;
+  unsigned long long* ewin = a.ewin + (size_t)blk * a.bm_stride;
+  unsigned long long* xmask = a.xmask + (size_t)blk * a.xm_stride;
+  const unsigned char* tflag = a.tflag + (size_t)blk * a.tf_stride;
+  float* sh = sh_all[wave];
+  for (int node0 = blockIdx.x * 4 + wave; node0 < a.n_det; node0 += nwaves) {
+    const int node = __builtin_amdgcn_readfirstlane(node0);
+    if (!tflag[node]) continue;
+    const unsigned long long pv = a.parg[blk][(size_t)node * D_P + lane];
+    const unsigned long long pc = a.pm[blk][(size_t)node * D_P + lane];
+    const bool valid = (pv >> 32) != 0ull;
+    const int arg = (int)(unsigned)pv;
+    const unsigned long long ties = __ballot(valid && (unsigned)pc > 1u);
+    const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
+    for (int e = eb + lane; e < ee; e += 64) xmask[e] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const float* rcp = a.rc[blk] + (size_t)node * D_P;
+    const float* rnp = a.rn[blk];
+    const float* w1tp = a.w1t[blk]; const float* w2tp = a.w2t[blk];
+    const float bias0 = a.b2[blk][col], bias1 = a.b2[blk][32 + col];
+    const float rc0 = rcp[col], rc1 = rcp[32 + col];
+    const float mx = __uint_as_float((unsigned)(pv >> 32));
+    for (int e0 = eb; e0 < ee; e0 += 32) {
+      const int nrows = min(32, ee - e0);
+      f32x16 h1a, h1b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nz = a.edge_nz[min(e0 + crow(r, half), ee - 1)];
+        h1a[r] = rc0 + rnp[(size_t)nz * D_P + col];
+        h1b[r] = rc1 + rnp[(size_t)nz * D_P + 32 + col];
+      }
+      {
+        const float* ap = a.pw + (size_t)min(e0 + col, ee - 1) * D_E + 4 * half;
+        const float* b0 = w1tp + (size_t)col * (D_E + 2 * D_R) + 4 * half;
+        const float* b1 = b0 + 32 * (D_E + 2 * D_R);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
+          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
+          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
+          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
+          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
+          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
+          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
+          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
+          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
+          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sh[crow(r, half) * LD64 + col] = relu_bits(h1a[r]);
+        sh[crow(r, half) * LD64 + 32 + col] = relu_bits(h1b[r]);
+      }
+      wave_lds_sync();
+      f32x16 h2a = zero16(), h2b = zero16();
+      {
+        const float* ap = sh + col * LD64 + 4 * half;
+        const float* b0 = w2tp + (size_t)col * D_P + 4 * half;
+        const float* b1 = b0 + 32 * D_P;
+#pragma unroll 4
+        for (int k = 0; k < D_P; k += 8) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
+          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h2b, 0, 0, 0);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h2b, 0, 0, 0);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h2b, 0, 0, 0);
+          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h2a, 0, 0, 0);
+          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
+        }
+      }
+      unsigned long long tleft = ties;
+      while (tleft) {
+        const int j = __builtin_ctzll(tleft);
+        tleft &= tleft - 1;
+        const float mj = __shfl(mx, j);                     // lane j holds column j's maximum
+        const int aj = __shfl(arg, j);                      // ... and its recorded winner (the primary)
+        if (col == (j & 31)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = j < 32 ? h2a[r] + bias0 : h2b[r] + bias1;
+            const int e = e0 + crow(r, half);
+            if (crow(r, half) < nrows && v == mj && e != aj) {
+              atomicOr(xmask + e, 1ull << j);
+              atomicOr(ewin + (e >> 6), 1ull << (e & 63));
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bitmap -> ascending list + per-word prefix counts (count -> scan -> fill: deterministic order).  blockIdx.y
+// selects the bitmap (one per block, the last one = OR over the blocks).
+struct ListArgs {
+  int n_words, n_edge, n_wg, n_lists;
+  long long bm_stride, wl_stride;
+  const unsigned long long* bits;   // [n_lists][bm_stride]
+  int* wg_count;                    // [n_lists][n_wg]
+  int* wg_off;                      // [n_lists][n_wg + 1] (total last)
+  int* rows;                        // [n_lists - 1][wl_stride] winner lists of the blocks
+  int* rows_any;                    // list of the last bitmap
+  int* wprefix;                     // [n_lists][bm_stride]
+};
+
+__device__ __forceinline__ unsigned long long list_word(const unsigned long long* __restrict__ bits, int w, int n_words, int n_edge) {
+  if (w >= n_words) return 0ull;
+  unsigned long long b = bits[w];
+  if (w == n_words - 1 && (n_edge & 63)) b &= (1ull << (n_edge & 63)) - 1ull;     // bits past the last edge
+  return b;
+}
+
+__global__ void __launch_bounds__(256) ewin_or(unsigned long long* __restrict__ ewin, long long bm_stride, int n_blocks, int n_words) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  unsigned long long v = 0ull;
+  for (int b = 0; b < n_blocks; ++b) v |= ewin[(size_t)b * bm_stride + w];
+  ewin[(size_t)n_blocks * bm_stride + w] = v;
+}
+
+__global__ void __launch_bounds__(256) list_count(const ListArgs a) {
+  __shared__ int red[4];
+  const unsigned long long* bits = a.bits + (size_t)blockIdx.y * a.bm_stride;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  int c = __popcll(list_word(bits, w, a.n_words, a.n_edge));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) a.wg_count[(size_t)blockIdx.y * a.n_wg + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of the workgroup counts of every list; one workgroup per list
+__global__ void __launch_bounds__(1024) list_scan(const ListArgs a) {
+  __shared__ int part[1024];
+  const int* cnt = a.wg_count + (size_t)blockIdx.x * a.n_wg;
+  int* out = a.wg_off + (size_t)blockIdx.x * (a.n_wg + 1);
+  const int n = a.n_wg, t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per, e = min(n, b + per);
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += cnt[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int i = b; i < e; ++i) { const int d = cnt[i]; out[i] = run; run += d; }
+  if (t == 1023) out[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) list_fill(const ListArgs a) {
+  __shared__ int part[256];
+  const int y = blockIdx.y;
+  const unsigned long long* bits = a.bits + (size_t)y * a.bm_stride;
+  int* rows = y < a.n_lists - 1 ? a.rows + (size_t)y * a.wl_stride : a.rows_any;
+  int* wprefix = a.wprefix + (size_t)y * a.bm_stride;
+  const int t = threadIdx.x, w = blockIdx.x * 256 + t;
+  unsigned long long b = list_word(bits, w, a.n_words, a.n_edge);
+  const int c = __popcll(b);
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int pos = a.wg_off[(size_t)y * (a.n_wg + 1) + blockIdx.x] + part[t] - c;
+  wprefix[w] = pos;                                   // winners before word w (w runs to n_wg * 256 <= bm_stride)
+  while (b) {
+    const int j = __builtin_ctzll(b);
+    b &= b - 1;
+    rows[pos++] = 64 * w + j;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// apos[node][j] = position in the block's winner list of the edge recorded as column j's arg-max, -1 when the
+// maximum is not positive (no gradient).  All blocks in one launch; off the backward chain.
+struct PosArgs {
+  int n_det;
+  long long bm_stride, ap_stride;
+  const unsigned long long* ewin; const int* wprefix;
+  const unsigned long long* parg[GNET_MAX_BLOCKS];
+  int* apos;                        // [B][ap_stride]
+};
+
+__global__ void __launch_bounds__(256) winner_positions(const PosArgs a) {
+  const int blk = blockIdx.y;
+  const unsigned long long* ewin = a.ewin + (size_t)blk * a.bm_stride;
+  const int* wprefix = a.wprefix + (size_t)blk * a.bm_stride;
+  int* apos = a.apos + (size_t)blk * a.ap_stride;
+  const long long total = (long long)a.n_det * D_P;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const unsigned long long pv = a.parg[blk][i];
+    apos[i] = (pv >> 32) != 0ull ? winner_pos(ewin, wprefix, (int)(unsigned)pv) : -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct EdgeBwdWArgs {
+  int n_edge, n_det;
+  const int* wcount;                // device: number of winner rows of this block
+  const int* wlist;                 // ascending winner edges
+  const int* edge_c; const int* edge_nz;
+  const int* apos;                  // [N,64] list position of column j's arg-max edge (-1: none)
+  const unsigned char* tflag; const unsigned long long* xmask;
+  const float* pw; const float* rc; const float* rn; const float* d_pc;
+  const float* w1t; const float* w2;      // pw_fc1 transposed [64][96]; pw_fc2 natural [64 (in f)][64 (out j)]
+  float* d_pw;                      // [E,32] += d P on winner rows
+  float* g1c;                       // [W,64] g1 of the winner rows, list order
+  float* arena; long long stride;
+  long long o_w1, o_w2, o_b2;
+};
+
+constexpr int EBW_WAVES = 4;
+constexpr int EBW_LDP = D_E + 1;                                // P tile row stride (scalar accesses only)
+constexpr int EBW_WAVE_FLOATS = 32 * LD64 + 32 * EBW_LDP + 160; // h1/g1 tile, P tile, edge ids [32], RJ [64], DV [64]
+constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);
+
+// Every wave owns whole 32-winner tiles of the block's winner list (rows sorted by centre), no workgroup barrier
+// in the tile loop.  Per tile:
+//   h1   = relu(P . Wp + (rc[c] + rn[n]))            32 MFMAs, the forward kernel's operation sequence
+//   per detection (segment of rows) of the tile, LANE = COLUMN j of the detection:
+//     row_j = apos[c][j] - first list position of the tile;  v_j = d_pc[c][j]  (0 when the winner is not in the tile)
+//     dW2[:, j] += v_j * h1[row_j][:]                64 FMAs on 16 gathered LDS quads, accumulators = registers
+//     D[row_j][j] = v_j                              d h2 of the tile, built in MFMA A-operand registers
+//   g1   = (h1 > 0) * (D . W2^T)                     64 MFMAs
+//   dP   = g1 . Wp^T -> d_pw[e] +=                   32 MFMAs;  dWp += P^T . g1   32 MFMAs
+// The next tile's row records and P rows are requested at the top of a tile, its bias rows (rc + rn) during the
+// d P / d Wp MFMAs.
+__global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sWpT = smem;                          // [64][36]  Wp^T: B operand of h1 (16-byte reads) and of d P (strided)
+  float* sW2 = sWpT + D_P * LD32;              // [64][68]  W2[f][j]: B operand of g1 (16-byte reads along j)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* sH = sW2 + D_P * LD64 + wave * EBW_WAVE_FLOATS;   // [32][68] bias -> h1 -> g1 of this wave's tile
+  float* sPt = sH + 32 * LD64;                 // [32][33]  P rows of the tile
+  int* sE = reinterpret_cast<int*>(sPt + 32 * EBW_LDP);    // [32] edge of every tile row
+  int* sRJ = sE + 32;                          // [64] tile row of column j's winner (-1: not in this tile)
+  float* sDV = reinterpret_cast<float*>(sRJ + 64);         // [64] d_pc[c][j]
+  for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
+  __syncthreads();
+  const int col = lane & 31, half = lane >> 5;
+  float w2acc[D_P];                            // lane j: d W2[f][j], f = register index
+#pragma unroll
+  for (int f = 0; f < D_P; ++f) w2acc[f] = 0.f;
+  f32x16 aWp0 = zero16(), aWp1 = zero16();     // d Wp[pf][f], f tiles 0 / 1
+  float gb2 = 0.f;                             // lane j: d b2[j]
+  const int W = *a.wcount;
+  const int ntiles = (W + 31) / 32;
+  const int nwaves = gridDim.x * EBW_WAVES;
+  const int per = (ntiles + nwaves - 1) / nwaves;
+  // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; XCD x gets the x-th contiguous eighth of the list,
+  // so the rc / rn / d_pc / apos rows it gathers (one image's worth for an 8-image batch) stay in its L2
+  const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int gw = lb * EBW_WAVES + wave;
+  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  const int q4 = lane >> 4, f4 = lane & 15;    // row-layout accesses: rows 4 i + q4, 16-byte chunk f4
+  // records of the next tile: edge, centre, neighbour row (lane = row, both half-waves alike), P in A layout
+  int nx_e = 0, nx_c = -1, nx_nz = 0;
+  f32x4 nx_pa[4];
+  float4 nx_bias[8];                           // rc[c] + rn[n] of rows 4 i + q4, chunk f4
+#define EBW_LOAD_ROWS(tile_)                                                                            \
+  do {                                                                                                  \
+    const int p_ = (tile_) * 32 + col;                                                                  \
+    nx_e = a.wlist[min(p_, W - 1)];                                                                     \
+    nx_c = p_ < W ? a.edge_c[nx_e] : -1;                                                                \
+    nx_nz = a.edge_nz[nx_e];                                                                            \
+    const float* ap_ = a.pw + (size_t)nx_e * D_E + 4 * half;                                            \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) nx_pa[k_] = *reinterpret_cast<const f32x4*>(ap_ + 8 * k_); \
+  } while (0)
+#define EBW_LOAD_BIAS()                                                                                 \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
+      const int row_ = 4 * i_ + q4;                                                                     \
+      const int cr_ = max(__shfl(nx_c, row_), 0), nzr_ = __shfl(nx_nz, row_);                           \
+      const float4 x_ = ldg4_b(a.rc, (unsigned)cr_ * (D_P * 4u) + 16u * f4);                            \
+      const float4 y_ = ldg4_b(a.rn, (unsigned)nzr_ * (D_P * 4u) + 16u * f4);                           \
+      nx_bias[i_] = make_float4(x_.x + y_.x, x_.y + y_.y, x_.z + y_.z, x_.w + y_.w);                    \
+    }                                                                                                   \
+  } while (0)
+  if (t0 < t1) { EBW_LOAD_ROWS(t0); EBW_LOAD_BIAS(); }
+  for (int t = t0; t < t1; ++t) {
+    const int p0 = t * 32;
+    const int nrows = min(32, W - p0);
+    const int my_e = nx_e, my_c = nx_c;
+    // ---- stage: edge ids, P tile, bias tile
+    if (half == 0) sE[col] = my_e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* pp = sPt + col * EBW_LDP + 4 * half + 8 * k;
+      pp[0] = nx_pa[k].x; pp[1] = nx_pa[k].y; pp[2] = nx_pa[k].z; pp[3] = nx_pa[k].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(sH + (4 * i + q4) * LD64 + 4 * f4) = nx_bias[i];
+    wave_lds_sync();
+    // ---- h1 = relu(P . Wp + (rc + rn)): the forward kernel's operation sequence (same bits)
+    {
+      f32x16 h1a, h1b;
+      float* hp = sH + (4 * half) * LD64 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { h1a[r] = hp[crow(r, 0) * LD64]; h1b[r] = hp[crow(r, 0) * LD64 + 32]; }
+      const float* b0 = sWpT + col * LD32 + 4 * half;
+      const float* b1 = b0 + 32 * LD32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 av = nx_pa[k];
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hp[crow(r, 0) * LD64] = relu_bits(h1a[r]); hp[crow(r, 0) * LD64 + 32] = relu_bits(h1b[r]); }
+    }
+    // the next tile's row records and P rows (consumed a whole tile later)
+    if (t + 1 < t1) EBW_LOAD_ROWS(t + 1);
+    wave_lds_sync();
+    // ---- segments of the tile (rows sorted by centre): wave-uniform loop
+    unsigned heads;
+    {
+      const int prev = __shfl_up(my_c, 1);
+      heads = (unsigned)__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev));
+    }
+    float dA[32];                                        // d h2[row = col][j = 4 half + 8 s + t] at index 4 s + t
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dA[i] = 0.f;
+    unsigned hleft = heads;
+    while (hleft) {
+      const int lo = __builtin_ctz(hleft);
+      hleft &= hleft - 1;
+      const int hi = hleft ? __builtin_ctz(hleft) : nrows;
+      const int cseg = __builtin_amdgcn_readlane(my_c, lo);
+      // lane j: column j of this detection
+      const int ap = a.apos[(size_t)cseg * D_P + lane];
+      const float dv = a.d_pc[(size_t)cseg * D_P + lane];
+      const int tf = a.tflag[cseg];
+      const int rowj = ap - p0;
+      const bool inj = ap >= 0 && rowj >= 0 && rowj < 32;              // the column's winner is a row of this tile
+      gb2 += inj ? dv : 0.f;
+      sRJ[lane] = inj ? rowj : -1;
+      sDV[lane] = dv;
+      // d W2[:, j] += d_pc[c][j] * h1[row of the column's winner]
+      if (inj) {
+        const float* hr = sH + rowj * LD64;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * k);
+          w2acc[4 * k + 0] = fmaf(dv, hv.x, w2acc[4 * k + 0]);
+          w2acc[4 * k + 1] = fmaf(dv, hv.y, w2acc[4 * k + 1]);
+          w2acc[4 * k + 2] = fmaf(dv, hv.z, w2acc[4 * k + 2]);
+          w2acc[4 * k + 3] = fmaf(dv, hv.w, w2acc[4 * k + 3]);
+          if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four quads in flight (registers)
+        }
+      }
+      wave_lds_sync();
+      // d h2 rows of this segment, A-operand layout (lane = row)
+      const bool mine = col >= lo && col < hi;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const int4 rj = *reinterpret_cast<const int4*>(sRJ + 4 * half + 8 * s8);
+        const float4 vv = *reinterpret_cast<const float4*>(sDV + 4 * half + 8 * s8);
+        dA[4 * s8 + 0] = rj.x == col ? vv.x : dA[4 * s8 + 0];
+        dA[4 * s8 + 1] = rj.y == col ? vv.y : dA[4 * s8 + 1];
+        dA[4 * s8 + 2] = rj.z == col ? vv.z : dA[4 * s8 + 2];
+        dA[4 * s8 + 3] = rj.w == col ? vv.w : dA[4 * s8 + 3];
+      }
+      if (tf) {
+        // tied maxima (rare): the extra winners of a column receive the same d_pc[c][j] (already divided by the count)
+        const unsigned long long xm = mine ? a.xmask[my_e] : 0ull;     // lane = row: its extra columns
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const float4 vv = *reinterpret_cast<const float4*>(sDV + 4 * half + 8 * s8);
+          const unsigned bits = (unsigned)(xm >> (4 * half + 8 * s8)) & 15u;
+          dA[4 * s8 + 0] = (bits & 1u) ? vv.x : dA[4 * s8 + 0];
+          dA[4 * s8 + 1] = (bits & 2u) ? vv.y : dA[4 * s8 + 1];
+          dA[4 * s8 + 2] = (bits & 4u) ? vv.z : dA[4 * s8 + 2];
+          dA[4 * s8 + 3] = (bits & 8u) ? vv.w : dA[4 * s8 + 3];
+        }
+#pragma unroll 1
+        for (int r = lo; r < hi; ++r) {
+          const unsigned long long xr = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(xm >> 32), r) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)xm, r);
+          if (xr == 0ull) continue;
+          if ((xr >> lane) & 1ull) {                     // lane j: column j has an extra winner in row r
+            gb2 += dv;
+            const float* hr = sH + r * LD64;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * k);
+              w2acc[4 * k + 0] = fmaf(dv, hv.x, w2acc[4 * k + 0]);
+              w2acc[4 * k + 1] = fmaf(dv, hv.y, w2acc[4 * k + 1]);
+              w2acc[4 * k + 2] = fmaf(dv, hv.z, w2acc[4 * k + 2]);
+              w2acc[4 * k + 3] = fmaf(dv, hv.w, w2acc[4 * k + 3]);
+              if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four quads in flight (registers)
+            }
+          }
+        }
+      }
+      wave_lds_sync();                                   // RJ / DV are rewritten by the next segment
+    }
+    // ---- g1 = (h1 > 0) * (d h2 . W2^T); overwrites h1 in place
+    {
+      f32x16 g1a = zero16(), g1b = zero16();
+      const float* b0 = sW2 + col * LD64 + 4 * half;
+      const float* b1 = b0 + 32 * LD64;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * s8);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * s8);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 0], bv0.x, g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 0], bv1.x, g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 1], bv0.y, g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 1], bv1.y, g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 2], bv0.z, g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 2], bv1.z, g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 3], bv0.w, g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 3], bv1.w, g1b, 0, 0, 0);
+        if (s8 & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      float* hp = sH + (4 * half) * LD64 + col;          // every lane rewrites the elements it reads
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool live = crow(r, half) < nrows;         // rows past the list (last tile): zero
+        const float ha = hp[crow(r, 0) * LD64], hb = hp[crow(r, 0) * LD64 + 32];
+        hp[crow(r, 0) * LD64] = (live && ha > 0.f) ? g1a[r] : 0.f;
+        hp[crow(r, 0) * LD64 + 32] = (live && hb > 0.f) ? g1b[r] : 0.f;
+      }
+    }
+    wave_lds_sync();
+    // ---- g1 rows -> compact list order (whole 256-byte rows; the buffer has slack rows past W)
+    {
+      float* dst = a.g1c + (size_t)p0 * D_P;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + q4;
+        *reinterpret_cast<float4*>(dst + row * D_P + 4 * f4) = *reinterpret_cast<const float4*>(sH + row * LD64 + 4 * f4);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's bias rows and the old d_pw values of this tile's rows (accumulator layout: rows crow(r, half),
+    // column col): in flight during the d Wp / d P MFMAs
+    if (t + 1 < t1) EBW_LOAD_BIAS();
+    float dold[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dold[r] = a.d_pw[(size_t)sE[crow(r, 0) + 4 * half] * D_E + col];
+    // ---- d Wp += P^T . g1
+    {
+      const float* X = sPt + col;
+      const float* Y = sH + col;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + half;
+        const float x = X[row * EBW_LDP];
+        aWp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, Y[row * LD64], aWp0, 0, 0, 0);
+        aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, Y[row * LD64 + 32], aWp1, 0, 0, 0);
+        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- d P = g1 . Wp^T;  d_pw[e] += d P
+    {
+      f32x16 acc = zero16();
+      const float* ap = sH + col * LD64 + 4 * half;
+      const float* bp = sWpT + (4 * half) * LD32 + col;             // Wp[pf = col][f] = sWpT[f][pf]
+#pragma unroll
+      for (int k = 0; k < D_P; k += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD32], acc, 0, 0, 0);
+        if ((k & 8) != 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      // rows past the list (last tile) go to the slack row E of d_pw: unconditional stores, no divergent branches
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int er = crow(r, half) < nrows ? sE[crow(r, 0) + 4 * half] : a.n_edge;
+        a.d_pw[(size_t)er * D_E + col] = dold[r] + acc[r];
+      }
+    }
+    wave_lds_sync();
+  }
+#undef EBW_LOAD_ROWS
+#undef EBW_LOAD_BIAS
+  // ---- partial weight gradients of this workgroup: the four waves' accumulators are added in wave order
+  __syncthreads();
+  float* red = sW2 + D_P * LD64;               // the waves' tile areas: 4 * 3392 floats >= 4096 + 2048 + 64
+  float* redW2 = red;                          // [f][j]
+  float* redWp = red + D_P * D_P;              // [2][16][64] accumulator registers
+  float* redB = redWp + 2 * 16 * 64;           // [64]
+  for (int w = 0; w < EBW_WAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int f = 0; f < D_P; ++f) redW2[f * D_P + lane] = (w ? redW2[f * D_P + lane] : 0.f) + w2acc[f];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        redWp[r * 64 + lane] = (w ? redWp[r * 64 + lane] : 0.f) + aWp0[r];
+        redWp[(16 + r) * 64 + lane] = (w ? redWp[(16 + r) * 64 + lane] : 0.f) + aWp1[r];
+      }
+      redB[lane] = (w ? redB[lane] : 0.f) + gb2;
+    }
+    __syncthreads();
+  }
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) ar[a.o_w2 + i] = redW2[i];     // [f][j]
+  if (wave < 2) {                              // rows 0-31 of pw_fc1 (pairwise features), f tile = wave
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ar[a.o_w1 + (size_t)crow(r, half) * D_P + 32 * wave + col] = redWp[(16 * wave + r) * 64 + lane];
+  }
+  if (tid < D_P) ar[a.o_b2 + tid] = redB[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// d_rc[i] = sum of g1 over i's winner edges (a contiguous range of the list);  d_rn[i] = sum over i's edges
+// e = (i, n), n != i (self pair: n_feats zeroed, network.py:371-374), of g1[reverse(e)] when the reversed pair
+// is a winner of n.  One wave per detection, four rows per wave-instruction, ascending order (no atomics).
+__global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ g1c, const int* __restrict__ row_ptr,
+                                                      const int* __restrict__ edge_n, const int* __restrict__ edge_t,
+                                                      const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix,
+                                                      int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n_det) return;
+  const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
+  const int eb = row_ptr[node], ee = row_ptr[node + 1];
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
+  const int p0 = winner_pos(ewin, wprefix, eb), p1 = winner_pos(ewin, wprefix, ee);
+  for (int p = p0 + sub; p < p1; p += 4) {
+    const float4 c = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
+    sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+  }
+  for (int base = eb; base < ee; base += 64) {
+    const int el = base + lane;
+    int tp = -1;                                            // list position of the reversed pair, if it is a winner
+    if (el < ee && edge_n[el] != node) {
+      const int t = edge_t[el];
+      if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp = winner_pos(ewin, wprefix, t);
+    }
+    unsigned long long mr = __ballot(tp >= 0);
+    while (mr) {
+      int j = -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if (q == sub) j = b; } }
+      const int p = __shfl(tp, j < 0 ? 0 : j);
+      if (j >= 0) {
+        const float4 v = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
+        sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    sc.x += __shfl_xor(sc.x, o); sc.y += __shfl_xor(sc.y, o); sc.z += __shfl_xor(sc.z, o); sc.w += __shfl_xor(sc.w, o);
+    sn.x += __shfl_xor(sn.x, o); sn.y += __shfl_xor(sn.y, o); sn.z += __shfl_xor(sn.z, o); sn.w += __shfl_xor(sn.w, o);
+  }
+  if (sub == 0) {
+    *reinterpret_cast<float4*>(d_rc + (size_t)node * D_P + 4 * f4) = sc;
+    *reinterpret_cast<float4*>(d_rn + (size_t)node * D_P + 4 * f4) = sn;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const ParamLayout& L, const float* params,
+                       gnet_buffers* buf, hipStream_t s) {
+  const int B = cfg->num_blocks, N = shape->n_det, E = (int)shape->n_edge;
+  const EdgeGeom G = edge_geom(E, N);
+  void* prof = buf->profiler;
+  const float* pt = buf->packed_t;
+  HIP_CHECK_RET(hipMemsetAsync(buf->ewin, 0, (size_t)(B + 1) * G.bm_stride * sizeof(unsigned long long), s));
+  WinArgs w;
+  w.n_det = N; w.bm_stride = (long long)G.bm_stride; w.xm_stride = (long long)G.xm_stride; w.tf_stride = (long long)G.tf_stride;
+  w.ewin = (unsigned long long*)buf->ewin; w.xmask = (unsigned long long*)buf->xmask; w.tflag = (unsigned char*)buf->tflag;
+  w.row_ptr = buf->row_ptr; w.edge_nz = buf->edge_nz; w.pw = buf->pw_feats;
+  for (int b = 1; b <= B; ++b) {
+    w.pm[b - 1] = (const unsigned long long*)buf->blk_pm[b]; w.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
+    w.rc[b - 1] = buf->blk_rc[b]; w.rn[b - 1] = buf->blk_rn[b];
+    w.w1t[b - 1] = pt + L.blk[b].w1; w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
+  }
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_ties<<<dim3(min((N + 3) / 4, 256), B), 256, 0, s>>>(w));
+  ListArgs l;
+  l.n_words = (int)G.n_words; l.n_edge = E; l.n_wg = (int)G.n_wg; l.n_lists = B + 1;
+  l.bm_stride = (long long)G.bm_stride; l.wl_stride = (long long)G.wl_stride;
+  l.bits = (const unsigned long long*)buf->ewin;
+  l.wg_count = buf->rl_scratch; l.wg_off = buf->rl_scratch + (size_t)(B + 1) * G.n_wg;
+  l.rows = buf->wlist; l.rows_any = buf->pw_rows; l.wprefix = buf->wprefix;
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, ewin_or<<<(int)((G.n_words + 255) / 256), 256, 0, s>>>((unsigned long long*)buf->ewin, (long long)G.bm_stride, B, (int)G.n_words));
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, list_count<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, list_scan<<<B + 1, 1024, 0, s>>>(l));
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, list_fill<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
+  PosArgs p;
+  p.n_det = N; p.bm_stride = (long long)G.bm_stride; p.ap_stride = (long long)G.ap_stride;
+  p.ewin = (const unsigned long long*)buf->ewin; p.wprefix = buf->wprefix; p.apos = buf->apos;
+  for (int b = 1; b <= B; ++b) p.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
+  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winner_positions<<<dim3(min((N * D_P + 255) / 256, 1024), B), 256, 0, s>>>(p));
+  return GNET_OK;
+}
+
+int edge_stage_set_attributes() {
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeBwdWSmem));
+  return GNET_OK;
+}
+
+int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const ParamLayout& L, const float* params, int b,
+                     gnet_buffers* buf, int n_partials, hipStream_t s) {
+  const int B = cfg->num_blocks, N = shape->n_det, E = (int)shape->n_edge;
+  const EdgeGeom G = edge_geom(E, N);
+  const BlockLayout& K = L.blk[b];
+  void* prof = buf->profiler;
+  const float* pt = buf->packed_t;
+  const int* wg_off = buf->rl_scratch + (size_t)(B + 1) * G.n_wg;
+  EdgeBwdWArgs e;
+  e.n_edge = E; e.n_det = N;
+  e.wcount = wg_off + (size_t)(b - 1) * (G.n_wg + 1) + G.n_wg;
+  e.wlist = buf->wlist + (size_t)(b - 1) * G.wl_stride;
+  e.edge_c = buf->edge_c; e.edge_nz = buf->edge_nz;
+  e.apos = buf->apos + (size_t)(b - 1) * G.ap_stride;
+  e.tflag = (const unsigned char*)buf->tflag + (size_t)(b - 1) * G.tf_stride;
+  e.xmask = (const unsigned long long*)buf->xmask + (size_t)(b - 1) * G.xm_stride;
+  e.pw = buf->pw_feats; e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b]; e.d_pc = buf->d_pc;
+  e.w1t = pt + K.w1; e.w2 = params + K.w2;
+  e.d_pw = buf->d_pw; e.g1c = buf->d_g1;
+  e.arena = buf->arena; e.stride = L.total; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
+  GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_w<<<n_partials, 64 * EBW_WAVES, kEdgeBwdWSmem, s>>>(e));
+  GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
+      buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, (const unsigned long long*)buf->ewin + (size_t)(b - 1) * G.bm_stride,
+      buf->wprefix + (size_t)(b - 1) * G.bm_stride, N, buf->d_rc, buf->d_rn));
+  return GNET_OK;
+}

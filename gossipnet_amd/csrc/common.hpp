@@ -109,6 +109,28 @@ static inline ParamLayout make_layout(const gnet_config* c) {
   return L;
 }
 
+// ---- geometry of the winner maps / lists of the backward edge stage (plan.hip, backward*.hip) ----------
+struct EdgeGeom {
+  size_t n_words;     // 64-bit words of a 1-bit-per-edge map
+  size_t n_wg;        // 256-word scan chunks (covers word index n_words too: position of the end sentinel)
+  size_t bm_stride;   // words between the blocks' maps / prefix arrays (= n_wg * 256)
+  size_t wl_stride;   // ints between the blocks' winner lists
+  size_t xm_stride;   // u64 between the blocks' extra-winner masks
+  size_t tf_stride;   // bytes between the blocks' per-detection tie flags
+  size_t ap_stride;   // ints between the blocks' [N,64] arg-max list positions
+};
+static inline EdgeGeom edge_geom(int64_t E, int64_t N) {
+  EdgeGeom g;
+  g.n_words = (size_t)(E + 63) / 64;
+  g.n_wg = (g.n_words + 1 + 255) / 256;
+  g.bm_stride = g.n_wg * 256;
+  g.wl_stride = ((size_t)E + 64 + 63) & ~(size_t)63;
+  g.xm_stride = ((size_t)E + 64 + 63) & ~(size_t)63;
+  g.tf_stride = ((size_t)N + 32 + 63) & ~(size_t)63;
+  g.ap_stride = ((size_t)N + 32) * D_P;
+  return g;
+}
+
 // ---- fp32 MFMA tile primitives ---------------------------------------------------------
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // the 16 accumulator registers hold D[row][col] with col = l&31,

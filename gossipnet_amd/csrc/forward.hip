@@ -10,7 +10,6 @@
 //   node_fwd         per block: fc1, fc2, shortcut (:390-408) of block b and reduce_dim (:348-354)
 //                    + the per-node halves of pw_fc1 of block b+1; after the last block: head (:258-273)
 // All dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
-#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -281,7 +280,7 @@ struct EdgeFwdArgs {
   unsigned long long* pm;        // [N,64], zeroed
   const int* row_ptr;            // [N+1]
   const int* edge_nz;            // [E+64] neighbour index, n_det (a zero row of rn) for self pairs and the tail
-  float* h1_out;                 // [E+64,64] relu(pw_fc1) kept for the backward pass (NULL at inference)
+  float* h1_out;                 // [E+64,64] relu(pw_fc1) (KEEP variant only: tests / debugging)
   unsigned long long* parg;      // [N,64] (max bits << 32) | first edge attaining it (training), zeroed
 };
 
@@ -303,7 +302,11 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
 constexpr int EFW_WAVES = 4;      // waves per workgroup; 2 workgroups per CU.  (6 waves = 3 per SIMD measured 28% SLOWER)
 constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 32 * E_LD2) * sizeof(float);
 
-template <bool TRAIN>     // TRAIN: keep h1 and the arg-max edge of every (centre, column) for the backward pass
+// TRAIN: record the arg-max edge of every (centre, column) for the sparse SegmentMax backward.  The pw_fc1
+// activations are NOT kept: the backward pass recomputes them for the ~26 % of the edges that carry gradient
+// (backward_edge.hip) -- storing them cost 0.37 GB of HBM writes per launch (2.8 TB/s on an MFMA-bound kernel)
+// and 5.9 GB of workspace for the bench batch.  KEEP (tests / debugging) stores them after all.
+template <bool TRAIN, bool KEEP>
 __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sWp = smem;                           // [64][36]  Wp^T
@@ -473,9 +476,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
       }
     }
-    if (TRAIN) {
-      // 288 GB of HBM: the backward pass reads h1 back instead of recomputing pw_fc1 (16 of its 144 MFMAs
-      // per tile plus the rc/rn gathers).  Whole 256-byte rows, 16 B per lane; behind this tile's loads.
+    if (KEEP) {
+      // whole 256-byte rows, 16 B per lane; behind this tile's loads
       float* dst = a.h1_out + (size_t)e0 * D_P;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -784,18 +786,20 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
     a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
     const int tiles = (E + PW_T - 1) / PW_T;
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
-      attr_set = true;
-    }
+    // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
     GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<min(tiles, 512), 512, kPwFwdSmem, s>>>(a));
   }
 
   const int ntile_n = (N + 31) / 32;
-  // edge_fwd_w partition (workgroups per CU: default 2): wave-owned contiguous tile ranges
-  static const int wg_per_cu = getenv("GNET_EDGE_FWD_W") ? max(1, atoi(getenv("GNET_EDGE_FWD_W"))) : 2;
-  const int ef_wg = max(1, min(wg_per_cu * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+  // edge_fwd_w partition (2 workgroups per CU): wave-owned contiguous tile ranges
+  const int ef_wg = max(1, min(2 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+  const bool keep_h1 = training == 2;
+  if (E > 0) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
+  }
   const int ef_tiles = (E + 31) / 32, ef_waves = ef_wg * EFW_WAVES;
   const int ef_span = max(1, (ef_tiles + ef_waves - 1) / ef_waves) * 32;       // edges per wave range
   for (int b = 0; b <= B; ++b) {
@@ -829,17 +833,14 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
         e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
         e.edge_nz = buf->edge_nz;
-        e.h1_out = training ? buf->blk_h1[b + 1] : nullptr;
+        e.h1_out = keep_h1 ? buf->blk_h1[b + 1] : nullptr;
         e.parg = training ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
         const int wg = ef_wg;
-        static bool attr_w = false;
-        if (!attr_w) {
-          HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
-          HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
-          attr_w = true;
-        }
-        if (training) { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<true><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
-        else { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<false><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
+        if (keep_h1) {
+          if (!buf->blk_h1[b + 1]) return GNET_ERR_INVALID;                  // planned without training == 2
+          GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<true, true><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e));
+        } else if (training) { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<true, false><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
+        else { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<false, false><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
       }
     }
   }

@@ -56,7 +56,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.blk_pm[k] = c.take<uint64_t>(2 * Np * D_P);      // pm, then parg (one memset clears both)
       b.blk_parg[k] = b.blk_pm[k] + Np * D_P;
       b.blk_q[k] = c.take<float>(Np * D_P);
-      b.blk_h1[k] = c.take<float>(Ep * D_P);
+      if (training == 2) b.blk_h1[k] = c.take<float>(Ep * D_P);     // tests / debugging only
     }
     b.head1 = c.take<float>(Np * D_HEAD);
     b.head2 = c.take<float>(Np * D_HEAD);
@@ -75,7 +75,16 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_pw = c.take<float>(Ep * D_E);
     b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
-    b.emask = c.take<uint64_t>(B * (Ep + 128) + 2 * (Ep / 64 + 384));   // per-edge masks of every block, then two 1-bit-per-edge maps (this block / any block)
+    {
+      const EdgeGeom G = edge_geom((int64_t)E, (int64_t)N);
+      b.ewin = c.take<uint64_t>((B + 1) * G.bm_stride);
+      b.wprefix = c.take<int32_t>((B + 1) * G.bm_stride);
+      b.wlist = c.take<int32_t>(B * G.wl_stride);
+      b.xmask = c.take<uint64_t>(B * G.xm_stride);
+      b.tflag = c.take<uint8_t>(B * G.tf_stride);
+      b.apos = c.take<int32_t>(B * G.ap_stride);
+      b.rl_scratch = c.take<int32_t>((B + 1) * (2 * G.n_wg + 1) + 64);
+    }
     b.pw_rows = c.take<int32_t>(Ep);
     b.w1_s = c.take<float>(Np * D_H);
     b.w1_t = c.take<float>(Np * D_H);

@@ -266,6 +266,7 @@ class Gnet(object):
         thr = float(cfg.gnet.neighbor_thresh)
         E = int(self._row_ptr_tmp[N].item()) if N > 0 else 0     # the one host sync of a step
         shape = _lib.gnet_shape(db.n_img, N, db.n_gt, E, db.n_anno)
+        training = self._mode(training)
         need = lib.gnet_workspace_bytes(C.byref(self._cfg), C.byref(shape), int(training))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
@@ -282,6 +283,10 @@ class Gnet(object):
             _lib.check(lib.gnet_graph_transpose(buf.row_ptr, buf.edge_c, buf.edge_n, E, buf.edge_t, s), "gnet_graph_transpose")
         self.num_edges = E
         return shape, buf
+
+    def _mode(self, training):
+        """`training` argument of the C ABI: 0 inference, 1 training, 2 training + per-block pw_fc1 activations kept."""
+        return 0 if not training else (2 if self.keep_edge_activations else 1)
 
     def begin(self, batch=None):
         """First, asynchronous half of run(): feed + neighbour counting.  Several Gnets (sharing variables
@@ -309,7 +314,7 @@ class Gnet(object):
         inp = db.c_inputs()
         self._inputs = inp
         _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
-                                    C.byref(buf), int(training), s), "gnet_forward")
+                                    C.byref(buf), self._mode(training), s), "gnet_forward")
         if training:
             _lib.check(lib.gnet_loss(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.class_weights),
                                      float(self.grad_scale), C.byref(buf), s), "gnet_loss")

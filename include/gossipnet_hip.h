@@ -99,7 +99,7 @@ typedef struct gnet_buffers {
   float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[64:96]             */
   uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count */
   float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
-  float* blk_h1[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] relu(pw_fc1) per edge, kept for the backward pass (training) */
+  float* blk_h1[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] relu(pw_fc1) per edge -- only when planned with training == 2 (tests / debugging: the backward pass recomputes the rows it needs) */
   uint64_t* blk_parg[GNET_MAX_BLOCKS + 1]; /* [n_det,64] (segment-max bits << 32) | index of the first edge that attains it (training) */
   float* head1;       /* [n_det,128] predict/fc1 */
   float* head2;       /* [n_det,128] predict/fc2 */
@@ -118,8 +118,15 @@ typedef struct gnet_buffers {
   float* d_rn;        /* [n_det,64] */
   float* d_pw;        /* [n_edge,32] grad wrt pw_feats */
   float* d_h1;        /* [n_edge,256] grad wrt pre-activation of pw_feats/fc1 */
-  float* d_g1;        /* [n_edge,64]  grad wrt pre-activation of block pw_fc1 (per block, transient) */
-  uint64_t* emask;    /* [num_blocks][n_edge+128] per block and edge: columns of the block's segment max it attains (0 = no gradient flows through it); followed by two bitmaps */
+  float* d_g1;        /* [n_edge+64,64] grad wrt pre-activation of block pw_fc1 on the block's winner edges, list order (per block, transient) */
+  /* sparse SegmentMax backward (csrc/backward_edge.hip): per block b = 1..num_blocks at index b-1, strides = edge_geom() */
+  uint64_t* ewin;     /* [num_blocks+1][bm_stride] 1 bit per edge: the edge attains a positive segment maximum of the block ("winner": gradient flows through it); last map = OR over the blocks */
+  int32_t* wprefix;   /* [num_blocks+1][bm_stride] winners before 64-edge word w */
+  int32_t* wlist;     /* [num_blocks][wl_stride] ascending winner edges of the block */
+  uint64_t* xmask;    /* [num_blocks][xm_stride] per edge: columns whose (tied) maximum it attains besides the recorded arg-max edge; valid on rows of flagged detections only */
+  uint8_t* tflag;     /* [num_blocks][tf_stride] the detection has a tied positive maximum in this block */
+  int32_t* apos;      /* [num_blocks][n_det+32,64] list position of the arg-max edge of every (detection, column); -1 = no gradient */
+  int32_t* rl_scratch;/* scan scratch of the list construction; also holds the list lengths */
   int32_t* pw_rows;   /* [n_edge+64] ascending indices of the edges with a non-zero d_pw row (rows of the pw-MLP backward) */
   float* w1_s;        /* [n_det,256] sum of d_h1 over the detection's own pairs (centre role)      */
   float* w1_t;        /* [n_det,256] sum of d_h1 over the reversed pairs (neighbour role)          */
@@ -156,7 +163,9 @@ int gnet_graph_fill(const float* dets, int32_t n_det, const int32_t* det_off, in
 int gnet_graph_transpose(const int32_t* row_ptr, const int32_t* edge_c, const int32_t* edge_n, int64_t n_edge,
                          int32_t* edge_t, gnet_stream_t stream);
 
-/* ---- workspace ----------------------------------------------------------------- */
+/* ---- workspace -----------------------------------------------------------------
+ * training: 0 = inference (two alternating sets of per-block tensors), 1 = training (everything the backward
+ * pass re-reads), 2 = training + keep the per-block pw_fc1 activations blk_h1 (tests / debugging only). */
 size_t gnet_workspace_bytes(const gnet_config* cfg, const gnet_shape* shape, int training);
 int gnet_plan(const gnet_config* cfg, const gnet_shape* shape, int training, void* workspace,
               size_t workspace_bytes, gnet_buffers* out);
@@ -176,8 +185,8 @@ int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs
  * Reproducible: no float atomics, fixed summation order (per-workgroup partials, summed in index order).
  * The gradient of the SegmentMax (network.py:383-386) reaches one edge per (detection, column); the edge
  * stage and the pw-MLP backward therefore run on the edges that carry gradient only -- the same sums as the
- * dense algorithm minus exact zeros.  Environment GNET_DENSE_BWD=1 (read once per process) selects the
- * dense implementation of the edge stage instead. */
+ * dense algorithm minus exact zeros.
+ * Limits: n_edge <= 2^24 - 128 (32-bit byte offsets into [E,64] fp32 arrays; GNET_ERR_UNSUPPORTED beyond). */
 int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                   const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream);
 

@@ -37,14 +37,30 @@ def gpu_pins(net, image=None):
     pins = {"pw": [cpu(dv("pw_h1", E * 256).view(E, 256)[e0:e1] > 0), cpu(dv("pw_h2", E * 256).view(E, 256)[e0:e1] > 0),
                    cpu(net.pw_feats[e0:e1] > 0)],
             "r": [], "h1": [], "sel": [], "q": [], "x": []}
-    em_stride = ((E + 128 + 63) // 64) * 64
-    emask = dv("emask", B * em_stride, dtype=torch.int64).view(B, em_stride)
-    shifts = torch.arange(64, device=emask.device, dtype=torch.int64).view(1, 64)
+    # winner sets: the recorded arg-max edge of every (detection, column) with a positive maximum, plus -- for
+    # detections flagged as tied -- the extra winners of the tied columns (csrc/backward_edge.hip winners_mark)
+    wl_stride = ((E + 64 + 63) // 64) * 64            # edge_geom(): xm_stride = wl_stride, tf_stride
+    tf_stride = ((N + 32 + 63) // 64) * 64
+    xmask = dv("xmask", B * wl_stride, dtype=torch.int64).view(B, wl_stride)
+    tflag = dv("tflag", B * tf_stride, dtype=torch.uint8).view(B, tf_stride)
+    edge_c = net.neighbor_pair_idxs[:, 0]
+    shifts = torch.arange(64, device=xmask.device, dtype=torch.int64).view(1, 64)
+    cols = torch.arange(64, device=xmask.device).view(1, 64).expand(N, 64)
+
+    def winner_sets(b):
+        parg = dv("blk_parg", N * 64, dtype=torch.int64, index=b).view(N, 64)
+        valid = (parg >> 32) != 0
+        sel = torch.zeros(E, 64, dtype=torch.bool, device=parg.device)
+        sel[(parg & 0xffffffff)[valid], cols[valid]] = True
+        tied_rows = tflag[b - 1, :N][edge_c] != 0                    # edges of flagged detections
+        extra = ((xmask[b - 1, :E].view(-1, 1) >> shifts) & 1) != 0
+        return sel | (extra & tied_rows.view(-1, 1))
+
     bf = net.block_feats
     for b in range(1, B + 1):
         pins["r"].append(cpu(dv("blk_r", N * 32, index=b).view(N, 32)[d0:d1] > 0))
         pins["h1"].append(cpu(dv("blk_h1", E * 64, index=b).view(E, 64)[e0:e1] > 0))
-        pins["sel"].append(cpu(((emask[b - 1, e0:e1].view(-1, 1) >> shifts) & 1) != 0))
+        pins["sel"].append(cpu(winner_sets(b)[e0:e1]))
         pins["q"].append(cpu(dv("blk_q", N * 64, index=b).view(N, 64)[d0:d1] > 0))
         pins["x"].append(cpu(bf[b][d0:d1] > 0))
     return pins

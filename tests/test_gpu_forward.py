@@ -57,6 +57,7 @@ def test_argmax_edges_recorded_for_backward():
     """Training forward keeps, per (detection, column), the first edge that attains the segment maximum
     (the sparse backward routes the SegmentMax gradient through it; network.py:383-386)."""
     net, orc = make_pair(80, 3)
+    net.keep_edge_activations = True
     batch = make_image(300, 80, seed=5)
     net.run(batch)
     torch.cuda.synchronize()
