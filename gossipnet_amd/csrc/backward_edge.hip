@@ -331,8 +331,9 @@ struct EdgeBwdWArgs {
 
 constexpr int EBW_WAVES = 4;
 constexpr int EBW_LDP = D_E + 1;                                // P tile row stride (scalar accesses only)
-constexpr int EBW_WAVE_FLOATS = 32 * LD64 + 32 * EBW_LDP + 160; // h1/g1 tile, P tile, edge ids [32], RJ [64], DV [64]
-constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);
+constexpr int EBW_SLOTS = 3;                                    // detections of a tile handled between two LDS hand-offs
+constexpr int EBW_WAVE_FLOATS = 32 * LD64 + 32 * EBW_LDP + 32 + EBW_SLOTS * 128;   // h1/g1 tile, P tile, edge ids [32], RJ/DV [slots][64]
+constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_E * LD64 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);
 
 // Every wave owns whole 32-winner tiles of the block's winner list (rows sorted by centre), no workgroup barrier
 // in the tile loop.  Per tile:
@@ -343,19 +344,28 @@ constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_P * LD64 + EBW_WAVES * 
 //     D[row_j][j] = v_j                              d h2 of the tile, built in MFMA A-operand registers
 //   g1   = (h1 > 0) * (D . W2^T)                     64 MFMAs
 //   dP   = g1 . Wp^T -> d_pw[e] +=                   32 MFMAs;  dWp += P^T . g1   32 MFMAs
-// The next tile's row records and P rows are requested at the top of a tile, its bias rows (rc + rn) during the
-// d P / d Wp MFMAs.
-__global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWArgs a) {
+// Latency discipline (vmcnt is one in-order counter for loads and stores): everything the NEXT tile reads from
+// HBM/L2 is requested before this tile's stores -- the list entries two tiles ahead, the row records and P rows one
+// tile ahead (right after the h1 MFMAs), the bias rows rc[c] / rn[n] and the first two detections' column records
+// right after the g1 MFMAs (in flight during the 64 d Wp / d P MFMAs).  d_pw[e] += d P uses returnless float
+// atomics: an edge is a row of exactly one tile per block and the blocks are separate launches, so every element
+// receives its additions in launch order -- the sum stays bitwise reproducible, and no old value has to be fetched.
+__global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sWpT = smem;                          // [64][36]  Wp^T: B operand of h1 (16-byte reads) and of d P (strided)
-  float* sW2 = sWpT + D_P * LD32;              // [64][68]  W2[f][j]: B operand of g1 (16-byte reads along j)
+  float* sWpT = smem;                          // [64][36]  Wp^T[f][pf]: B operand of h1 (16-byte reads along pf)
+  float* sWp = sWpT + D_P * LD32;              // [32][68]  Wp[pf][f]:   B operand of d P (16-byte reads along f)
+  float* sW2 = sWp + D_E * LD64;               // [64][68]  W2[f][j]:    B operand of g1 (16-byte reads along j)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* sH = sW2 + D_P * LD64 + wave * EBW_WAVE_FLOATS;   // [32][68] bias -> h1 -> g1 of this wave's tile
   float* sPt = sH + 32 * LD64;                 // [32][33]  P rows of the tile
   int* sE = reinterpret_cast<int*>(sPt + 32 * EBW_LDP);    // [32] edge of every tile row
-  int* sRJ = sE + 32;                          // [64] tile row of column j's winner (-1: not in this tile)
-  float* sDV = reinterpret_cast<float*>(sRJ + 64);         // [64] d_pc[c][j]
-  for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) sWpT[(i >> 5) * LD32 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  int* sRJ = sE + 32;                          // [slots][64] tile row of column j's winner (-1: not in this tile)
+  float* sDV = reinterpret_cast<float*>(sRJ + EBW_SLOTS * 64);   // [slots][64] d_pc[c][j]
+  for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) {
+    const float v = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];          // W1[pf = i & 31][f = i >> 5]
+    sWpT[(i >> 5) * LD32 + (i & 31)] = v;
+    sWp[(i & 31) * LD64 + (i >> 5)] = v;
+  }
   for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
   __syncthreads();
   const int col = lane & 31, half = lane >> 5;
@@ -375,34 +385,56 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   const int t0 = gw * per, t1 = min(ntiles, t0 + per);
   const int q4 = lane >> 4, f4 = lane & 15;    // row-layout accesses: rows 4 i + q4, 16-byte chunk f4
   // records of the next tile: edge, centre, neighbour row (lane = row, both half-waves alike), P in A layout
+  int nx2_e = 0;                               // list entry two tiles ahead
   int nx_e = 0, nx_c = -1, nx_nz = 0;
   f32x4 nx_pa[4];
-  float4 nx_bias[8];                           // rc[c] + rn[n] of rows 4 i + q4, chunk f4
-#define EBW_LOAD_ROWS(tile_)                                                                            \
+  float4 nx_x[8], nx_y[8];                     // rc[c] / rn[n] of rows 4 i + q4, chunk f4 (added at the top of the tile)
+  // column records (lane = column j) of the first two detections of the next tile
+  int apA = -1, apB = -1, apC = -1, tfA = 0, tfB = 0, tfC = 0;
+  float dvA = 0.f, dvB = 0.f, dvC = 0.f;
+#define EBW_LOAD_LIST(tile_) do { nx2_e = a.wlist[min((tile_) * 32 + col, W - 1)]; } while (0)
+#define EBW_LOAD_ROWS(tile_)     /* uses nx2_e = list entries of tile_ */                               \
   do {                                                                                                  \
-    const int p_ = (tile_) * 32 + col;                                                                  \
-    nx_e = a.wlist[min(p_, W - 1)];                                                                     \
-    nx_c = p_ < W ? a.edge_c[nx_e] : -1;                                                                \
+    nx_e = nx2_e;                                                                                       \
+    nx_c = (tile_) * 32 + col < W ? a.edge_c[nx_e] : -1;                                                \
     nx_nz = a.edge_nz[nx_e];                                                                            \
     const float* ap_ = a.pw + (size_t)nx_e * D_E + 4 * half;                                            \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) nx_pa[k_] = *reinterpret_cast<const f32x4*>(ap_ + 8 * k_); \
   } while (0)
-#define EBW_LOAD_BIAS()                                                                                 \
+#define EBW_LOAD_BIAS()          /* uses nx_c / nx_nz of the next tile */                               \
   do {                                                                                                  \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
       const int row_ = 4 * i_ + q4;                                                                     \
       const int cr_ = max(__shfl(nx_c, row_), 0), nzr_ = __shfl(nx_nz, row_);                           \
-      const float4 x_ = ldg4_b(a.rc, (unsigned)cr_ * (D_P * 4u) + 16u * f4);                            \
-      const float4 y_ = ldg4_b(a.rn, (unsigned)nzr_ * (D_P * 4u) + 16u * f4);                           \
-      nx_bias[i_] = make_float4(x_.x + y_.x, x_.y + y_.y, x_.z + y_.z, x_.w + y_.w);                    \
+      nx_x[i_] = ldg4_b(a.rc, (unsigned)cr_ * (D_P * 4u) + 16u * f4);                                   \
+      nx_y[i_] = ldg4_b(a.rn, (unsigned)nzr_ * (D_P * 4u) + 16u * f4);                                  \
     }                                                                                                   \
+    int cA_ = __builtin_amdgcn_readfirstlane(nx_c), cB_ = cA_, cC_ = cA_;                               \
+    {                                                                                                   \
+      const int prev_ = __shfl_up(nx_c, 1);                                                             \
+      unsigned hm_ = (unsigned)__ballot(half == 0 && col > 0 && nx_c != prev_ && nx_c >= 0);            \
+      if (hm_) { cB_ = __builtin_amdgcn_readlane(nx_c, __builtin_ctz(hm_)); cC_ = cB_; hm_ &= hm_ - 1; } \
+      if (hm_) cC_ = __builtin_amdgcn_readlane(nx_c, __builtin_ctz(hm_));                               \
+    }                                                                                                   \
+    const unsigned oa_ = (unsigned)max(cA_, 0) * D_P + lane, ob_ = (unsigned)max(cB_, 0) * D_P + lane;  \
+    const unsigned oc_ = (unsigned)max(cC_, 0) * D_P + lane;                                            \
+    apA = a.apos[oa_]; dvA = a.d_pc[oa_]; tfA = a.tflag[max(cA_, 0)];                                   \
+    apB = a.apos[ob_]; dvB = a.d_pc[ob_]; tfB = a.tflag[max(cB_, 0)];                                   \
+    apC = a.apos[oc_]; dvC = a.d_pc[oc_]; tfC = a.tflag[max(cC_, 0)];                                   \
   } while (0)
-  if (t0 < t1) { EBW_LOAD_ROWS(t0); EBW_LOAD_BIAS(); }
+  if (t0 < t1) {
+    EBW_LOAD_LIST(t0);
+    EBW_LOAD_ROWS(t0);
+    if (t0 + 1 < t1) EBW_LOAD_LIST(t0 + 1);
+    EBW_LOAD_BIAS();
+  }
   for (int t = t0; t < t1; ++t) {
     const int p0 = t * 32;
     const int nrows = min(32, W - p0);
     const int my_e = nx_e, my_c = nx_c;
-    // ---- stage: edge ids, P tile, bias tile
+    const int tapA = apA, tapB = apB, tapC = apC, ttfA = tfA, ttfB = tfB, ttfC = tfC;
+    const float tdvA = dvA, tdvB = dvB, tdvC = dvC;
+    // ---- stage: edge ids, P tile, bias tile (rc + rn: the forward kernel's operand order)
     if (half == 0) sE[col] = my_e;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -410,7 +442,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       pp[0] = nx_pa[k].x; pp[1] = nx_pa[k].y; pp[2] = nx_pa[k].z; pp[3] = nx_pa[k].w;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(sH + (4 * i + q4) * LD64 + 4 * f4) = nx_bias[i];
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<float4*>(sH + (4 * i + q4) * LD64 + 4 * f4) =
+          make_float4(nx_x[i].x + nx_y[i].x, nx_x[i].y + nx_y[i].y, nx_x[i].z + nx_y[i].z, nx_x[i].w + nx_y[i].w);
     wave_lds_sync();
     // ---- h1 = relu(P . Wp + (rc + rn)): the forward kernel's operation sequence (same bits)
     {
@@ -437,8 +471,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { hp[crow(r, 0) * LD64] = relu_bits(h1a[r]); hp[crow(r, 0) * LD64 + 32] = relu_bits(h1b[r]); }
     }
-    // the next tile's row records and P rows (consumed a whole tile later)
+    // the next tile's row records and P rows (its list entries arrived a tile ago); the list entries after those
     if (t + 1 < t1) EBW_LOAD_ROWS(t + 1);
+    if (t + 2 < t1) EBW_LOAD_LIST(t + 2);
     wave_lds_sync();
     // ---- segments of the tile (rows sorted by centre): wave-uniform loop
     unsigned heads;
@@ -450,78 +485,117 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
 #pragma unroll
     for (int i = 0; i < 32; ++i) dA[i] = 0.f;
     unsigned hleft = heads;
+    int seg0 = 0;                                        // index of the chunk's first detection within the tile
+    // segment index of this lane's row (lane = row): number of heads at or before it, minus one
+    const int kseg = __popc(heads & (0xffffffffu >> (31 - col))) - 1;
     while (hleft) {
-      const int lo = __builtin_ctz(hleft);
-      hleft &= hleft - 1;
-      const int hi = hleft ? __builtin_ctz(hleft) : nrows;
-      const int cseg = __builtin_amdgcn_readlane(my_c, lo);
-      // lane j: column j of this detection
-      const int ap = a.apos[(size_t)cseg * D_P + lane];
-      const float dv = a.d_pc[(size_t)cseg * D_P + lane];
-      const int tf = a.tflag[cseg];
-      const int rowj = ap - p0;
-      const bool inj = ap >= 0 && rowj >= 0 && rowj < 32;              // the column's winner is a row of this tile
-      gb2 += inj ? dv : 0.f;
-      sRJ[lane] = inj ? rowj : -1;
-      sDV[lane] = dv;
-      // d W2[:, j] += d_pc[c][j] * h1[row of the column's winner]
-      if (inj) {
-        const float* hr = sH + rowj * LD64;
+      // EBW_SLOTS detections per chunk (one chunk for nearly every tile), branch-free: a missing detection is an
+      // all-inactive slot.  Pass 1 = column records -> slots + the d W2 gathers (all requested back to back),
+      // pass 2 = d h2 rows from the slots.
+      int lo[EBW_SLOTS], hi[EBW_SLOTS], tfk[EBW_SLOTS], growk[EBW_SLOTS];
+      float dvk[EBW_SLOTS], dvm[EBW_SLOTS];
+      int tf_any = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * k);
-          w2acc[4 * k + 0] = fmaf(dv, hv.x, w2acc[4 * k + 0]);
-          w2acc[4 * k + 1] = fmaf(dv, hv.y, w2acc[4 * k + 1]);
-          w2acc[4 * k + 2] = fmaf(dv, hv.z, w2acc[4 * k + 2]);
-          w2acc[4 * k + 3] = fmaf(dv, hv.w, w2acc[4 * k + 3]);
-          if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four quads in flight (registers)
+      for (int k = 0; k < EBW_SLOTS; ++k) {
+        const bool have = hleft != 0u;                   // wave-uniform
+        lo[k] = have ? __builtin_ctz(hleft) : 0;
+        hleft &= hleft - 1;
+        hi[k] = have ? (hleft ? __builtin_ctz(hleft) : nrows) : 0;
+        // lane j: column j of this detection (the first detections of a tile were requested a tile ago)
+        int ap; float dv; int tf;
+        if (seg0 == 0) { ap = k == 0 ? tapA : k == 1 ? tapB : tapC; dv = k == 0 ? tdvA : k == 1 ? tdvB : tdvC; tf = k == 0 ? ttfA : k == 1 ? ttfB : ttfC; }
+        else {
+          const int cseg = max(__builtin_amdgcn_readlane(my_c, lo[k]), 0);
+          ap = a.apos[(size_t)cseg * D_P + lane]; dv = a.d_pc[(size_t)cseg * D_P + lane]; tf = a.tflag[cseg];
+        }
+        const int rowj = ap - p0;
+        const bool inj = have && ap >= 0 && rowj >= lo[k] && rowj < hi[k];     // the column's winner is a row of this tile
+        sRJ[k * 64 + lane] = inj ? rowj : -1;
+        sDV[k * 64 + lane] = dv;
+        growk[k] = inj ? rowj : 0; dvm[k] = inj ? dv : 0.f; dvk[k] = dv;
+        tfk[k] = have ? tf : 0; tf_any |= tfk[k];
+        gb2 += dvm[k];
+      }
+      // d W2[:, j] += d_pc[c][j] * h1[row of the column's recorded winner].  One copy of the gather (not unrolled
+      // over the slots: the register allocator cannot keep three copies' loads apart); inactive lanes add 0 * h1[0]
+      static_assert(EBW_SLOTS == 3, "slot selects below");
+#pragma unroll 1
+      for (int k = 0; k < EBW_SLOTS; ++k) {
+        const int gr = k == 0 ? growk[0] : k == 1 ? growk[1] : growk[2];
+        const float dm = k == 0 ? dvm[0] : k == 1 ? dvm[1] : dvm[2];
+        const float* hr = sH + gr * LD64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * q);
+          w2acc[4 * q + 0] = fmaf(dm, hv.x, w2acc[4 * q + 0]);
+          w2acc[4 * q + 1] = fmaf(dm, hv.y, w2acc[4 * q + 1]);
+          w2acc[4 * q + 2] = fmaf(dm, hv.z, w2acc[4 * q + 2]);
+          w2acc[4 * q + 3] = fmaf(dm, hv.w, w2acc[4 * q + 3]);
         }
       }
       wave_lds_sync();
-      // d h2 rows of this segment, A-operand layout (lane = row)
-      const bool mine = col >= lo && col < hi;
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        const int4 rj = *reinterpret_cast<const int4*>(sRJ + 4 * half + 8 * s8);
-        const float4 vv = *reinterpret_cast<const float4*>(sDV + 4 * half + 8 * s8);
-        dA[4 * s8 + 0] = rj.x == col ? vv.x : dA[4 * s8 + 0];
-        dA[4 * s8 + 1] = rj.y == col ? vv.y : dA[4 * s8 + 1];
-        dA[4 * s8 + 2] = rj.z == col ? vv.z : dA[4 * s8 + 2];
-        dA[4 * s8 + 3] = rj.w == col ? vv.w : dA[4 * s8 + 3];
-      }
-      if (tf) {
-        // tied maxima (rare): the extra winners of a column receive the same d_pc[c][j] (already divided by the count)
-        const unsigned long long xm = mine ? a.xmask[my_e] : 0ull;     // lane = row: its extra columns
+      // pass 2: d h2 rows, A-operand layout (lane = row): the row reads the slot of its own detection
+      {
+        const int ks = kseg - seg0;
+        const bool mine = col < nrows && ks >= 0 && ks < EBW_SLOTS;
+        const int slot = mine ? ks : 0;
+        const int mrow = mine ? col : -2;                // (slot entries are tile rows or -1)
+        const int* rjp = sRJ + slot * 64 + 4 * half;
+        const float* dvp = sDV + slot * 64 + 4 * half;
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
-          const float4 vv = *reinterpret_cast<const float4*>(sDV + 4 * half + 8 * s8);
-          const unsigned bits = (unsigned)(xm >> (4 * half + 8 * s8)) & 15u;
-          dA[4 * s8 + 0] = (bits & 1u) ? vv.x : dA[4 * s8 + 0];
-          dA[4 * s8 + 1] = (bits & 2u) ? vv.y : dA[4 * s8 + 1];
-          dA[4 * s8 + 2] = (bits & 4u) ? vv.z : dA[4 * s8 + 2];
-          dA[4 * s8 + 3] = (bits & 8u) ? vv.w : dA[4 * s8 + 3];
+          const int4 rj = *reinterpret_cast<const int4*>(rjp + 8 * s8);
+          const float4 vv = *reinterpret_cast<const float4*>(dvp + 8 * s8);
+          dA[4 * s8 + 0] = rj.x == mrow ? vv.x : dA[4 * s8 + 0];
+          dA[4 * s8 + 1] = rj.y == mrow ? vv.y : dA[4 * s8 + 1];
+          dA[4 * s8 + 2] = rj.z == mrow ? vv.z : dA[4 * s8 + 2];
+          dA[4 * s8 + 3] = rj.w == mrow ? vv.w : dA[4 * s8 + 3];
         }
+      }
+      if (tf_any) {
+        // tied maxima (rare): rows that are EXTRA winners of some columns receive the same d_pc[c][j] (already
+        // divided by the count).  One (not unrolled) copy of the code: slot values picked by selects.
+        static_assert(EBW_SLOTS == 3, "slot selects below");
 #pragma unroll 1
-        for (int r = lo; r < hi; ++r) {
-          const unsigned long long xr = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(xm >> 32), r) << 32) |
-                                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)xm, r);
-          if (xr == 0ull) continue;
-          if ((xr >> lane) & 1ull) {                     // lane j: column j has an extra winner in row r
-            gb2 += dv;
+        for (int k = 0; k < EBW_SLOTS; ++k) {
+          const int tfs = k == 0 ? tfk[0] : k == 1 ? tfk[1] : tfk[2];
+          if (!tfs) continue;
+          const int los = k == 0 ? lo[0] : k == 1 ? lo[1] : lo[2];
+          const int his = k == 0 ? hi[0] : k == 1 ? hi[1] : hi[2];
+          const float dvs = k == 0 ? dvk[0] : k == 1 ? dvk[1] : dvk[2];
+          const bool mine = col >= los && col < his;
+          const unsigned long long xs = mine ? a.xmask[my_e] : 0ull;     // lane = row: its extra columns
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            const float4 vv = *reinterpret_cast<const float4*>(sDV + k * 64 + 4 * half + 8 * s8);
+            const unsigned bits = (unsigned)(xs >> (4 * half + 8 * s8)) & 15u;
+            dA[4 * s8 + 0] = (bits & 1u) ? vv.x : dA[4 * s8 + 0];
+            dA[4 * s8 + 1] = (bits & 2u) ? vv.y : dA[4 * s8 + 1];
+            dA[4 * s8 + 2] = (bits & 4u) ? vv.z : dA[4 * s8 + 2];
+            dA[4 * s8 + 3] = (bits & 8u) ? vv.w : dA[4 * s8 + 3];
+          }
+#pragma unroll 1
+          for (int r = los; r < his; ++r) {
+            const unsigned long long xr = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(xs >> 32), r) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)xs, r);
+            if (xr == 0ull) continue;
+            const float dx = ((xr >> lane) & 1ull) ? dvs : 0.f;      // lane j: column j has an extra winner in row r
+            gb2 += dx;
             const float* hr = sH + r * LD64;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-              const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * k);
-              w2acc[4 * k + 0] = fmaf(dv, hv.x, w2acc[4 * k + 0]);
-              w2acc[4 * k + 1] = fmaf(dv, hv.y, w2acc[4 * k + 1]);
-              w2acc[4 * k + 2] = fmaf(dv, hv.z, w2acc[4 * k + 2]);
-              w2acc[4 * k + 3] = fmaf(dv, hv.w, w2acc[4 * k + 3]);
-              if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four quads in flight (registers)
+            for (int q = 0; q < 16; ++q) {
+              const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * q);
+              w2acc[4 * q + 0] = fmaf(dx, hv.x, w2acc[4 * q + 0]);
+              w2acc[4 * q + 1] = fmaf(dx, hv.y, w2acc[4 * q + 1]);
+              w2acc[4 * q + 2] = fmaf(dx, hv.z, w2acc[4 * q + 2]);
+              w2acc[4 * q + 3] = fmaf(dx, hv.w, w2acc[4 * q + 3]);
+              if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
       }
-      wave_lds_sync();                                   // RJ / DV are rewritten by the next segment
+      seg0 += EBW_SLOTS;
+      if (hleft) wave_lds_sync();                        // the slots are rewritten by the next chunk
     }
     // ---- g1 = (h1 > 0) * (d h2 . W2^T); overwrites h1 in place
     {
@@ -540,7 +614,6 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
         g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 2], bv1.z, g1b, 0, 0, 0);
         g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 3], bv0.w, g1a, 0, 0, 0);
         g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 3], bv1.w, g1b, 0, 0, 0);
-        if (s8 & 1) __builtin_amdgcn_sched_barrier(0);
       }
       float* hp = sH + (4 * half) * LD64 + col;          // every lane rewrites the elements it reads
 #pragma unroll
@@ -552,22 +625,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       }
     }
     wave_lds_sync();
-    // ---- g1 rows -> compact list order (whole 256-byte rows; the buffer has slack rows past W)
-    {
-      float* dst = a.g1c + (size_t)p0 * D_P;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + q4;
-        *reinterpret_cast<float4*>(dst + row * D_P + 4 * f4) = *reinterpret_cast<const float4*>(sH + row * LD64 + 4 * f4);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the next tile's bias rows and the old d_pw values of this tile's rows (accumulator layout: rows crow(r, half),
-    // column col): in flight during the d Wp / d P MFMAs
+    // the next tile's bias rows and first column records: requested BEFORE this tile's stores, in flight during the
+    // d Wp / d P MFMAs
     if (t + 1 < t1) EBW_LOAD_BIAS();
-    float dold[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dold[r] = a.d_pw[(size_t)sE[crow(r, 0) + 4 * half] * D_E + col];
     // ---- d Wp += P^T . g1
     {
       const float* X = sPt + col;
@@ -578,37 +638,47 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
         const float x = X[row * EBW_LDP];
         aWp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, Y[row * LD64], aWp0, 0, 0, 0);
         aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, Y[row * LD64 + 32], aWp1, 0, 0, 0);
-        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- d P = g1 . Wp^T;  d_pw[e] += d P
     {
       f32x16 acc = zero16();
       const float* ap = sH + col * LD64 + 4 * half;
-      const float* bp = sWpT + (4 * half) * LD32 + col;             // Wp[pf = col][f] = sWpT[f][pf]
+      const float* bp = sWp + col * LD64 + 4 * half;                // B[k = f][n = pf] = Wp[pf = col][f]
 #pragma unroll
       for (int k = 0; k < D_P; k += 8) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD32], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD32], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD32], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD32], acc, 0, 0, 0);
-        if ((k & 8) != 0) __builtin_amdgcn_sched_barrier(0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
       }
-      // rows past the list (last tile) go to the slack row E of d_pw: unconditional stores, no divergent branches
+      // rows past the list (last tile) go to the slack row E of d_pw: unconditional, no divergent branches
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int er = crow(r, half) < nrows ? sE[crow(r, 0) + 4 * half] : a.n_edge;
-        a.d_pw[(size_t)er * D_E + col] = dold[r] + acc[r];
+        const unsigned er = crow(r, half) < nrows ? (unsigned)sE[crow(r, 0) + 4 * half] : (unsigned)a.n_edge;
+        __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<char*>(a.d_pw) + (er * (D_E * 4u) + 4u * col)), acc[r],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- g1 rows -> compact list order (whole 256-byte rows; the buffer has slack rows past W)
+    {
+      float* dst = a.g1c + (size_t)p0 * D_P;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + q4;
+        *reinterpret_cast<float4*>(dst + row * D_P + 4 * f4) = *reinterpret_cast<const float4*>(sH + row * LD64 + 4 * f4);
       }
     }
     wave_lds_sync();
   }
+#undef EBW_LOAD_LIST
 #undef EBW_LOAD_ROWS
 #undef EBW_LOAD_BIAS
   // ---- partial weight gradients of this workgroup: the four waves' accumulators are added in wave order
   __syncthreads();
-  float* red = sW2 + D_P * LD64;               // the waves' tile areas: 4 * 3392 floats >= 4096 + 2048 + 64
+  float* red = sW2 + D_P * LD64;               // the waves' tile areas: 4 * 3648 floats >= 4096 + 2048 + 64
   float* redW2 = red;                          // [f][j]
   float* redWp = red + D_P * D_P;              // [2][16][64] accumulator registers
   float* redB = redWp + 2 * 16 * 64;           // [64]
