@@ -9,12 +9,11 @@
 // Kernels (launch order):
 //   head_bwd       predict/logits, fc2, fc1                       -> d_x (grad wrt block_feats[B])
 //   winners_mark + winner lists of every block (backward_edge.hip; depend on the forward pass only)
-//   per block b = B..1:
-//     blk_bwd_post  shortcut ReLU, fc2, fc1                       -> d_x := dz, d_pc = dp / tie count
-//     edge stage (backward_edge.hip), on the edges that attain a segment maximum only:
-//       edge_bwd_w       pw_fc2, pw_fc1 on 32-row tiles of winners  -> d_pw (+=), d_g1 (winner rows)
-//       gather_winners   centre / reversed-edge sums of those rows   -> d_rc, d_rn
-//     blk_bwd_pre   per-node halves of pw_fc1, reduce_dim         -> d_x := dz + drpre . Wr^T
+//   per block b = B..1, three launches:
+//     blk_bwd_node  [centre / reversed-edge sums of block b+1's g1 rows -> per-node halves of pw_fc1, reduce_dim of
+//                   block b+1 -> d_x += drpre . Wr^T] + [shortcut ReLU, fc2, fc1 of block b -> d_x := dz, d_pc]
+//     edge_bwd_w    (backward_edge.hip) pw_fc2, pw_fc1 on 32-row tiles of the winner edges -> d_pw (+=), g1 rows
+//   blk_bwd_node  once more for the first block's pre stage
 //   pw_bwd_main    pw_feats fc3, fc2 (+ d_h1 = grad wrt fc1 pre-activation), on the listed rows
 //   pw_w1_nodesums + pw_w1_classrows   pw_feats fc1 (score columns via per-detection sums, 7 geometry rows)
 //   reduce_partials  sums the per-workgroup partial weight gradients in a fixed order
@@ -134,210 +133,270 @@ __global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-struct BlkPostArgs {
+// gather_winners: d_rc[i] = sum of g1 over i's winner edges (a contiguous range of the block's compact g1 rows),
+// d_rn[i] = sum over i's edges e = (i, n), n != i (self pair: n_feats zeroed, network.py:371-374), of g1[reverse(e)]
+// when the reversed pair is a winner of n.  One wave per detection (the sums are latency / L2-bandwidth bound: 16 000
+// waves in flight; folded into the node kernel's 2 000 waves they took twice as long), four rows per
+// wave-instruction, ascending order, no atomics.
+// blk_bwd_node: the N-sized GEMMs between two edge stages of the backward chain in ONE launch:
+//   pre(b)   per-node halves of pw_fc1 and reduce_dim of block b (network.py:348-376 backward):
+//            d W1[32:96], d b1, d Wr, d br; d_x += drpre . Wr^T
+//   post(b-1) shortcut ReLU, fc2, fc1 of block b-1 (network.py:390-408 backward): d_x := dz, d W4, d b4, d W3, d b3,
+//            d_pc = dp / tie count (the SegmentMax gradient's even split, TF _SegmentMinOrMaxGrad)
+// The forward pass fuses post(b) + pre(b+1) the same way (node_fwd).  One workgroup = 64 detections, 8 waves:
+// wave = (row tile rt, role cw); the two row tiles run the same phase sequence in lock-step.
+struct BlkNodeArgs {
   int n_det;
-  float* d_x;                       // in: grad wrt block output; out: dz = d_x * (x_out > 0)
-  const float* x_out; const float* q; const unsigned long long* pm;
-  const float* w4; const float* w3; // natural [64,128], [64,64]
-  float* d_pc;
-  float* arena; long long stride;
+  int do_pre, do_post;
+  const float* d_rc; const float* d_rn;       // [N,64] gather_winners of block b (NULL: no edges)
+  // pre (block b)
+  const float* r; const float* x_prev;        // x_prev = block_feats[b-1] (NULL = zeros); also x_out of the post stage
+  const float* w1; const float* wr;           // natural [96,64] (rows 32-63 centre, 64-95 neighbour), [128,32]
+  long long o_w1, o_b1, o_wr, o_br;
+  // post (block b-1)
+  const float* q; const unsigned long long* pm;
+  const float* w4; const float* w3;           // natural [64,128], [64,64]
   long long o_w4, o_b4, o_w3, o_b3;
+  float* d_x; float* d_pc;
+  float* arena; long long stride;
 };
 
-__global__ void __launch_bounds__(256) blk_bwd_post(const BlkPostArgs a) {
-  __shared__ __attribute__((aligned(16))) float sDz[32 * LD128];
-  __shared__ __attribute__((aligned(16))) float sQ[32 * LD64];
-  __shared__ __attribute__((aligned(16))) float sP[32 * LD64];
-  __shared__ __attribute__((aligned(16))) float sDq[32 * LD64];
-  __shared__ __attribute__((aligned(16))) float sR[2 * 32 * D_P];   // K-half partials
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31, half = lane >> 5;
-  f32x16 aW4[2][1], aW3[1][1];
-  aW4[0][0] = zero16(); aW4[1][0] = zero16(); aW3[0][0] = zero16();
-  float gb4 = 0.f, gb3 = 0.f;
-  const int ntiles = (a.n_det + 31) / 32;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int row0 = t * 32;
-    __syncthreads();
-    for (int i = tid; i < 32 * (D_S / 4); i += 256) {
-      const int row = i >> 5, c4 = i & 31;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + row < a.n_det) {
-        const size_t o = (size_t)(row0 + row) * D_S + 4 * c4;
-        const float4 g = *reinterpret_cast<const float4*>(a.d_x + o);
-        const float4 x = *reinterpret_cast<const float4*>(a.x_out + o);
-        v = make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f);
-        *reinterpret_cast<float4*>(a.d_x + o) = v;      // dz: also the shortcut gradient
-      }
-      *reinterpret_cast<float4*>(sDz + row * LD128 + 4 * c4) = v;
-    }
-    load_tile<D_P, LD64>(sQ, a.q, row0, a.n_det, tid, 256);
-    for (int i = tid; i < 32 * D_P; i += 256) {
-      const int row = i >> 6, ff = i & 63;
-      float v = 0.f;
-      if (row0 + row < a.n_det) {
-        const size_t o = (size_t)(row0 + row) * D_P + ff;
-        v = __uint_as_float((unsigned)(a.pm[o] >> 32));
-      }
-      sP[row * LD64 + ff] = v;
-    }
-    __syncthreads();
-    // d W4 += q^T . dz : wave w owns output column tile w
-    {
-      f32x16 (&acc)[2][1] = aW4;
-      const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + h;
-        const float x0 = sQ[row * LD64 + r], x1 = sQ[row * LD64 + 32 + r];
-        const float y = sDz[row * LD128 + 32 * wave + r];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, acc[1][0], 0, 0, 0);
-      }
-    }
-    if (tid < D_S) gb4 += col_sum32(sDz, LD128, tid);
-    // dq = (dz . W4^T) * (q > 0): wave = (column tile, K half)
-    {
-      const int nt = wave & 1, kh = wave >> 1;
-      f32x16 acc = zero16();
-      mma_abt<64>(acc, sDz + 64 * kh, LD128, a.w4 + (size_t)(32 * nt) * D_S + 64 * kh, D_S, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
-    }
-    __syncthreads();
-    for (int i = tid; i < 32 * D_P; i += 256) {
-      const int row = i >> 6, ff = i & 63;
-      const float v = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
-      sDq[row * LD64 + ff] = sQ[row * LD64 + ff] > 0.f ? v : 0.f;
-    }
-    __syncthreads();
-    // d W3 += p^T . dq : wave = (mi, nj)
-    {
-      const int mi = wave >> 1, nj = wave & 1;
-      const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + h;
-        aW3[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[row * LD64 + 32 * mi + r], sDq[row * LD64 + 32 * nj + r],
-                                                         aW3[0][0], 0, 0, 0);
-      }
-    }
-    if (tid < D_P) gb3 += col_sum32(sDq, LD64, tid);
-    // dp = dq . W3^T : wave = (column tile, K half)
-    {
-      const int nt = wave & 1, kh = wave >> 1;
-      f32x16 acc = zero16();
-      mma_abt<32>(acc, sDq + 32 * kh, LD64, a.w3 + (size_t)(32 * nt) * D_P + 32 * kh, D_P, lane);
-      __syncthreads();   // sR of the dq step fully consumed
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
-    }
-    __syncthreads();
-    for (int i = tid; i < 32 * D_P; i += 256) {
-      const int row = i >> 6, ff = i & 63;
-      if (row0 + row < a.n_det) {
-        const size_t o = (size_t)(row0 + row) * D_P + ff;
-        const float dp = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
-        const unsigned cnt = (unsigned)(a.pm[o] & 0xffffffffull);
-        a.d_pc[o] = dp / (float)cnt;                     // weighted_grads = grad / num_selected
-      }
-    }
-  }
-  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
-  store_acc(ar + a.o_w4 + 32 * wave, D_S, aW4[0][0], lane);
-  store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * wave, D_S, aW4[1][0], lane);
-  store_acc(ar + a.o_w3 + (size_t)(32 * (wave >> 1)) * D_P + 32 * (wave & 1), D_P, aW3[0][0], lane);
-  if (tid < D_S) ar[a.o_b4 + tid] = gb4;
-  if (tid < D_P) ar[a.o_b3 + tid] = gb3;
+constexpr int BN_RT_FLOATS = 2 * 32 * LD128 + 2 * 32 * LD64 + 2 * 32 * LD32 + 4 * 32 * 32;   // per row tile: X, DZ, Rc|Rn, Rr|Dr, Part
+constexpr size_t kBlkNodeSmem = (size_t)(2 * BN_RT_FLOATS) * sizeof(float);
+
+__device__ __forceinline__ unsigned long long bn_low_mask(int bit) { return bit ? (~0ull >> (64 - bit)) : 0ull; }
+__device__ __forceinline__ int bn_winner_pos(const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix, int e) {
+  const int w = e >> 6;
+  return wprefix[w] + __popcll(ewin[w] & bn_low_mask(e & 63));
 }
 
-// ------------------------------------------------------------------------------------------
-struct BlkPreArgs {
-  int n_det;
-  int write_dx;                     // block > 1: d_x += drpre . Wr^T
-  const float* d_rc; const float* d_rn; const float* r; const float* x_prev;   // x_prev NULL = zeros
-  const float* w1;                  // natural [96,64]; rows 32-63 centre, 64-95 neighbour
-  const float* wr;                  // natural [128,32]
-  float* d_x;
-  float* arena; long long stride;
-  long long o_w1, o_b1, o_wr, o_br;
-};
-
-__global__ void __launch_bounds__(256) blk_bwd_pre(const BlkPreArgs a) {
-  __shared__ __attribute__((aligned(16))) float sRc[32 * LD64];
-  __shared__ __attribute__((aligned(16))) float sRn[32 * LD64];
-  __shared__ __attribute__((aligned(16))) float sRr[32 * LD32];
-  __shared__ __attribute__((aligned(16))) float sDr[32 * LD32];
-  __shared__ __attribute__((aligned(16))) float sX[32 * LD128];
-  __shared__ __attribute__((aligned(16))) float sPart[4 * 32 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31, half = lane >> 5;
-  f32x16 aWcn = zero16(), aWr = zero16();
-  float gb1 = 0.f, gbr = 0.f;
-  const int ntiles = (a.n_det + 31) / 32;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int row0 = t * 32;
-    __syncthreads();
-    load_tile<D_P, LD64>(sRc, a.d_rc, row0, a.n_det, tid, 256);
-    load_tile<D_P, LD64>(sRn, a.d_rn, row0, a.n_det, tid, 256);
-    load_tile<D_R, LD32>(sRr, a.r, row0, a.n_det, tid, 256);
-    if (a.x_prev) load_tile<D_S, LD128>(sX, a.x_prev, row0, a.n_det, tid, 256);
-    else for (int i = tid; i < 32 * LD128; i += 256) sX[i] = 0.f;
-    __syncthreads();
-    // dr = drc . Wc^T + drn . Wn^T : wave = (term, K half)
-    {
-      const int term = wave & 1, kh = wave >> 1;
-      f32x16 acc = zero16();
-      mma_abt<32>(acc, (term ? sRn : sRc) + 32 * kh, LD64, a.w1 + (size_t)(32 + 32 * term) * D_P + 32 * kh, D_P, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sPart[(wave * 32 + crow(r, half)) * 32 + col] = acc[r];
+__global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ g1c, const int* __restrict__ row_ptr,
+                                                      const int* __restrict__ edge_n, const int* __restrict__ edge_t,
+                                                      const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix,
+                                                      int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n_det) return;
+  const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
+  const int eb = row_ptr[node], ee = row_ptr[node + 1];
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
+  const int p0 = bn_winner_pos(ewin, wprefix, eb), p1 = bn_winner_pos(ewin, wprefix, ee);
+  for (int p = p0 + sub; p < p1; p += 4) {
+    const float4 c = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
+    sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+  }
+  for (int base = eb; base < ee; base += 64) {
+    const int el = base + lane;
+    int tp = -1;                                            // list position of the reversed pair, if it is a winner
+    if (el < ee && edge_n[el] != node) {
+      const int t = edge_t[el];
+      if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp = bn_winner_pos(ewin, wprefix, t);
     }
-    // d Wc += r^T . drc ; d Wn += r^T . drn : wave = (term, column tile)
-    {
-      const int term = wave >> 1, nj = wave & 1;
-      const float* Y = term ? sRn : sRc;
-      const int r = lane & 31, h = lane >> 5;
+    unsigned long long mr = __ballot(tp >= 0);
+    while (mr) {
+      int j = -1;
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + h;
-        aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(sRr[row * LD32 + r], Y[row * LD64 + 32 * nj + r], aWcn, 0, 0, 0);
-      }
-    }
-    if (tid < D_P) gb1 += col_sum32(sRc, LD64, tid);
-    __syncthreads();
-    for (int i = tid; i < 32 * D_R; i += 256) {
-      const int row = i >> 5, ff = i & 31;
-      float v = sPart[(0 * 32 + row) * 32 + ff] + sPart[(1 * 32 + row) * 32 + ff];
-      v += sPart[(2 * 32 + row) * 32 + ff];
-      v += sPart[(3 * 32 + row) * 32 + ff];
-      sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? v : 0.f;    // ReLU of reduce_dim
-    }
-    __syncthreads();
-    // d Wr += x_prev^T . drpre : wave w owns rows [32w, 32w+32) of Wr
-    {
-      const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + h;
-        aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * wave + r], sDr[row * LD32 + r], aWr, 0, 0, 0);
-      }
-    }
-    if (tid < D_R) gbr += col_sum32(sDr, LD32, tid);
-    if (a.write_dx) {
-      f32x16 acc = zero16();
-      mma_abt<D_R>(acc, sDr, LD32, a.wr + (size_t)(32 * wave) * D_R, D_R, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int node = row0 + crow(r, half);
-        if (node < a.n_det) a.d_x[(size_t)node * D_S + 32 * wave + col] += acc[r];
+      for (int q = 0; q < 4; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if (q == sub) j = b; } }
+      const int p = __shfl(tp, j < 0 ? 0 : j);
+      if (j >= 0) {
+        const float4 v = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
+        sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
       }
     }
   }
-  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
-  store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (wave >> 1)) * D_P + 32 * (wave & 1), D_P, aWcn, lane);
-  store_acc(ar + a.o_wr + (size_t)(32 * wave) * D_R, D_R, aWr, lane);
-  if (tid < D_P) ar[a.o_b1 + tid] = gb1;
-  if (tid < D_R) ar[a.o_br + tid] = gbr;
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    sc.x += __shfl_xor(sc.x, o); sc.y += __shfl_xor(sc.y, o); sc.z += __shfl_xor(sc.z, o); sc.w += __shfl_xor(sc.w, o);
+    sn.x += __shfl_xor(sn.x, o); sn.y += __shfl_xor(sn.y, o); sn.z += __shfl_xor(sn.z, o); sn.w += __shfl_xor(sn.w, o);
+  }
+  if (sub == 0) {
+    *reinterpret_cast<float4*>(d_rc + (size_t)node * D_P + 4 * f4) = sc;
+    *reinterpret_cast<float4*>(d_rn + (size_t)node * D_P + 4 * f4) = sn;
+  }
+}
+
+__global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 2, cw = wave & 3, lt = tid & 255;       // row tile, role within the row tile, thread within it
+  const int col = lane & 31, half = lane >> 5;
+  float* base = smem + rt * BN_RT_FLOATS;
+  float* sX = base;                          // [32][132] x_prev (= block_feats[b-1])
+  float* sDZ = sX + 32 * LD128;              // [32][132] d_x tile: dz of block b, then dz of block b-1
+  float* sRc = sDZ + 32 * LD128;             // [32][68]  d_rc          | post: q
+  float* sRn = sRc + 32 * LD64;              // [32][68]  d_rn          | post: p (segment max)
+  float* sRr = sRn + 32 * LD64;              // [32][36]  r             | post: dq [32][68] over Rr + Dr
+  float* sDr = sRr + 32 * LD32;              // [32][36]  drpre
+  float* sPart = sDr + 32 * LD32;            // [4][32][32] K-split partials | post: [2][32][64]
+  float* sQ = sRc; float* sP = sRn; float* sDq = sRr; float* sR = sPart;
+  f32x16 aWcn = zero16(), aWr = zero16(), aW4a = zero16(), aW4b = zero16(), aW3 = zero16();
+  float gb1 = 0.f, gbr = 0.f, gb4 = 0.f, gb3 = 0.f;
+  const int ntiles = (a.n_det + 63) / 64;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int row0 = t * 64 + 32 * rt;                    // first detection of this row tile
+    __syncthreads();
+    // ---- tiles from HBM: x_prev, d_x, r
+    if (a.x_prev) load_tile<D_S, LD128>(sX, a.x_prev, row0, a.n_det, lt, 256);
+    else for (int i = lt; i < 32 * LD128; i += 256) sX[i] = 0.f;
+    if (a.do_post || a.do_pre) load_tile<D_S, LD128>(sDZ, a.d_x, row0, a.n_det, lt, 256);
+    if (a.do_pre) {
+      load_tile<D_R, LD32>(sRr, a.r, row0, a.n_det, lt, 256);
+      if (a.d_rc) { load_tile<D_P, LD64>(sRc, a.d_rc, row0, a.n_det, lt, 256); load_tile<D_P, LD64>(sRn, a.d_rn, row0, a.n_det, lt, 256); }
+      else { for (int i = lt; i < 2 * 32 * LD64; i += 256) sRc[i] = 0.f; }      // no edges
+    }
+    __syncthreads();
+    if (a.do_pre) {
+      // dr = drc . Wc^T + drn . Wn^T : role = (term, K half)
+      {
+        const int term = cw & 1, kh = cw >> 1;
+        f32x16 acc = zero16();
+        mma_abt<32>(acc, (term ? sRn : sRc) + 32 * kh, LD64, a.w1 + (size_t)(32 + 32 * term) * D_P + 32 * kh, D_P, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sPart[(cw * 32 + crow(r, half)) * 32 + col] = acc[r];
+      }
+      // d Wc += r^T . drc ; d Wn += r^T . drn : role = (term, column tile)
+      {
+        const int term = cw >> 1, nj = cw & 1;
+        const float* Y = term ? sRn : sRc;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int row = 2 * kk + half;
+          aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(sRr[row * LD32 + col], Y[row * LD64 + 32 * nj + col], aWcn, 0, 0, 0);
+        }
+      }
+      if (lt < D_P) gb1 += col_sum32(sRc, LD64, lt);
+      __syncthreads();
+      for (int i = lt; i < 32 * D_R; i += 256) {
+        const int row = i >> 5, ff = i & 31;
+        float v = sPart[(0 * 32 + row) * 32 + ff] + sPart[(1 * 32 + row) * 32 + ff];
+        v += sPart[(2 * 32 + row) * 32 + ff];
+        v += sPart[(3 * 32 + row) * 32 + ff];
+        sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? v : 0.f;    // ReLU of reduce_dim
+      }
+      __syncthreads();
+      // d Wr += x_prev^T . drpre : role cw owns rows [32 cw, 32 cw + 32) of Wr
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + half;
+        aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDr[row * LD32 + col], aWr, 0, 0, 0);
+      }
+      if (lt < D_R) gbr += col_sum32(sDr, LD32, lt);
+      if (a.do_post) {
+        // d_x += drpre . Wr^T (columns [32 cw, 32 cw + 32))
+        f32x16 acc = zero16();
+        mma_abt<D_R>(acc, sDr, LD32, a.wr + (size_t)(32 * cw) * D_R, D_R, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sDZ[crow(r, half) * LD128 + 32 * cw + col] += acc[r];
+      }
+      __syncthreads();
+    }
+    if (a.do_post) {
+      // dz = d_x * (x_out > 0): also the shortcut gradient of block b-1 (network.py:407-408)
+      for (int i = lt; i < 32 * (D_S / 4); i += 256) {
+        const int row = i >> 5, c4 = i & 31;
+        const float4 g = *reinterpret_cast<const float4*>(sDZ + row * LD128 + 4 * c4);
+        const float4 x = *reinterpret_cast<const float4*>(sX + row * LD128 + 4 * c4);
+        const float4 v = make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f);
+        *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = v;
+        if (row0 + row < a.n_det) *reinterpret_cast<float4*>(a.d_x + (size_t)(row0 + row) * D_S + 4 * c4) = v;
+      }
+      load_tile<D_P, LD64>(sQ, a.q, row0, a.n_det, lt, 256);
+      for (int i = lt; i < 32 * D_P; i += 256) {
+        const int row = i >> 6, ff = i & 63;
+        float v = 0.f;
+        if (row0 + row < a.n_det) v = __uint_as_float((unsigned)(a.pm[(size_t)(row0 + row) * D_P + ff] >> 32));
+        sP[row * LD64 + ff] = v;
+      }
+      __syncthreads();
+      // d W4 += q^T . dz : role cw owns output column tile cw
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + half;
+        const float x0 = sQ[row * LD64 + col], x1 = sQ[row * LD64 + 32 + col];
+        const float y = sDZ[row * LD128 + 32 * cw + col];
+        aW4a = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, aW4a, 0, 0, 0);
+        aW4b = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, aW4b, 0, 0, 0);
+      }
+      if (lt < D_S) gb4 += col_sum32(sDZ, LD128, lt);
+      // dq = (dz . W4^T) * (q > 0): role = (column tile, K half)
+      {
+        const int nt = cw & 1, kh = cw >> 1;
+        f32x16 acc = zero16();
+        mma_abt<64>(acc, sDZ + 64 * kh, LD128, a.w4 + (size_t)(32 * nt) * D_S + 64 * kh, D_S, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
+      }
+      __syncthreads();
+      for (int i = lt; i < 32 * D_P; i += 256) {
+        const int row = i >> 6, ff = i & 63;
+        const float v = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
+        sDq[row * LD64 + ff] = sQ[row * LD64 + ff] > 0.f ? v : 0.f;
+      }
+      __syncthreads();
+      // d W3 += p^T . dq : role = (mi, nj)
+      {
+        const int mi = cw >> 1, nj = cw & 1;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int row = 2 * kk + half;
+          aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[row * LD64 + 32 * mi + col], sDq[row * LD64 + 32 * nj + col], aW3, 0, 0, 0);
+        }
+      }
+      if (lt < D_P) gb3 += col_sum32(sDq, LD64, lt);
+      // dp = dq . W3^T : role = (column tile, K half)
+      {
+        const int nt = cw & 1, kh = cw >> 1;
+        f32x16 acc = zero16();
+        mma_abt<32>(acc, sDq + 32 * kh, LD64, a.w3 + (size_t)(32 * nt) * D_P + 32 * kh, D_P, lane);
+        __syncthreads();   // sR of the dq step fully consumed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
+      }
+      __syncthreads();
+      for (int i = lt; i < 32 * D_P; i += 256) {
+        const int row = i >> 6, ff = i & 63;
+        if (row0 + row < a.n_det) {
+          const size_t o = (size_t)(row0 + row) * D_P + ff;
+          const float dp = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
+          const unsigned cnt = (unsigned)(a.pm[o] & 0xffffffffull);
+          a.d_pc[o] = dp / (float)cnt;                     // weighted_grads = grad / num_selected
+        }
+      }
+    }
+  }
+  // ---- partial weight gradients of this workgroup: row tile 1 is added to row tile 0 (fixed order), then stored
+  __syncthreads();
+  float* red = smem;                           // [80][256] accumulator registers of row tile 1 + [4][256] bias sums
+  if (rt == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      red[(r) * 256 + lt] = aWcn[r]; red[(16 + r) * 256 + lt] = aWr[r]; red[(32 + r) * 256 + lt] = aW4a[r];
+      red[(48 + r) * 256 + lt] = aW4b[r]; red[(64 + r) * 256 + lt] = aW3[r];
+    }
+    red[80 * 256 + lt] = gb1; red[81 * 256 + lt] = gbr; red[82 * 256 + lt] = gb4; red[83 * 256 + lt] = gb3;
+  }
+  __syncthreads();
+  if (rt == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      aWcn[r] += red[(r) * 256 + lt]; aWr[r] += red[(16 + r) * 256 + lt]; aW4a[r] += red[(32 + r) * 256 + lt];
+      aW4b[r] += red[(48 + r) * 256 + lt]; aW3[r] += red[(64 + r) * 256 + lt];
+    }
+    gb1 += red[80 * 256 + lt]; gbr += red[81 * 256 + lt]; gb4 += red[82 * 256 + lt]; gb3 += red[83 * 256 + lt];
+    float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+    if (a.do_pre) {
+      store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aWcn, lane);
+      store_acc(ar + a.o_wr + (size_t)(32 * cw) * D_R, D_R, aWr, lane);
+      if (lt < D_P) ar[a.o_b1 + lt] = gb1;
+      if (lt < D_R) ar[a.o_br + lt] = gbr;
+    }
+    if (a.do_post) {
+      store_acc(ar + a.o_w4 + 32 * cw, D_S, aW4a, lane);
+      store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * cw, D_S, aW4b, lane);
+      store_acc(ar + a.o_w3 + (size_t)(32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aW3, lane);
+      if (lt < D_S) ar[a.o_b4 + lt] = gb4;
+      if (lt < D_P) ar[a.o_b3 + lt] = gb3;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -683,8 +742,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into the [E,64] fp32 arrays
   void* prof = buf->profiler;
   const long long stride = L.total;
-  const int ntile_n = (N + 31) / 32;
-  const int g_node = min(ntile_n, 256);
+  const int g_node = min((N + 63) / 64, 256);                                           // node-kernel workgroups (64 detections each)
+  const int g_head = min((N + 31) / 32, 256);
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? 256 : 0;                                                  // edge_bwd_w workgroups (one per CU)
   const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
@@ -709,34 +768,38 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     h.hw1 = params + L.hw1; h.hw2 = params + L.hw2; h.hwl = params + L.hwl;
     h.d_x = buf->d_x; h.arena = buf->arena; h.stride = stride;
     h.o_hw1 = L.hw1; h.o_hb1 = L.hb1; h.o_hw2 = L.hw2; h.o_hb2 = L.hb2; h.o_hwl = L.hwl; h.o_hbl = L.hbl;
-    GNET_LAUNCH(prof, GNET_K_HEAD_BWD, s, head_bwd<<<g_node, 256, 0, s>>>(h));
+    GNET_LAUNCH(prof, GNET_K_HEAD_BWD, s, head_bwd<<<g_head, 256, 0, s>>>(h));
   }
-  for (int b = B; b >= 1; --b) {
-    const BlockLayout& K = L.blk[b];
-    {
-      BlkPostArgs p;
-      p.n_det = N; p.d_x = buf->d_x; p.x_out = buf->block_feats[b]; p.q = buf->blk_q[b];
-      p.pm = (const unsigned long long*)buf->blk_pm[b];
-      p.w4 = params + K.w4; p.w3 = params + K.w3;
-      p.d_pc = buf->d_pc;
-      p.arena = buf->arena; p.stride = stride; p.o_w4 = K.w4; p.o_b4 = K.b4; p.o_w3 = K.w3; p.o_b3 = K.b3;
-      GNET_LAUNCH(prof, GNET_K_BLK_POST, s, blk_bwd_post<<<g_node, 256, 0, s>>>(p));
+  // backward chain: node(post B) -> edge(B) -> node(pre B + post B-1) -> edge(B-1) -> ... -> node(pre 1)
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  for (int b = B + 1; b >= 1; --b) {
+    // node stage: pre of block b (b <= B), post of block b-1 (b >= 2)
+    BlkNodeArgs n;
+    n.n_det = N; n.do_pre = b <= B; n.do_post = b >= 2;
+    n.d_rc = E > 0 ? buf->d_rc : nullptr; n.d_rn = E > 0 ? buf->d_rn : nullptr;
+    if (b <= B && E > 0) {
+      GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
+          buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, (const unsigned long long*)buf->ewin + (size_t)(b - 1) * G.bm_stride,
+          buf->wprefix + (size_t)(b - 1) * G.bm_stride, N, buf->d_rc, buf->d_rn));
     }
-    if (E > 0) {
-      const int st = edge_stage_block(cfg, shape, L, params, b, buf, g_edge, s);
+    n.x_prev = b >= 2 ? buf->block_feats[b - 1] : nullptr;
+    if (b <= B) {
+      const BlockLayout& K = L.blk[b];
+      n.r = buf->blk_r[b]; n.w1 = params + K.w1; n.wr = params + K.wr;
+      n.o_w1 = K.w1; n.o_b1 = K.b1; n.o_wr = K.wr; n.o_br = K.br;
+    } else { n.r = nullptr; n.w1 = n.wr = nullptr; n.o_w1 = n.o_b1 = n.o_wr = n.o_br = 0; }
+    if (b >= 2) {
+      const BlockLayout& K = L.blk[b - 1];
+      n.q = buf->blk_q[b - 1]; n.pm = (const unsigned long long*)buf->blk_pm[b - 1];
+      n.w4 = params + K.w4; n.w3 = params + K.w3;
+      n.o_w4 = K.w4; n.o_b4 = K.b4; n.o_w3 = K.w3; n.o_b3 = K.b3;
+    } else { n.q = nullptr; n.pm = nullptr; n.w4 = n.w3 = nullptr; n.o_w4 = n.o_b4 = n.o_w3 = n.o_b3 = 0; }
+    n.d_x = buf->d_x; n.d_pc = buf->d_pc; n.arena = buf->arena; n.stride = stride;
+    GNET_LAUNCH(prof, b <= B ? GNET_K_BLK_PRE : GNET_K_BLK_POST, s, blk_bwd_node<<<g_node, 512, kBlkNodeSmem, s>>>(n));
+    // edge stage of block b-1
+    if (b >= 2 && E > 0) {
+      const int st = edge_stage_block(cfg, shape, L, params, b - 1, buf, g_edge, s);
       if (st != GNET_OK) return st;
-    } else {
-      HIP_CHECK_RET(hipMemsetAsync(buf->d_rc, 0, (size_t)N * D_P * sizeof(float), s));
-      HIP_CHECK_RET(hipMemsetAsync(buf->d_rn, 0, (size_t)N * D_P * sizeof(float), s));
-    }
-    {
-      BlkPreArgs p;
-      p.n_det = N; p.write_dx = b > 1;
-      p.d_rc = buf->d_rc; p.d_rn = buf->d_rn; p.r = buf->blk_r[b];
-      p.x_prev = b > 1 ? buf->block_feats[b - 1] : nullptr;
-      p.w1 = params + K.w1; p.wr = params + K.wr; p.d_x = buf->d_x;
-      p.arena = buf->arena; p.stride = stride; p.o_w1 = K.w1; p.o_b1 = K.b1; p.o_wr = K.wr; p.o_br = K.br;
-      GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, blk_bwd_pre<<<g_node, 256, 0, s>>>(p));
     }
   }
   if (E > 0) {
@@ -764,7 +827,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     r.w1c_end = (long long)2 * L.cprime * D_H; r.pw1_end = L.pw2; r.pw_end = L.blk[1].wr;
     r.blk_sz = (B > 1) ? (L.blk[2].wr - L.blk[1].wr) : (L.hw1 - L.blk[1].wr);
     r.nblocks = B;
-    r.n_w1c = g_w1c; r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_node;
+    r.n_w1c = g_w1c; r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_head;
     r.grads = grads;
     GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 255) / 256), 256, 0, s>>>(r));
   }

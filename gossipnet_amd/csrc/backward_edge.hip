@@ -21,7 +21,8 @@
 //                     g1   = (h1 > 0) * (d h2 . W2^T)     64 MFMAs, d h2 built in A-operand registers
 //                     dP   = g1 . Wp^T, dWp += P^T . g1   (32 + 32 MFMAs)
 //                   160 MFMAs per 32 rows instead of 224 for the dense-on-winner-rows formulation.
-//   gather_winners  d_rc / d_rn: centre sums (a contiguous range of the compact g1 rows) and reversed-pair sums
+//   (d_rc / d_rn -- centre sums over a contiguous range of the compact g1 rows, reversed-pair sums -- are taken
+//   inside the next node kernel, backward.hip blk_bwd_node)
 // No float atomics, static work assignment: gradients stay bitwise reproducible.
 #include "common.hpp"
 #include "backward_edge.hpp"
@@ -704,54 +705,6 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
   if (tid < D_P) ar[a.o_b2 + tid] = redB[tid];
 }
 
-// ------------------------------------------------------------------------------------------
-// d_rc[i] = sum of g1 over i's winner edges (a contiguous range of the list);  d_rn[i] = sum over i's edges
-// e = (i, n), n != i (self pair: n_feats zeroed, network.py:371-374), of g1[reverse(e)] when the reversed pair
-// is a winner of n.  One wave per detection, four rows per wave-instruction, ascending order (no atomics).
-__global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ g1c, const int* __restrict__ row_ptr,
-                                                      const int* __restrict__ edge_n, const int* __restrict__ edge_t,
-                                                      const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix,
-                                                      int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= n_det) return;
-  const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
-  const int eb = row_ptr[node], ee = row_ptr[node + 1];
-  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
-  const int p0 = winner_pos(ewin, wprefix, eb), p1 = winner_pos(ewin, wprefix, ee);
-  for (int p = p0 + sub; p < p1; p += 4) {
-    const float4 c = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
-    sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
-  }
-  for (int base = eb; base < ee; base += 64) {
-    const int el = base + lane;
-    int tp = -1;                                            // list position of the reversed pair, if it is a winner
-    if (el < ee && edge_n[el] != node) {
-      const int t = edge_t[el];
-      if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp = winner_pos(ewin, wprefix, t);
-    }
-    unsigned long long mr = __ballot(tp >= 0);
-    while (mr) {
-      int j = -1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if (q == sub) j = b; } }
-      const int p = __shfl(tp, j < 0 ? 0 : j);
-      if (j >= 0) {
-        const float4 v = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
-        sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {
-    sc.x += __shfl_xor(sc.x, o); sc.y += __shfl_xor(sc.y, o); sc.z += __shfl_xor(sc.z, o); sc.w += __shfl_xor(sc.w, o);
-    sn.x += __shfl_xor(sn.x, o); sn.y += __shfl_xor(sn.y, o); sn.z += __shfl_xor(sn.z, o); sn.w += __shfl_xor(sn.w, o);
-  }
-  if (sub == 0) {
-    *reinterpret_cast<float4*>(d_rc + (size_t)node * D_P + 4 * f4) = sc;
-    *reinterpret_cast<float4*>(d_rn + (size_t)node * D_P + 4 * f4) = sn;
-  }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -817,8 +770,5 @@ int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const Para
   e.d_pw = buf->d_pw; e.g1c = buf->d_g1;
   e.arena = buf->arena; e.stride = L.total; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
   GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_w<<<n_partials, 64 * EBW_WAVES, kEdgeBwdWSmem, s>>>(e));
-  GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
-      buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, (const unsigned long long*)buf->ewin + (size_t)(b - 1) * G.bm_stride,
-      buf->wprefix + (size_t)(b - 1) * G.bm_stride, N, buf->d_rc, buf->d_rn));
   return GNET_OK;
 }
