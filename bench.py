@@ -13,15 +13,24 @@ One "step" = one pass of the hot path over one batch of `--images` synthetic ima
 Inputs are resident in HBM before the timed region.  value = detections/sec over all ranks.
 
 The JSON line also carries
-  roofline     : the dominant kernel class (by HIP-event time inside the timed region), its
-                 algorithmic FLOPs per launch (SURVEY 8d formulas) / its average launch duration,
-                 against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-  cpu_baseline : the CPU oracle (oracle/gnet_oracle.py, a port of the reference TF-CPU path)
-                 timed on this host on a bounded sample (rank 0, N=1 only)
+  roofline      the dominant kernel class (by HIP-event time inside the timed region): nominal FLOPs of the
+                reference's algorithm per launch / average launch duration against the fp32 MFMA peak
+                (157.3 TFLOP/s, MI355X_MICROARCH.md) = `frac`; `executed_tflops` / `executed_frac` = the MFMA
+                FLOPs the kernel really issues (the restructured math executes fewer); `traffic` = HBM bytes per
+                launch from the separate rocprofv3 --pmc passes (profiles/r02_traffic.json), reported only while
+                that file was collected from the same kernel sources (hash), else null
+  hbm           the HBM-bound kernel classes: algorithmic bytes per launch / average launch duration vs 8 TB/s
+  executed      whole-step MFMA FLOPs really issued and their fraction of the fp32 MFMA peak
+  other_configs the other BASELINE configurations and the reference's own step shape (1 image/step), measured
+                in the same run (rank 0, 1 GPU only): detections/s, E/N, ms/step
+  cpu_baseline  the CPU oracle (oracle/gnet_oracle.py, a port of the reference TF-CPU path) timed on this host on
+                bounded samples, all cores and one thread (rank 0, N=1 only), with the lscpu model string
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,9 +42,20 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def algorithmic_flops(cls, E, N, C):
+def kernel_source_hash():
+    """Identity of the kernel sources the library was built from (profiles/*_traffic.json carries the same)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gossipnet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def nominal_flops(cls, E, N, C):
     """Nominal (reference-algorithm) FLOPs of one launch of kernel class `cls` (2 per MAC)."""
     dpw = 2 * (C if C > 1 else 1) + 7
     table = {
@@ -44,10 +64,38 @@ def algorithmic_flops(cls, E, N, C):
         "node_fwd": 2.0 * N * (128 * 32 + 64 * 64 + 64 * 128),
         "edge_bwd": 4.0 * E * (96 * 64 + 64 * 64),
         "pw_bwd_main": 4.0 * E * (256 * 256 + 256 * 32),
-        "pw_bwd_w1": 2.0 * E * dpw * 256,
-        "blk_bwd_post": 4.0 * N * (64 * 64 + 64 * 128),
-        "blk_bwd_pre": 4.0 * N * (128 * 32),
+        "node_bwd": 4.0 * N * (128 * 32 + 64 * 64 + 64 * 128),
         "head_bwd": 4.0 * N * (2 * 128 * 128 + 128),
+    }
+    return table.get(cls)
+
+
+def executed_mfma_flops(cls, E, N, winners_per_block, pw_rows):
+    """MFMA FLOPs one launch really issues (4096 per v_mfma_f32_32x32x2_f32), from the kernels' tile loops:
+    edge_fwd_w 96 MFMAs per 32 edges (pw_fc1 split P.Wp + rc[c] + rn[n]); edge_bwd_w 160 MFMAs per 32 winner rows;
+    pw_fwd fc2 + fc3 (fc1 runs on the vector ALU through its one-hot structure); pw_bwd_main 4 GEMMs per listed row."""
+    table = {
+        "edge_fwd": 96 * 4096.0 * E / 32,
+        "edge_bwd": 160 * 4096.0 * winners_per_block / 32,
+        "pw_fwd": 2.0 * E * (256 * 256 + 256 * 32),
+        "pw_bwd_main": 2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32),
+        "node_fwd": 2.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128),
+        "node_bwd": 4.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128),
+        "head_bwd": 4.0 * N * (2 * 128 * 128),
+    }
+    return table.get(cls)
+
+
+def algorithmic_bytes(cls, E, N, B, winners_per_block, pw_rows, n_params):
+    """Compulsory HBM bytes of one launch of the HBM-bound kernel classes."""
+    table = {
+        # own + reversed winner rows of the compact g1 array (256 B each), d_rc / d_rn out
+        "gather_winners": 2.0 * 256 * winners_per_block + 2.0 * 256 * N + 12.0 * E,
+        # d_h1 rows that carry gradient: once (own pairs) + once (reversed pairs), geometry columns, S / T out
+        "pw_w1_nodesums": 2.0 * 1024 * pw_rows + 32.0 * pw_rows + 2.0 * 1024 * N + 4.0 * E,
+        # arg-max / tie records of every block in, winner bitmaps / lists / positions out
+        "winner_lists": B * (N * 64 * (8 + 8 + 8 + 4) + 4.0 * winners_per_block + E / 4.0),
+        "reduce_partials": None,   # filled by the caller (arena size)
     }
     return table.get(cls)
 
@@ -60,21 +108,67 @@ def step_flops(E, N, C, B=16):
     return 3.0 * fwd - 2.0 * E * dpw * 256
 
 
-def cpu_baseline(images, num_classes, num_blocks, budget_s):
+def lscpu_model():
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        d = dict((l.split(":", 1)[0].strip(), l.split(":", 1)[1].strip()) for l in out.splitlines() if ":" in l)
+        return {"model": d.get("Model name"), "sockets": d.get("Socket(s)"), "cores_per_socket": d.get("Core(s) per socket"),
+                "threads_per_core": d.get("Thread(s) per core"), "cpus": d.get("CPU(s)")}
+    except Exception as exc:      # noqa: BLE001
+        return {"model": None, "error": str(exc)}
+
+
+def cpu_baseline(make, num_classes, num_blocks, budget_s):
+    """oracle/gnet_oracle.py (kind "port") on the host cores: one full-size image of the bench workload, fwd+bwd, with
+    1 thread, 16 threads and all hardware threads (torch's intra-op pool); `value` = the fastest of them (the op mix
+    -- gathers, segment reductions, small GEMMs -- does not scale with threads), every run listed under `runs`."""
     from oracle import gnet_oracle as go
     orc = go.GnetOracle(num_classes, num_blocks)
-    n_done, dets, t_total = 0, 0, 0.0
-    for im in images:
-        t0 = time.perf_counter()
-        orc.forward_backward(im)
-        dt = time.perf_counter() - t0
-        t_total += dt
-        n_done += 1
-        dets += im["dets"].shape[0]
-        if t_total > budget_s:
-            break
-    return {"value": dets / t_total, "unit": "detections/sec", "cores": int(torch.get_num_threads()),
-            "kind": "port", "sample": "%d image(s) of the same workload, fwd+bwd, torch-CPU fp32 oracle, %.1f s" % (n_done, t_total)}
+    all_threads = int(torch.get_num_threads())
+    im = make(0, None)
+    runs, spent = [], 0.0
+    try:
+        for nt in sorted({1, min(16, all_threads), all_threads}):
+            if spent > 2.0 * budget_s:
+                break
+            torch.set_num_threads(nt)
+            t0 = time.perf_counter()
+            out, _ = orc.forward_backward(im)
+            dt = time.perf_counter() - t0
+            spent += dt
+            runs.append({"threads": nt, "value": round(im["dets"].shape[0] / dt, 2), "seconds": round(dt, 2)})
+    finally:
+        torch.set_num_threads(all_threads)
+    best = max(runs, key=lambda r: r["value"])
+    n, e = im["dets"].shape[0], len(out["neighbor_pair_idxs"])
+    return {"value": best["value"], "unit": "detections/sec", "cores": best["threads"], "kind": "port",
+            "sample": "1 image of the bench workload (N=%d, E/N=%.1f), fwd+bwd, torch-CPU fp32 oracle, %.1f s in total"
+                      % (n, e / n, spent),
+            "runs": runs, "cpu": lscpu_model()}
+
+
+def time_config(dev, classes, blocks, dets, images, preset, steps, warmup):
+    """detections/s of one configuration on one GPU (no kernel timing)."""
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet, DeviceBatch
+    from gossipnet_amd.synthetic import make_image
+    reset_cfg()
+    cfg.gnet.num_blocks = blocks
+    net = Gnet(classes, device=dev)
+    batch = DeviceBatch([make_image(dets, classes, seed=1000 + i, preset=preset) for i in range(images)], dev)
+    for _ in range(warmup):
+        net.run(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.run(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    e = int(net.num_edges)
+    del net
+    return {"detections_per_sec": round(dets * images * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "edges_per_det": round(e / (dets * images), 2), "dets_per_image": dets, "images_per_step": images,
+            "num_classes": classes, "num_blocks": blocks, "preset": preset, "steps": steps}
 
 
 def main():
@@ -89,8 +183,7 @@ def main():
     ap.add_argument("--preset", default="dense", choices=["dense", "coco_like"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1, help="split the step's images over this many streams "
-                    "(replica Gnets sharing the variables): overlaps MFMA-bound and HBM-bound kernels")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,58 +203,50 @@ def main():
     from gossipnet_amd.config import cfg, reset_cfg
     from gossipnet_amd.network import Gnet, DeviceBatch
     from gossipnet_amd.synthetic import make_image
-    from gossipnet_amd.data_parallel import allreduce_gradients
+    from gossipnet_amd.data_parallel import allreduce_gradients, broadcast_parameters, shard_images
     reset_cfg()
     cfg.gnet.num_blocks = args.blocks
     net = Gnet(args.classes, device=dev)
-    nets = [net] + [Gnet(args.classes, device=dev, reuse=True) for _ in range(args.lanes - 1)]
-    for n_ in nets:   # gradient of the mean over all images of the global batch
-        n_.grad_scale = 1.0 / (args.images * world)
+    if dist is not None:
+        broadcast_parameters(net.params, dist)             # replicas start from rank 0's parameters
+    net.grad_scale = 1.0 / (args.images * world)           # gradient of the mean over the global batch
 
-    images = [make_image(args.dets, args.classes, seed=rank * args.images + i, preset=args.preset) for i in range(args.images)]
-    # inputs resident in HBM before the timed region
-    batches = [DeviceBatch(images[l::args.lanes], dev) for l in range(args.lanes)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.lanes)] if args.lanes > 1 else [None]
+    # the global step's images (seeds 0 .. images*world-1), dealt to the ranks by edge count (cost ~ E, not N)
+    n_global = args.images * world
+    gen = lambda seed, n=None: make_image(n or args.dets, args.classes, seed=seed, preset=args.preset)
+    if world > 1:
+        all_imgs = [gen(i) for i in range(n_global)]
+        costs = [float(Gnet.count_edges(im["dets"], dev)) for im in all_imgs]
+        images = shard_images(all_imgs, rank, world, costs=costs, per_rank=args.images)
+    else:
+        images = [gen(i) for i in range(args.images)]
+    batch = DeviceBatch(images, dev)                       # inputs resident in HBM before the timed region
+    side = torch.cuda.Stream(device=dev) if dist is not None else None
 
     def step():
-        if args.lanes == 1:
-            net.run(batches[0])
-        else:
-            main_s = torch.cuda.current_stream(dev)
-            for n_, b_, s_ in zip(nets, batches, streams):
-                s_.wait_stream(main_s)
-                with torch.cuda.stream(s_):
-                    n_.begin(b_)
-            for n_, s_ in zip(nets, streams):
-                with torch.cuda.stream(s_):
-                    n_.run()
-            for n_, s_ in zip(nets[1:], streams[1:]):
-                main_s.wait_stream(s_)
-            main_s.wait_stream(streams[0])
-            for n_ in nets[1:]:
-                net.grads.add_(n_.grads)
+        net.run(batch)
         if dist is not None:
-            allreduce_gradients(net.grads, dist)
+            # the one collective of a step, on a side stream behind reduce_partials
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                allreduce_gradients(net.grads, dist)
+            torch.cuda.current_stream(dev).wait_stream(side)
 
     for _ in range(args.warmup):
         step()
-    E = sum(int(n_.num_edges) for n_ in nets)
-    # Per-kernel HIP events cost ~4% of the step when every launch is bracketed (~230 launches), so the timed
+    E = int(net.num_edges)
+    N_local = int(net.num_dets)
+    # Per-kernel HIP events cost ~4% of the step when every launch is bracketed (~150 launches), so the timed
     # region brackets only the DOMINANT kernel class (picked from one fully instrumented, untimed step);
     # the complete per-class table is measured in a second, untimed pass after the timed region.
     dominant = None
     if not args.no_kernel_timing:
-        for n_ in nets:
-            n_.enable_kernel_timing(classes=None, capacity=512)
+        net.enable_kernel_timing(classes=None, capacity=512)
         step()
         torch.cuda.synchronize()
-        probe = {}
-        for n_ in nets:
-            for k_, (ms_, c_) in n_.read_kernel_timing().items():
-                probe[k_] = probe.get(k_, 0.0) + ms_
+        probe = {k_: ms_ for k_, (ms_, c_) in net.read_kernel_timing().items()}
         dominant = max(probe.items(), key=lambda kv: kv[1])[0]
-        for n_ in nets:
-            n_.enable_kernel_timing(classes=[dominant], capacity=(args.steps + 1) * 64)
+        net.enable_kernel_timing(classes=[dominant], capacity=(args.steps + 1) * 64)
 
     torch.cuda.synchronize()
     if dist is not None:
@@ -179,50 +264,83 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        et = torch.tensor([E], dtype=torch.float64, device=dev)
+        et = torch.tensor([E, N_local], dtype=torch.float64, device=dev)
         dist.all_reduce(et)
-        e_total = float(et.item())
+        e_total, dets_per_step = float(et[0].item()), int(et[1].item())
     else:
-        e_total = float(E)
-
-    dets_per_step = args.dets * args.images * world
+        e_total, dets_per_step = float(E), N_local
     value = dets_per_step * args.steps / elapsed
 
-    roofline = None
-    timing = {}
-    table = {}
+    roofline, hbm, executed = None, None, None
+    table, counts = {}, {}
     if not args.no_kernel_timing:
-        for n_ in nets:
-            for k_, (ms_, c_) in n_.read_kernel_timing().items():
-                pm_, pc_ = timing.get(k_, (0.0, 0))
-                timing[k_] = (pm_ + ms_, pc_ + c_)
-        # second pass (untimed): every class, for the kernel_ms_per_step table
+        timing = net.read_kernel_timing()
         table_steps = min(args.steps, 5)
-        for n_ in nets:
-            n_.enable_kernel_timing(classes=None, capacity=(table_steps + 1) * 256)
+        net.enable_kernel_timing(classes=None, capacity=(table_steps + 1) * 256)
         for _ in range(table_steps):
             step()
         torch.cuda.synchronize()
-        for n_ in nets:
-            for k_, (ms_, c_) in n_.read_kernel_timing().items():
-                table[k_] = table.get(k_, 0.0) + ms_ / table_steps
-        N_local = args.dets * args.images
+        for k_, (ms_, c_) in net.read_kernel_timing().items():
+            table[k_] = ms_ / table_steps
+            counts[k_] = c_ // table_steps
+        stats = net.backward_stats()          # winner rows per block (mean), rows of the pw-MLP backward
+        wpb, pw_rows = stats["winners_per_block"], stats["pw_rows"]
+        n_params = int(net.params.numel())
         dom = max(timing.items(), key=lambda kv: kv[1][0]) if timing else None
         if dom is not None:
             cls, (ms, cnt) = dom
-            fl = algorithmic_flops(cls, E / args.lanes, N_local / args.lanes, args.classes)
+            fl = nominal_flops(cls, E, N_local, args.classes)
+            ex = executed_mfma_flops(cls, E, N_local, wpb, pw_rows)
             if fl is not None:
                 avg_s = ms / cnt * 1e-3
                 ach = fl / avg_s / 1e12
-                traffic = None
-                tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
-                if os.path.exists(tf) and args.dets == 2000 and args.images == 8 and args.preset == "dense" and args.classes == 80:
-                    # HBM bytes per launch from a separate rocprofv3 --pmc run of this same workload
-                    traffic = json.load(open(tf))["kernels"].get(cls, {}).get("hbm_bytes")
+                traffic, note = None, None
+                if os.path.exists(TRAFFIC_FILE):
+                    tf = json.load(open(TRAFFIC_FILE))
+                    same = (tf.get("kernel_source_hash") == kernel_source_hash() and tf.get("workload") ==
+                            [args.dets, args.images, args.classes, args.blocks, args.preset])
+                    if same:
+                        traffic = tf["kernels"].get(cls, {}).get("hbm_bytes")
+                    else:
+                        note = "profiles/r02_traffic.json was collected from other kernel sources / another workload: not reported"
                 roofline = {"bound": "mfma", "kernel": cls, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                            "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
-                            "flops_per_launch": fl}
+                            "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt, "flops_per_launch": fl,
+                            "nominal": "FLOPs of the reference's algorithm (SURVEY 8d); see executed_*",
+                            "executed_flops_per_launch": ex,
+                            "executed_tflops": round(ex / avg_s / 1e12, 3) if ex else None,
+                            "executed_frac": round(ex / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ex else None}
+                if note:
+                    roofline["traffic_note"] = note
+        # whole-step executed MFMA FLOPs
+        ex_total = 0.0
+        for k_, c_ in counts.items():
+            e_ = executed_mfma_flops(k_, E, N_local, wpb, pw_rows)
+            if e_:
+                ex_total += e_ * c_
+        step_s = elapsed / args.steps
+        executed = {"mfma_tflop_per_step": round(ex_total / 1e12, 4),
+                    "tflops": round(ex_total / step_s / 1e12, 3),
+                    "frac_fp32_mfma_peak": round(ex_total / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "winner_rows_per_block_over_E": round(wpb / max(E, 1), 4), "pw_rows_over_E": round(pw_rows / max(E, 1), 4)}
+        # HBM-bound classes
+        kernels = {}
+        for k_ in ("gather_winners", "pw_w1_nodesums", "winner_lists", "reduce_partials"):
+            if k_ not in table or not counts.get(k_):
+                continue
+            by = algorithmic_bytes(k_, E, N_local, args.blocks, wpb, pw_rows, n_params)
+            if k_ == "reduce_partials":
+                by = float(stats["arena_bytes_read"])
+            # winner_lists = 7 different kernels: its bytes are per step, the others' per launch
+            per_step = by if k_ == "winner_lists" else by * counts[k_]
+            gbs = per_step / (table[k_] * 1e-3) / 1e9
+            kernels[k_] = {"bytes_per_step": round(per_step), "ms_per_step": round(table[k_], 4), "launches_per_step": counts[k_],
+                           "gb_per_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if kernels:
+            worst = min(kernels.items(), key=lambda kv: kv[1]["frac"])[0]
+            hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes": "algorithmic (compulsory) bytes per launch", "kernels": kernels,
+                   "worst": worst,
+                   "whole_step_gb_per_s": round((8712.0 * E + 45156.0 * N_local) / step_s / 1e9, 1)}
 
     if rank == 0:
         out = {
@@ -234,16 +352,29 @@ def main():
                                    "%d images/step/GPU (configs[4] per-GPU share), %d blocks" % (args.preset, args.images, args.blocks),
                        "dets_per_image": args.dets, "images_per_step_per_gpu": args.images, "num_classes": args.classes,
                        "num_blocks": args.blocks, "edges_per_step_all_gpus": e_total,
-                       "edges_per_det": round(e_total / dets_per_step, 2), "parallelism": "dp%d" % world, "lanes_per_gpu": args.lanes,
-                       "step": "graph build + fwd + matching/loss + bwd" + (" + RCCL all-reduce" if world > 1 else "")},
-            "whole_step": {"note": "nominal = FLOPs of the reference's dense algorithm (SURVEY 8d); the sparse SegmentMax backward executes fewer",
-                           "nominal_tflops": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * world * args.steps / elapsed / 1e12, 3),
-                           "frac_fp32_mfma_peak": round(step_flops(E, args.dets * args.images, args.classes, args.blocks) * args.steps / elapsed / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+                       "edges_per_det": round(e_total / dets_per_step, 2), "parallelism": "dp%d" % world,
+                       "image_assignment": "longest-processing-time by edge count" if world > 1 else "all images on the one GPU",
+                       "step": "graph build + fwd + matching/loss + bwd" + (" + RCCL all-reduce (side stream)" if world > 1 else "")},
+            "whole_step": {"note": "nominal = FLOPs of the reference's dense algorithm (SURVEY 8d); `executed` = MFMA FLOPs really issued",
+                           "nominal_tflops": round(step_flops(e_total, dets_per_step, args.classes, args.blocks) * args.steps / elapsed / 1e12, 3),
+                           "nominal_frac_fp32_mfma_peak_per_gpu": round(step_flops(e_total, dets_per_step, args.classes, args.blocks) / world * args.steps / elapsed / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roofline,
+            "executed": executed,
+            "hbm": hbm,
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(table.items(), key=lambda kv: -kv[1])},
+            "kernel_launches_per_step": counts,
         }
+        if world == 1 and not args.no_other_configs:
+            del batch
+            net.release_workspace()
+            oc = {}
+            oc["configs[1] coco_person N=1000 C=1, 8 images/step"] = time_config(dev, 1, 16, 1000, 8, "dense", 10, 3)
+            oc["configs[2] N=2000 C=80, 1 image/step (the reference's step shape, train.py:115)"] = time_config(dev, 80, 16, 2000, 1, "dense", 20, 5)
+            oc["configs[2] N=2000 C=80, 8 images/step, coco_like preset"] = time_config(dev, 80, 16, 2000, 8, "coco_like", 10, 3)
+            oc["configs[3] dense N=10000 C=80, 1 image/step"] = time_config(dev, 80, 16, 10000, 1, "dense", 5, 2)
+            out["other_configs"] = oc
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(images, args.classes, args.blocks, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(gen, args.classes, args.blocks, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -28,7 +28,7 @@ class gnet_config(C.Structure):
                 ("shortcut_dim", C.c_int32), ("reduced_dim", C.c_int32), ("pairfeat_dim", C.c_int32),
                 ("pwfeat_dim", C.c_int32), ("pwfeat_narrow_dim", C.c_int32),
                 ("num_pwfeat_fc", C.c_int32), ("predict_fc_dim", C.c_int32), ("num_predict_fc", C.c_int32),
-                ("num_block_pw_fc", C.c_int32), ("num_block_fc", C.c_int32)]
+                ("num_block_pw_fc", C.c_int32), ("num_block_fc", C.c_int32), ("pw_feat_multiplyer", C.c_float)]
 
 
 class gnet_shape(C.Structure):
@@ -59,8 +59,8 @@ EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_grap
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
            "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm"]
 
-KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "blk_bwd_post", "edge_bwd", "blk_bwd_pre",
-            "pw_bwd_main", "pw_bwd_w1", "reduce_partials"]
+KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
+            "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials"]
 
 _lib = None
 
@@ -70,14 +70,22 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        # not a fallback: the same HIP sources, compiled on the spot when hipcc is available
+    from . import build as _build
+    stale = False
+    if os.path.exists(LIB_PATH):
         try:
-            from . import build as _build
+            stale = open(LIB_PATH + ".srchash").read().strip() != _build.source_hash()
+        except OSError:
+            stale = True
+    if stale or not os.path.exists(LIB_PATH):
+        # not a fallback: the same HIP sources, compiled on the spot when hipcc is available (a library built from
+        # other sources than the ones in the tree is rebuilt rather than silently used)
+        try:
             _build.build()
         except Exception as exc:      # noqa: BLE001
-            raise GnetError("libgossipnet_hip.so is missing (%s) and could not be built (%s): run "
-                            "`python -m gossipnet_amd.build` -- there is no CPU fallback" % (LIB_PATH, exc))
+            raise GnetError("libgossipnet_hip.so is %s (%s) and could not be built (%s): run "
+                            "`python -m gossipnet_amd.build` -- there is no CPU fallback"
+                            % ("stale" if stale else "missing", LIB_PATH, exc))
     # torch bundles its own HIP runtime: it must be mapped first so that this library binds to the
     # same libamdhip64 as the streams/allocations it is handed (loading /opt/rocm's copy first breaks launches)
     import torch  # noqa: F401

@@ -18,6 +18,18 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """Identity of the sources a library is built from (written next to the .so; _lib.load() checks it)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    for f in files:
+        h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "gossipnet_hip.h"), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "backward_edge.hpp"),
@@ -45,6 +57,8 @@ def build(force=False, verbose=False):
     if procs or force or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)
+    with open(LIB + ".srchash", "w") as f:
+        f.write(source_hash())
     return LIB
 
 

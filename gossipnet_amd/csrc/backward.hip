@@ -578,6 +578,7 @@ struct PwW1Args {
   float* arena; long long stride;
   long long o_w1, o_b1;
   int nchunks;
+  float mult;                       // cfg.gnet.pw_feat_multiplyer: the score columns of the features carry it too
 };
 
 __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
@@ -668,7 +669,7 @@ __global__ void __launch_bounds__(256) pw_w1_classrows(const PwW1Args a) {
   for (int base = i0; base < i1; base += 64) {
     const int i = base + lane;
     const bool valid = i < i1;
-    const float sc = valid ? a.scores[i] : 0.f;
+    const float sc = valid ? a.scores[i] * a.mult : 0.f;     // (x * 1.0f is exact)
     const bool member = valid && (!a.multiclass || a.classes[i] - 1 == k);
     unsigned long long mask = __ballot(member);
     while (mask) {
@@ -778,7 +779,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     n.n_det = N; n.do_pre = b <= B; n.do_post = b >= 2;
     n.d_rc = E > 0 ? buf->d_rc : nullptr; n.d_rn = E > 0 ? buf->d_rn : nullptr;
     if (b <= B && E > 0) {
-      GNET_LAUNCH(prof, GNET_K_BLK_PRE, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
+      GNET_LAUNCH(prof, GNET_K_GATHER, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
           buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, (const unsigned long long*)buf->ewin + (size_t)(b - 1) * G.bm_stride,
           buf->wprefix + (size_t)(b - 1) * G.bm_stride, N, buf->d_rc, buf->d_rn));
     }
@@ -795,7 +796,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       n.o_w4 = K.w4; n.o_b4 = K.b4; n.o_w3 = K.w3; n.o_b3 = K.b3;
     } else { n.q = nullptr; n.pm = nullptr; n.w4 = n.w3 = nullptr; n.o_w4 = n.o_b4 = n.o_w3 = n.o_b3 = 0; }
     n.d_x = buf->d_x; n.d_pc = buf->d_pc; n.arena = buf->arena; n.stride = stride;
-    GNET_LAUNCH(prof, b <= B ? GNET_K_BLK_PRE : GNET_K_BLK_POST, s, blk_bwd_node<<<g_node, 512, kBlkNodeSmem, s>>>(n));
+    GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<<<g_node, 512, kBlkNodeSmem, s>>>(n));
     // edge stage of block b-1
     if (b >= 2 && E > 0) {
       const int st = edge_stage_block(cfg, shape, L, params, b - 1, buf, g_edge, s);
@@ -817,9 +818,9 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     w.row_ptr = buf->row_ptr; w.edge_t = buf->edge_t; w.geo = buf->geo; w.d_h1 = buf->d_h1;
     w.scores = in->det_scores; w.classes = in->det_classes; w.eany = eany;
     w.w1_s = buf->w1_s; w.w1_t = buf->w1_t;
-    w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1; w.nchunks = g_w1c;
-    GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_w1_nodesums<<<g_w1, 256, 0, s>>>(w));
-    GNET_LAUNCH(prof, GNET_K_PW_W1, s, pw_w1_classrows<<<dim3(2 * L.cprime, g_w1c), 256, 0, s>>>(w));
+    w.arena = buf->arena; w.stride = stride; w.o_w1 = L.pw1; w.o_b1 = L.pb1; w.nchunks = g_w1c; w.mult = cfg->pw_feat_multiplyer;
+    GNET_LAUNCH(prof, GNET_K_W1_SUMS, s, pw_w1_nodesums<<<g_w1, 256, 0, s>>>(w));
+    GNET_LAUNCH(prof, GNET_K_W1_CLASS, s, pw_w1_classrows<<<dim3(2 * L.cprime, g_w1c), 256, 0, s>>>(w));
   }
   {
     ReduceArgs r;

@@ -724,23 +724,23 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
     w.rc[b - 1] = buf->blk_rc[b]; w.rn[b - 1] = buf->blk_rn[b];
     w.w1t[b - 1] = pt + L.blk[b].w1; w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
   }
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winners_ties<<<dim3(min((N + 3) / 4, 256), B), 256, 0, s>>>(w));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_ties<<<dim3(min((N + 3) / 4, 256), B), 256, 0, s>>>(w));
   ListArgs l;
   l.n_words = (int)G.n_words; l.n_edge = E; l.n_wg = (int)G.n_wg; l.n_lists = B + 1;
   l.bm_stride = (long long)G.bm_stride; l.wl_stride = (long long)G.wl_stride;
   l.bits = (const unsigned long long*)buf->ewin;
   l.wg_count = buf->rl_scratch; l.wg_off = buf->rl_scratch + (size_t)(B + 1) * G.n_wg;
   l.rows = buf->wlist; l.rows_any = buf->pw_rows; l.wprefix = buf->wprefix;
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, ewin_or<<<(int)((G.n_words + 255) / 256), 256, 0, s>>>((unsigned long long*)buf->ewin, (long long)G.bm_stride, B, (int)G.n_words));
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, list_count<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, list_scan<<<B + 1, 1024, 0, s>>>(l));
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, list_fill<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, ewin_or<<<(int)((G.n_words + 255) / 256), 256, 0, s>>>((unsigned long long*)buf->ewin, (long long)G.bm_stride, B, (int)G.n_words));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, list_count<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, list_scan<<<B + 1, 1024, 0, s>>>(l));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, list_fill<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
   PosArgs p;
   p.n_det = N; p.bm_stride = (long long)G.bm_stride; p.ap_stride = (long long)G.ap_stride;
   p.ewin = (const unsigned long long*)buf->ewin; p.wprefix = buf->wprefix; p.apos = buf->apos;
   for (int b = 1; b <= B; ++b) p.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
-  GNET_LAUNCH(prof, GNET_K_BLK_POST, s, winner_positions<<<dim3(min((N * D_P + 255) / 256, 1024), B), 256, 0, s>>>(p));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_positions<<<dim3(min((N * D_P + 255) / 256, 1024), B), 256, 0, s>>>(p));
   return GNET_OK;
 }
 

@@ -68,6 +68,7 @@ struct GeoArgs {
   int4* einfo;      // [E]    (fc1 row of c's score column, fc1 row of n's score column, score_c, score_n)
   int* edge_nz;     // [E+64] n, or n_det for self pairs (their neighbour features are zeroed, network.py:371-374) and the tail
   int n_det;
+  float mult;       // cfg.gnet.pw_feat_multiplyer (network.py:199-200: the whole feature row times it)
 };
 
 // _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns are kept
@@ -100,9 +101,10 @@ __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
     if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
   }
   float4* gp = reinterpret_cast<float4*>(a.geo + (size_t)e * 8);
-  gp[0] = make_float4(a.edge_iou[e], xd, yd, l2);
-  gp[1] = make_float4(wd, hd, ad, 0.f);
-  a.einfo[e] = make_int4(rc, rn, __float_as_int(sc), __float_as_int(sn));
+  const float m = a.mult;                   // x * 1.0f is exact: the default changes no bit
+  gp[0] = make_float4(a.edge_iou[e] * m, xd * m, yd * m, l2 * m);
+  gp[1] = make_float4(wd * m, hd * m, ad * m, 0.f);
+  a.einfo[e] = make_int4(rc, rn, __float_as_int(sc * m), __float_as_int(sn * m));
   a.edge_nz[e] = c == n ? a.n_det : n;
 }
 
@@ -777,7 +779,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.n_edge = E; g.edge_c = buf->edge_c; g.edge_n = buf->edge_n; g.edge_iou = buf->edge_iou;
     g.dets = (const float4*)in->dets; g.scores = in->det_scores; g.classes = in->det_classes;
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
-    g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N;
+    g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
     GNET_LAUNCH(prof, GNET_K_PW_FWD, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
     a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.einfo = (const int4*)buf->einfo;

@@ -7,17 +7,21 @@ semantics (gradient = mean over the images of the global batch) are set through 
 import torch
 
 
-def shard_images(images, rank, world, costs=None):
+def shard_images(images, rank, world, costs=None, per_rank=None):
     """Deal the images of a global step to ranks.  With per-image costs (edge counts), use the
-    longest-processing-time rule so that ranks get balanced edge totals (cost is ~ E, not N)."""
+    longest-processing-time rule so that ranks get balanced edge totals (cost is ~ E, not N);
+    per_rank caps the number of images a rank may take (equal image counts: weak scaling)."""
     if costs is None:
         return images[rank::world]
-    order = sorted(range(len(images)), key=lambda i: -costs[i])
+    order = sorted(range(len(images)), key=lambda i: (-costs[i], i))
     loads = [0.0] * world
+    taken = [0] * world
     mine = []
     for i in order:
-        r = min(range(world), key=lambda k: (loads[k], k))
+        open_ranks = [k for k in range(world) if per_rank is None or taken[k] < per_rank] or list(range(world))
+        r = min(open_ranks, key=lambda k: (loads[k], k))
         loads[r] += costs[i]
+        taken[r] += 1
         if r == rank:
             mine.append(i)
     return [images[i] for i in sorted(mine)]

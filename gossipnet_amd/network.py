@@ -154,7 +154,7 @@ class Gnet(object):
             num_classes, g.num_blocks, g.neighbor_thresh, int(bool(cfg.train.normalize_loss)),
             float(cfg.train.loss_multiplyer), g.shortcut_dim, g.reduced_dim, g.pairfeat_dim, g.pwfeat_dim,
             g.pwfeat_narrow_dim, g.num_pwfeat_fc, g.predict_fc_dim, g.num_predict_fc, g.num_block_pw_fc,
-            g.num_block_fc)
+            g.num_block_fc, float(g.pw_feat_multiplyer))
         n = self._lib.gnet_param_count(C.byref(self._cfg))
         if n < 0:
             _lib.check(int(n), "gnet_param_count")
@@ -195,7 +195,8 @@ class Gnet(object):
         self._shape = None
         self._row_ptr_tmp = None
         self._scratch_tmp = None
-        self.grad_scale = 1.0
+        self.grad_scale = 1.0      # scale of the data-loss gradient (1 / images of the global step: mean over images)
+        self.reg_scale = 1.0       # scale of the l2-regulariser gradient (1 / world size under a SUM all-reduce)
         # tests / debugging: keep the per-block pw_fc1 activations [E,64] in HBM (Gnet.debug_view("blk_h1", ...));
         # the default training path recomputes them for the rows the backward pass needs
         self.keep_edge_activations = False
@@ -293,12 +294,17 @@ class Gnet(object):
         through reuse=True, each on its own stream) can be begun before any of them is finished, so that the
         one host sync of a step (reading the edge count) of one lane overlaps the kernels of the others."""
         db = self.feed(batch) if batch is not None else self._dbatch
-        self._count_graph(db)
+        with torch.cuda.device(self.device):
+            self._count_graph(db)
         self._begun = True
         return self
 
     def run(self, batch=None, training=None, backward=None):
         """One evaluation of the graph = the reference's sess.run.  training=None -> GT present."""
+        with torch.cuda.device(self.device):       # kernels launch on the current device: make it this net's
+            return self._run(batch, training, backward)
+
+    def _run(self, batch, training, backward):
         if batch is not None or not getattr(self, "_begun", False):
             self.begin(batch)
         self._begun = False
@@ -322,11 +328,58 @@ class Gnet(object):
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                              C.byref(buf), _vp(self.grads), s), "gnet_backward")
                 if self.weight_reg:
-                    # slim get_total_loss adds sum(l2_regularizer(scale)(w)) -> d/dw = scale * w (train.py:231-238)
-                    self.grads.addcmul_(self.params, self._reg_mask, value=float(self.weight_reg) * float(self.grad_scale))
+                    # slim get_total_loss adds sum(l2_regularizer(scale)(w)) -> d/dw = scale * w (train.py:231-238),
+                    # ONCE per optimisation step whatever the number of images in it: not scaled by grad_scale.
+                    # Under data parallelism every rank adds reg_scale = 1 / world of it (the all-reduce sums).
+                    self.grads.addcmul_(self.params, self._reg_mask, value=float(self.weight_reg) * float(self.reg_scale))
         return self
 
     # ------------------------------------------------------------------ measurement
+    @staticmethod
+    def count_edges(dets, device):
+        """Number of neighbour pairs (incl. self pairs) of one image: pass 1 of the graph build only.  The cost of an
+        image is ~ its edge count, not its detection count: used to balance images over ranks."""
+        lib = _lib.load()
+        device = torch.device(device)
+        d = torch.as_tensor(np.ascontiguousarray(np.asarray(dets, np.float32).reshape(-1, 4))).to(device)
+        n = int(d.shape[0])
+        if n == 0:
+            return 0
+        off = torch.tensor([0, n], dtype=torch.int32, device=device)
+        row_ptr = torch.empty(n + 1, dtype=torch.int32, device=device)
+        scratch = torch.empty(n + 1024, dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            s = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(lib.gnet_graph_count(_vp(d), n, _vp(off), 1, float(cfg.gnet.neighbor_thresh), _vp(row_ptr), _vp(scratch), s),
+                       "gnet_graph_count")
+        return int(row_ptr[n].item())
+
+    def release_workspace(self):
+        self._ws = None
+        self._buf = None
+
+    def backward_stats(self):
+        """Sizes the sparse backward pass worked on in the last run (device counters read back; measurement only):
+        mean winner rows per block, rows of the pw-MLP backward, bytes reduce_partials read."""
+        E, N, B = int(self.num_edges), int(self.num_dets), self.num_blocks
+        if E == 0:
+            return {"winners_per_block": 0.0, "pw_rows": 0, "arena_bytes_read": 0}
+        n_words = (E + 63) // 64
+        n_wg = (n_words + 1 + 255) // 256
+        rl = self.debug_view("rl_scratch", (B + 1) * (2 * n_wg + 1), dtype=torch.int32).cpu().numpy()
+        off = rl[(B + 1) * n_wg:].reshape(B + 1, n_wg + 1)
+        totals = off[:, n_wg]
+        cp = self.num_classes if self.num_classes > 1 else 1
+        n = int(self.params.numel())
+        g_w1c = max(1, min(128, 256 // (2 * cp))); g_w1 = max(1, min(512, (N + 3) // 4)); g_pw = min((E + 31) // 32, 512)
+        g_edge, g_node, g_head = 256, min((N + 63) // 64, 256), min((N + 31) // 32, 256)
+        w1c = 2 * cp * 256; pw1 = (2 * cp + 7) * 256 + 256; pw = pw1 + 256 * 256 + 256 + 256 * 32 + 32
+        blk = 128 * 32 + 32 + 96 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 * 128 + 128
+        edge_p = 32 * 64 + 64 * 64 + 64
+        head = n - pw - B * blk
+        reads = w1c * g_w1c + (pw1 - w1c) * g_w1 + (pw - pw1) * g_pw + B * (edge_p * g_edge + (blk - edge_p) * g_node) + head * g_head
+        return {"winners_per_block": float(totals[:B].mean()), "pw_rows": int(totals[B]), "arena_bytes_read": int(reads) * 4}
+
     def enable_kernel_timing(self, classes=None, capacity=4096):
         """HIP-event timing of the selected kernel classes (names in _lib.KCLASSES) on the launch stream."""
         mask = 0

@@ -29,8 +29,11 @@ class LearningRate(object):
 
 
 class ExponentialMovingAverage(object):
-    """tf.train.ExponentialMovingAverage(decay) without num_updates (train.py:263-272): shadow starts
-    at the first value; shadow -= (1 - decay) * (shadow - value)."""
+    """tf.train.ExponentialMovingAverage(decay) without num_updates, applied to loss TENSORS (train.py:263-272).
+    For a Tensor (not a Variable) TF of that era creates a ZEROS slot and does not debias, so the smoothed
+    losses start at (1 - decay) * value and ramp up; shadow -= (1 - decay) * (shadow - value).  (Stated from the
+    TF <= 1.0 source as remembered -- TensorFlow is not installable here to confirm; only the displayed loss
+    depends on it.)"""
 
     def __init__(self, decay=0.7):
         self.decay = decay
@@ -39,7 +42,8 @@ class ExponentialMovingAverage(object):
     def apply(self, **values):
         for k, v in values.items():
             v = float(v)
-            self.shadow[k] = v if k not in self.shadow else self.shadow[k] - (1.0 - self.decay) * (self.shadow[k] - v)
+            old = self.shadow.get(k, 0.0)
+            self.shadow[k] = old - (1.0 - self.decay) * (old - v)
         return dict(self.shadow)
 
     def average(self, name):
@@ -70,6 +74,9 @@ class Optimizer(object):
         p = lambda t: C.c_void_p(t.data_ptr())
         n = net.params.numel()
         if self.clip > 0:
+            if grad_scale != 1.0:          # clip_gradient_norm acts on the gradient the optimizer sees: scale first
+                net.grads.mul_(float(grad_scale))
+                grad_scale = 1.0
             _lib.check(self.lib.gnet_clip_by_norm(p(net.grads), p(self._offs), self._ntensors, self.clip, s),
                        "gnet_clip_by_norm")
         self.global_step += 1
@@ -82,10 +89,15 @@ class Optimizer(object):
 
 
 def train_step(net, opt, batch, lr, dist=None):
-    """One iteration of train.py:316-320: forward + loss (+ l2) + backward [+ all-reduce] + update."""
+    """One iteration of train.py:316-320: forward + loss (+ l2) + backward [+ all-reduce] + update.
+    Under data parallelism (dist) the caller sets net.grad_scale = 1 / (images of the global step); the l2
+    regulariser is added once per step: every rank contributes 1 / world of it to the SUM all-reduce."""
+    if dist is not None:
+        net.reg_scale = 1.0 / dist.get_world_size()
     net.run(batch)
     if dist is not None:
         from .data_parallel import allreduce_gradients
         allreduce_gradients(net.grads, dist)
-    opt.apply_gradients(lr)
+    with torch.cuda.device(net.device):
+        opt.apply_gradients(lr)
     return net.loss

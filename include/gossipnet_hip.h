@@ -51,6 +51,7 @@ typedef struct gnet_config {
   float loss_multiplyer;   /* cfg.train.loss_multiplyer                          */
   int32_t shortcut_dim, reduced_dim, pairfeat_dim, pwfeat_dim, pwfeat_narrow_dim;
   int32_t num_pwfeat_fc, predict_fc_dim, num_predict_fc, num_block_pw_fc, num_block_fc;
+  float pw_feat_multiplyer; /* cfg.gnet.pw_feat_multiplyer: factor on every _geometry_feats column (network.py:199-200) */
 } gnet_config;
 
 /* Sizes of one batch: n_img images concatenated (the reference runs n_img = 1,
@@ -226,8 +227,8 @@ int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, const float* 
  * milliseconds and launch counts per class into ms_sum[GNET_KCLASS_COUNT] / count[...], and resets. */
 enum {
   GNET_K_GRAPH = 0, GNET_K_PACK, GNET_K_PW_FWD, GNET_K_NODE_FWD, GNET_K_EDGE_FWD, GNET_K_LOSS,
-  GNET_K_HEAD_BWD, GNET_K_BLK_POST, GNET_K_EDGE_BWD, GNET_K_BLK_PRE, GNET_K_PW_BWD, GNET_K_PW_W1,
-  GNET_K_REDUCE, GNET_KCLASS_COUNT
+  GNET_K_HEAD_BWD, GNET_K_WINNERS, GNET_K_EDGE_BWD, GNET_K_GATHER, GNET_K_NODE_BWD, GNET_K_PW_BWD,
+  GNET_K_W1_SUMS, GNET_K_W1_CLASS, GNET_K_REDUCE, GNET_KCLASS_COUNT
 };
 int gnet_profiler_create(int32_t capacity, uint32_t class_mask, void** out);
 int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count);

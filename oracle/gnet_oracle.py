@@ -307,7 +307,7 @@ class GnetOracle:
 
     def __init__(self, num_classes, num_blocks=16, params=None, class_weights=None,
                  dtype=torch.float32, thresh=NEIGHBOR_THRESH, normalize_loss=False,
-                 loss_multiplyer=1.0, bias_init=0.01, matching_fn=None):
+                 loss_multiplyer=1.0, bias_init=0.01, matching_fn=None, pw_feat_multiplyer=1.0):
         self.num_classes = num_classes
         self.num_blocks = num_blocks
         self.dtype = dtype
@@ -315,6 +315,7 @@ class GnetOracle:
         self.thresh = thresh
         self.normalize_loss = normalize_loss
         self.loss_multiplyer = loss_multiplyer
+        self.pw_feat_multiplyer = pw_feat_multiplyer    # config.py:77, network.py:199-200
         if params is None:
             params = init_params(num_classes, num_blocks, bias_init=bias_init)
         self.params = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True)
@@ -343,13 +344,14 @@ class GnetOracle:
         db, det_anno_iou, det_det_iou, pairs = preprocess(
             dets, batch["det_classes"], gt_boxes, gt_crowd, gt_classes, C, self.thresh, npd)
         raw = geometry_feats(db, det_det_iou, batch["det_scores"], batch["det_classes"], pairs, C, npd)
+        raw = raw * npd(self.pw_feat_multiplyer)             # network.py:199-200
         out = {"det_anno_iou": det_anno_iou, "neighbor_pair_idxs": pairs, "raw_pw_feats": raw,
                "num_dets": N}
         if keep:
             out["det_det_iou"] = det_det_iou
         c_idx = torch.from_numpy(pairs[:, 0].copy())
         n_idx = torch.from_numpy(pairs[:, 1].copy())
-        f = torch.from_numpy(raw).to(self.dtype)          # stop_gradient (:454), multiplyer 1.0 (:199-200)
+        f = torch.from_numpy(raw).to(self.dtype)          # stop_gradient (:454)
         # _pw_feats_fc network.py:324-342
         pin = (lambda key, i: None) if pins is None else (lambda key, i: torch.as_tensor(np.asarray(pins[key][i])))
         own = {"pw": [], "r": [], "h1": [], "sel": [], "q": [], "x": []}   # this forward's own smooth piece (keep=True)

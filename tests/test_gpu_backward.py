@@ -193,6 +193,56 @@ def test_weight_reg_gradient():
     assert float((diff - expect).abs().max()) < 2e-6 * float(net.grads.abs().max())
 
 
+def test_weight_reg_multi_image_batch():
+    """The l2 regulariser enters ONCE per step (train.py:231-238: data loss + sum of l2 terms) whatever the number
+    of images and the data-loss scale: grads = grad_scale * sum_i g_i + weight_reg * w on the regularised weights."""
+    c, b = 80, 2
+    net, orc = make_pair(c, b)
+    net.keep_edge_activations = True
+    imgs = [make_image(n, c, seed=s_) for n, s_ in ((60, 0), (45, 1), (80, 2))]
+    net.weight_reg = 0.0005
+    net.grad_scale = 1.0 / 3
+    net.run(imgs)
+    torch.cuda.synchronize()
+    gsum = None
+    for i, im in enumerate(imgs):
+        _, g = orc.forward_backward(im, pins=gpu_pins(net, image=i))
+        gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
+    want = {}
+    for k, v in gsum.items():
+        w = orc.params[k].detach().numpy()
+        reg = 0.0005 * w if (k.endswith("weights") and "/predict/" not in k) else 0.0
+        want[k] = v / 3.0 + reg
+    errs = grad_errors(net, want, c, b)
+    assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
+    assert abs(float(net.regularization_loss()) - 0.5 * 0.0005 * sum(float((orc.params[k] ** 2).sum()) for k in want
+                                                                     if k.endswith("weights") and "/predict/" not in k)) < 1e-4
+
+
+def test_pw_feat_multiplyer():
+    """cfg.gnet.pw_feat_multiplyer scales every _geometry_feats column (network.py:199-200)."""
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet
+    c, b = 80, 2
+    reset_cfg()
+    cfg.gnet.num_blocks = b
+    cfg.gnet.pw_feat_multiplyer = 2.5
+    params = go.init_params(c, b)
+    net = Gnet(c)
+    net.keep_edge_activations = True
+    net.load_params(params)
+    orc = go.GnetOracle(c, b, params=params, pw_feat_multiplyer=2.5)
+    batch = make_image(120, c, seed=4)
+    ref = orc.forward(batch)
+    net.run(batch)
+    torch.cuda.synchronize()
+    check_outputs(net, ref)
+    assert rel_err(net.pw_feats.cpu().numpy(), ref["pw_feats"].detach().numpy()) < 1e-5
+    pinned = pinned_errors(net, orc, batch, c, b)
+    assert max(pinned.values()) <= PINNED
+    reset_cfg()
+
+
 def test_exact_ties_from_duplicate_detections():
     """Duplicate detections give bit-identical edge activations: the segment max then has exact positive
     ties and TF splits the gradient evenly among them.  Exercises the tie counting of the

@@ -58,3 +58,46 @@ def test_learning_rate_schedule_cpu_semantics():
     cfg.train.lr_multi_step = [(2, 0.1), (4, 0.01)]
     lr = LearningRate()
     assert [lr.get_lr(i) for i in range(1, 7)] == [0.1, 0.1, 0.01, 0.01, 0.01, 0.01]   # train.py:31-37
+
+
+def test_one_rank_nccl_step_equals_single_process_step(tmp_path):
+    """The product gradient buffer meets torch.distributed before the 8-GPU node does: a 1-rank `nccl` (= RCCL) group,
+    broadcast_parameters(net.params), train_step(..., dist=dist) with the all-reduce on the flat net.grads buffer --
+    bitwise the same parameters as the step without a process group."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.network import Gnet
+from gossipnet_amd.synthetic import make_image
+from gossipnet_amd.train import Optimizer, train_step
+from gossipnet_amd.data_parallel import broadcast_parameters, shard_images
+use_dist = sys.argv[2] == "1"
+dist = None
+if use_dist:
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+reset_cfg(); cfg.gnet.num_blocks = 3
+net = Gnet(80, weight_reg=0.0005)
+if use_dist: broadcast_parameters(net.params, dist)
+opt = Optimizer(net)
+imgs = [make_image(n, 80, seed=s) for n, s in ((150, 0), (90, 1), (200, 2))]
+costs = [float(Gnet.count_edges(im["dets"], "cuda:0")) for im in imgs]
+mine = shard_images(imgs, 0, 1, costs=costs, per_rank=3)
+net.grad_scale = 1.0 / len(imgs)
+for it in range(3):
+    train_step(net, opt, mine, 1e-3, dist=dist)
+torch.cuda.synchronize()
+np.save(sys.argv[1], net.params.cpu().numpy())
+if use_dist: dist.destroy_process_group()
+""" % root
+    outs = []
+    for mode in ("0", "1"):
+        f = str(tmp_path / ("p%s.npy" % mode))
+        subprocess.run([sys.executable, "-c", script, f, mode], check=True, cwd=root, timeout=600)
+        outs.append(np.load(f))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
