@@ -180,9 +180,18 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   const int eb = row_ptr[node], ee = row_ptr[node + 1];
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
   const int p0 = bn_winner_pos(ewin, wprefix, eb), p1 = bn_winner_pos(ewin, wprefix, ee);
-  for (int p = p0 + sub; p < p1; p += 4) {
-    const float4 c = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
-    sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+  // the sums are latency-bound: several rows per quarter-wave in flight (a missing row re-reads row p0 / position 0 with
+  // weight 0); ascending order per quarter-wave, the quarter-waves are folded at the end (fixed order)
+  for (int p = p0 + sub; p < p1; p += 16) {
+    float4 c[4]; float w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool have = p + 4 * q < p1;
+      w[q] = have ? 1.f : 0.f;
+      c[q] = *reinterpret_cast<const float4*>(g1c + (size_t)(have ? p + 4 * q : p0) * D_P + 4 * f4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sc.x = fmaf(w[q], c[q].x, sc.x); sc.y = fmaf(w[q], c[q].y, sc.y); sc.z = fmaf(w[q], c[q].z, sc.z); sc.w = fmaf(w[q], c[q].w, sc.w); }
   }
   for (int base = eb; base < ee; base += 64) {
     const int el = base + lane;
@@ -193,14 +202,16 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
     }
     unsigned long long mr = __ballot(tp >= 0);
     while (mr) {
-      int j = -1;
+      // next 8 reversed rows: two per quarter-wave
+      int j[2] = {-1, -1};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if (q == sub) j = b; } }
-      const int p = __shfl(tp, j < 0 ? 0 : j);
-      if (j >= 0) {
-        const float4 v = *reinterpret_cast<const float4*>(g1c + (size_t)p * D_P + 4 * f4);
-        sn.x += v.x; sn.y += v.y; sn.z += v.z; sn.w += v.w;
-      }
+      for (int q = 0; q < 8; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if ((q & 3) == sub) j[q >> 2] = b; } }
+      const int pa = __shfl(tp, j[0] < 0 ? 0 : j[0]), pb = __shfl(tp, j[1] < 0 ? 0 : j[1]);
+      const float4 va = *reinterpret_cast<const float4*>(g1c + (size_t)max(pa, 0) * D_P + 4 * f4);
+      const float4 vb = *reinterpret_cast<const float4*>(g1c + (size_t)max(pb, 0) * D_P + 4 * f4);
+      const float wa = j[0] >= 0 ? 1.f : 0.f, wb = j[1] >= 0 ? 1.f : 0.f;
+      sn.x = fmaf(wa, va.x, sn.x); sn.y = fmaf(wa, va.y, sn.y); sn.z = fmaf(wa, va.z, sn.z); sn.w = fmaf(wa, va.w, sn.w);
+      sn.x = fmaf(wb, vb.x, sn.x); sn.y = fmaf(wb, vb.y, sn.y); sn.z = fmaf(wb, vb.z, sn.z); sn.w = fmaf(wb, vb.w, sn.w);
     }
   }
 #pragma unroll
@@ -602,35 +613,50 @@ __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
       const int tt = in ? a.edge_t[el] : 0;
       unsigned long long mo = __ballot(in && W1_BIT(el));
       unsigned long long mr = __ballot(in && W1_BIT(tt));
+      // four rows in flight per wave (the sums are latency-bound: 2 rows per round trip kept the kernel at 2.5 TB/s);
+      // rows are taken in ascending edge order, missing slots re-read the last row with weight 0
       while (mo) {
-        const int j0 = __builtin_ctzll(mo); mo &= mo - 1;
-        const bool two = mo != 0ull;
-        const int j1 = two ? __builtin_ctzll(mo) : j0; mo &= mo - 1;      // (mo == 0 stays 0)
-        const int e = base + j0, e1 = base + j1;
-        const float4 d0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e * D_H + 4 * lane);
-        const float4 d1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e1 * D_H + 4 * lane);
-        const float4 ga0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8);
-        const float4 gc0 = *reinterpret_cast<const float4*>(a.geo + (size_t)e * 8 + 4);
-        const float4 ga1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8);
-        const float4 gc1 = *reinterpret_cast<const float4*>(a.geo + (size_t)e1 * 8 + 4);
-        S.x += d0.x; S.y += d0.y; S.z += d0.z; S.w += d0.w;
-        ACC4(g[0], ga0.x, d0); ACC4(g[1], ga0.y, d0); ACC4(g[2], ga0.z, d0); ACC4(g[3], ga0.w, d0);
-        ACC4(g[4], gc0.x, d0); ACC4(g[5], gc0.y, d0); ACC4(g[6], gc0.z, d0);
-        if (two) {
-          S.x += d1.x; S.y += d1.y; S.z += d1.z; S.w += d1.w;
-          ACC4(g[0], ga1.x, d1); ACC4(g[1], ga1.y, d1); ACC4(g[2], ga1.z, d1); ACC4(g[3], ga1.w, d1);
-          ACC4(g[4], gc1.x, d1); ACC4(g[5], gc1.y, d1); ACC4(g[6], gc1.z, d1);
+        int e[4]; float wgt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool have = mo != 0ull;
+          const int j = have ? __builtin_ctzll(mo) : 0;
+          if (have) mo &= mo - 1;
+          e[q] = have ? base + j : (q ? e[q - 1] : base);
+          wgt[q] = have ? 1.f : 0.f;
+        }
+        float4 d[4], ga[4], gc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          d[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e[q] * D_H + 4 * lane);
+          ga[q] = *reinterpret_cast<const float4*>(a.geo + (size_t)e[q] * 8);
+          gc[q] = *reinterpret_cast<const float4*>(a.geo + (size_t)e[q] * 8 + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (wgt[q] != 0.f) {                              // wave-uniform
+            const float4 dq = d[q];
+            S.x += dq.x; S.y += dq.y; S.z += dq.z; S.w += dq.w;
+            ACC4(g[0], ga[q].x, dq); ACC4(g[1], ga[q].y, dq); ACC4(g[2], ga[q].z, dq); ACC4(g[3], ga[q].w, dq);
+            ACC4(g[4], gc[q].x, dq); ACC4(g[5], gc[q].y, dq); ACC4(g[6], gc[q].z, dq);
+          }
         }
       }
       while (mr) {
-        const int j0 = __builtin_ctzll(mr); mr &= mr - 1;
-        const bool two = mr != 0ull;
-        const int j1 = two ? __builtin_ctzll(mr) : j0; mr &= mr - 1;
-        const int r0 = __builtin_amdgcn_readlane(tt, j0), r1 = __builtin_amdgcn_readlane(tt, j1);
-        const float4 t0 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r0 * D_H + 4 * lane);
-        const float4 t1 = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r1 * D_H + 4 * lane);
-        T.x += t0.x; T.y += t0.y; T.z += t0.z; T.w += t0.w;
-        if (two) { T.x += t1.x; T.y += t1.y; T.z += t1.z; T.w += t1.w; }
+        int r[4]; bool hv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hv[q] = mr != 0ull;
+          const int j = hv[q] ? __builtin_ctzll(mr) : 0;
+          if (hv[q]) mr &= mr - 1;
+          r[q] = hv[q] ? __builtin_amdgcn_readlane(tt, j) : (q ? r[q - 1] : 0);
+        }
+        float4 tq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r[q] * D_H + 4 * lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (hv[q]) { T.x += tq[q].x; T.y += tq[q].y; T.z += tq[q].z; T.w += tq[q].w; }
       }
     }
 #undef W1_BIT
@@ -701,24 +727,31 @@ struct ReduceArgs {
   float* grads;
 };
 
+// 64 parameters x 4 partial groups per workgroup: group g adds the copies g, g + 4, ... (four independent load
+// streams per parameter instead of one dependent chain), the groups are folded in a fixed order.
 __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.total) return;
-  int n;
-  if (p < a.w1c_end) n = a.n_w1c;
-  else if (p < a.pw1_end) n = a.n_w1;
-  else if (p < a.pw_end) n = a.n_pw;
-  else if (p < a.pw_end + a.blk_sz * a.nblocks) {
-    const long long q = (p - a.pw_end) % a.blk_sz;
-    const long long w1 = D_S * D_R + D_R;                       // start of pw_fc1 weights
-    const long long w2 = w1 + (D_E + 2 * D_R) * D_P + D_P;      // start of pw_fc2 weights
-    const bool edge = (q >= w1 && q < w1 + D_E * D_P) || (q >= w2 && q < w2 + D_P * D_P + D_P);
-    n = edge ? a.n_edge : a.n_node;
-  } else n = a.n_head;
+  __shared__ float part[4][64];
+  const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long p = (long long)blockIdx.x * 64 + px;
   float v = 0.f;
-  const float* src = a.arena + p;
-  for (int k = 0; k < n; ++k) v += src[(size_t)k * a.stride];
-  a.grads[p] = v;
+  if (p < a.total) {
+    int n;
+    if (p < a.w1c_end) n = a.n_w1c;
+    else if (p < a.pw1_end) n = a.n_w1;
+    else if (p < a.pw_end) n = a.n_pw;
+    else if (p < a.pw_end + a.blk_sz * a.nblocks) {
+      const long long q = (p - a.pw_end) % a.blk_sz;
+      const long long w1 = D_S * D_R + D_R;                       // start of pw_fc1 weights
+      const long long w2 = w1 + (D_E + 2 * D_R) * D_P + D_P;      // start of pw_fc2 weights
+      const bool edge = (q >= w1 && q < w1 + D_E * D_P) || (q >= w2 && q < w2 + D_P * D_P + D_P);
+      n = edge ? a.n_edge : a.n_node;
+    } else n = a.n_head;
+    const float* src = a.arena + p;
+    for (int k = g; k < n; k += 4) v += src[(size_t)k * a.stride];
+  }
+  part[g][px] = v;
+  __syncthreads();
+  if (g == 0 && p < a.total) a.grads[p] = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
 }
 
 }  // namespace
@@ -830,7 +863,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     r.nblocks = B;
     r.n_w1c = g_w1c; r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_head;
     r.grads = grads;
-    GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 255) / 256), 256, 0, s>>>(r));
+    GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 63) / 64), 256, 0, s>>>(r));
   }
   return launch_status();
 }
