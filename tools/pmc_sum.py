@@ -1,11 +1,38 @@
-import csv, collections, sys
-names=["edge_bwd","edge_fwd","pw_bwd_main","pw_w1_nodesums","pw_w1_classrows","pw_fwd","gather_sparse","gather_sums","winners_mark","blk_bwd_pre","blk_bwd_post","node_fwd","reduce_partials","graph_sweep","head_bwd","match_greedy"]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter(); dur=collections.defaultdict(float); seen=set()
-for row in csv.DictReader(open(sys.argv[1])):
-    k = next((x for x in names if x in row["Kernel_Name"]), None)
-    if not k: continue
-    agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-    if row["Dispatch_Id"] not in seen:
-        seen.add(row["Dispatch_Id"]); n[k]+=1; dur[k]+= (int(row["End_Timestamp"])-int(row["Start_Timestamp"]))/1e3
-for k, v in sorted(agg.items(), key=lambda kv:-dur[kv[0]]):
-    print("%-16s n=%3d avg_us=%8.1f " % (k, n[k], dur[k]/n[k]) + " ".join("%s=%.4g" % (c.replace("SQ_","").replace("_sum",""), x/n[k]) for c,x in sorted(v.items())))
+"""Per-kernel, per-launch averages of a rocprofv3 --pmc counter_collection.csv (one pass).  usage: pmc_sum.py <csv> [--json]"""
+import collections
+import csv
+import json
+import sys
+
+# substring of the kernel symbol -> name used in the profile summaries / profiles/*_traffic.json (bench.py kernel classes)
+NAMES = [("edge_bwd_w", "edge_bwd"), ("edge_fwd_w", "edge_fwd"), ("pw_bwd_main", "pw_bwd_main"), ("pw_w1_nodesums", "pw_w1_nodesums"),
+         ("pw_w1_classrows", "pw_w1_classrows"), ("pw_fwd", "pw_fwd"), ("gather_winners", "gather_winners"),
+         ("winners_mark", "winners_mark"), ("winners_ties", "winners_ties"), ("winner_positions", "winner_positions"),
+         ("list_fill", "list_fill"), ("list_count", "list_count"), ("blk_bwd_node", "node_bwd"), ("node_fwd", "node_fwd"),
+         ("reduce_partials", "reduce_partials"), ("graph_sweep", "graph_sweep"), ("head_bwd", "head_bwd"),
+         ("match_greedy", "match_greedy"), ("edge_geometry", "edge_geometry"), ("roi_pool", "roi_pool"), ("imfeat", "imfeat")]
+
+
+def summarise(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.Counter(); dur = collections.defaultdict(float); seen = set()
+    for row in csv.DictReader(open(path)):
+        k = next((nm for sub, nm in NAMES if sub in row["Kernel_Name"]), None)
+        if not k:
+            continue
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        if row["Dispatch_Id"] not in seen:
+            seen.add(row["Dispatch_Id"]); n[k] += 1
+            dur[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+    return {k: dict(launches=n[k], avg_us=dur[k] / n[k], **{c.replace("SQ_", "").replace("_sum", ""): x / n[k] for c, x in v.items()})
+            for k, v in agg.items()}
+
+
+if __name__ == "__main__":
+    res = summarise(sys.argv[1])
+    if "--json" in sys.argv:
+        print(json.dumps(res))
+    else:
+        for k, v in sorted(res.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
+            print("%-16s n=%3d avg_us=%8.1f " % (k, v["launches"], v["avg_us"]) +
+                  " ".join("%s=%.4g" % (c, x) for c, x in sorted(v.items()) if c not in ("launches", "avg_us")))
