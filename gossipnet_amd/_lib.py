@@ -51,13 +51,14 @@ class gnet_buffers(C.Structure):
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
                                            "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
                                            "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +
-                [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t), ("profiler", C.c_void_p)])
+                [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t), ("profiler", C.c_void_p), ("start_feat", C.c_void_p)])
 
 
 EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_graph_transpose", "gnet_workspace_bytes", "gnet_plan",
            "gnet_forward", "gnet_loss", "gnet_backward", "det_matching_workspace_bytes", "det_matching_f32",
-           "roi_pool_fwd_f32", "roi_pool_bwd_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
-           "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm"]
+           "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
+           "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
+           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
             "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials"]
@@ -118,6 +119,8 @@ def load():
     lib.roi_pool_fwd_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, i32, f32, vp, vp, vp]
     lib.roi_pool_bwd_f32.restype = C.c_int
     lib.roi_pool_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+    lib.roi_pool_bwd_atomic_f32.restype = C.c_int
+    lib.roi_pool_bwd_atomic_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.gnet_profiler_create.restype = C.c_int
     lib.gnet_profiler_create.argtypes = [i32, C.c_uint32, P(vp)]
     lib.gnet_profiler_read.restype = C.c_int
@@ -130,6 +133,12 @@ def load():
     lib.gnet_momentum_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp]
     lib.gnet_clip_by_norm.restype = C.c_int
     lib.gnet_clip_by_norm.argtypes = [vp, vp, i32, f32, vp]
+    lib.gnet_fc_workspace_bytes.restype = sz
+    lib.gnet_fc_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.gnet_fc_forward.restype = C.c_int
+    lib.gnet_fc_forward.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, vp, sz, vp]
+    lib.gnet_fc_backward.restype = C.c_int
+    lib.gnet_fc_backward.argtypes = [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp, vp, vp, vp, sz, vp]
     lib.gnet_version.restype = C.c_char_p
     lib.gnet_version.argtypes = []
     _lib = lib

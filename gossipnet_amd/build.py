@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgossipnet_hip.so")
-SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "plan.hip"]
+SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "fc.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 

@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
 struct BlkNodeArgs {
   int n_det;
   int do_pre, do_post;
+  int want_dx0;                               // pre stage of block 1 with start features: d_x := dz + drpre . Wr^T (unmasked)
   const float* d_rc; const float* d_rn;       // [N,64] gather_winners of block b (NULL: no edges)
   // pre (block b)
   const float* r; const float* x_prev;        // x_prev = block_feats[b-1] (NULL = zeros); also x_out of the post stage
@@ -291,12 +292,17 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
         aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDr[row * LD32 + col], aWr, 0, 0, 0);
       }
       if (lt < D_R) gbr += col_sum32(sDr, LD32, lt);
-      if (a.do_post) {
+      if (a.do_post || a.want_dx0) {
         // d_x += drpre . Wr^T (columns [32 cw, 32 cw + 32))
         f32x16 acc = zero16();
         mma_abt<D_R>(acc, sDr, LD32, a.wr + (size_t)(32 * cw) * D_R, D_R, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sDZ[crow(r, half) * LD128 + 32 * cw + col] += acc[r];
+        for (int r = 0; r < 16; ++r) {
+          const int row = crow(r, half);
+          const float v = sDZ[row * LD128 + 32 * cw + col] + acc[r];
+          sDZ[row * LD128 + 32 * cw + col] = v;
+          if (!a.do_post && row0 + row < a.n_det) a.d_x[(size_t)(row0 + row) * D_S + 32 * cw + col] = v;   // gradient wrt the start features
+        }
       }
       __syncthreads();
     }
@@ -809,14 +815,14 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   for (int b = B + 1; b >= 1; --b) {
     // node stage: pre of block b (b <= B), post of block b-1 (b >= 2)
     BlkNodeArgs n;
-    n.n_det = N; n.do_pre = b <= B; n.do_post = b >= 2;
+    n.n_det = N; n.do_pre = b <= B; n.do_post = b >= 2; n.want_dx0 = (b == 1 && buf->start_feat) ? 1 : 0;
     n.d_rc = E > 0 ? buf->d_rc : nullptr; n.d_rn = E > 0 ? buf->d_rn : nullptr;
     if (b <= B && E > 0) {
       GNET_LAUNCH(prof, GNET_K_GATHER, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
           buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, (const unsigned long long*)buf->ewin + (size_t)(b - 1) * G.bm_stride,
           buf->wprefix + (size_t)(b - 1) * G.bm_stride, N, buf->d_rc, buf->d_rn));
     }
-    n.x_prev = b >= 2 ? buf->block_feats[b - 1] : nullptr;
+    n.x_prev = b >= 2 ? buf->block_feats[b - 1] : buf->start_feat;
     if (b <= B) {
       const BlockLayout& K = L.blk[b];
       n.r = buf->blk_r[b]; n.w1 = params + K.w1; n.wr = params + K.wr;

@@ -602,6 +602,7 @@ struct NodeFwdArgs {
   int training;
   const unsigned long long* pm;  // [N,64] block b
   const float* x_prev;           // [N,128] block b input (NULL = zeros)
+  const float* x0;               // [N,128] start features for the first launch (do_post == 0); NULL = zeros
   const float* w3t; const float* b3;   // fc1 transposed [64][64]
   const float* w4t; const float* b4;   // fc2 transposed [128][64]
   float* q; float* x_out;
@@ -663,7 +664,16 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     }
     __syncthreads();
   } else {
-    for (int i = tid; i < 32 * N_LD; i += 256) sX[i] = 0.f;   // start_feat = zeros (network.py:241-246)
+    if (a.x0) {                                               // start_feat from the image features (network.py:223-240)
+      for (int i = tid; i < 32 * (D_S / 4); i += 256) {
+        const int row = i >> 5, c4 = i & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < a.n_det) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)(row0 + row) * D_S + 4 * c4);
+        *reinterpret_cast<float4*>(sX + row * N_LD + 4 * c4) = v;
+      }
+    } else {
+      for (int i = tid; i < 32 * N_LD; i += 256) sX[i] = 0.f;   // start_feat = zeros (network.py:241-246)
+    }
     __syncthreads();
   }
   if (a.do_pre) {
@@ -809,7 +819,8 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     NodeFwdArgs n;
     n.n_det = N; n.do_post = b >= 1; n.do_pre = b < B; n.do_head = b == B; n.training = training;
     n.pm = b >= 1 ? (const unsigned long long*)buf->blk_pm[b] : nullptr;
-    n.x_prev = b >= 2 ? buf->block_feats[b - 1] : nullptr;
+    n.x_prev = b >= 2 ? buf->block_feats[b - 1] : buf->start_feat;
+    n.x0 = b == 0 ? buf->start_feat : nullptr;
     if (b >= 1) {
       n.w3t = pt + L.blk[b].w3; n.b3 = params + L.blk[b].b3;
       n.w4t = pt + L.blk[b].w4; n.b4 = params + L.blk[b].b4;

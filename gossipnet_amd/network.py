@@ -23,6 +23,21 @@ def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def imfeat_param_spec(imfeat_channels):
+    """Variables of the image-feature start features (network.py:223-240), appended behind the core parameters:
+    flatten(roifeats) [N, crop_h*crop_w*C] -> fully_connected (-> imfeat_dim, only if > 0) -> fully_connected (-> 128).
+    TF names the first layer of the scope `fully_connected`, a second one `fully_connected_1`."""
+    g = cfg.gnet
+    d_in = int(cfg.imfeat_crop_height) * int(cfg.imfeat_crop_width) * int(imfeat_channels)
+    spec, names = [], ["gnet/reduce_imfeats/fully_connected/", "gnet/reduce_imfeats/fully_connected_1/"]
+    if g.imfeat_dim > 0:
+        spec += [(names[0] + "weights", (d_in, int(g.imfeat_dim))), (names[0] + "biases", (int(g.imfeat_dim),))]
+        d_in = int(g.imfeat_dim)
+        names = names[1:]
+    spec += [(names[0] + "weights", (d_in, g.shortcut_dim)), (names[0] + "biases", (g.shortcut_dim,))]
+    return spec
+
+
 def param_spec(num_classes, num_blocks):
     """TF variable names + shapes in flat-buffer order (include/gossipnet_hip.h)."""
     cp = num_classes if num_classes > 1 else 1
@@ -94,6 +109,12 @@ class DeviceBatch(object):
         self.n_det, self.n_gt = int(dets.shape[0]), int(gtb.shape[0])
         self.n_anno = int(self.anno_off_h[-1])
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        # image-feature variant: one NHWC feature map [1,H,W,C] per image (the trunk's output; caller-supplied)
+        self.imfeats = None
+        if all("imfeats" in im for im in images):
+            self.imfeats = [torch.as_tensor(np.asarray(im["imfeats"], np.float32) if not torch.is_tensor(im["imfeats"]) else im["imfeats"])
+                            .to(device=device, dtype=torch.float32).reshape((1,) + tuple(im["imfeats"].shape[-3:])).contiguous()
+                            for im in images]
         self.dets, self.det_scores, self.det_classes = t(dets), t(scores), t(classes)
         self.gt_boxes, self.gt_crowd, self.gt_classes = t(gtb), t(crowd), t(gcls)
         self.det_off, self.gt_off, self.anno_off = t(self.det_off_h), t(self.gt_off_h), t(self.anno_off_h)
@@ -137,16 +158,20 @@ class Gnet(object):
         return spec
 
     def __init__(self, num_classes, class_weights=None, batch=None, weight_reg=None, reuse=False,
-                 device=None):
+                 device=None, imfeat_channels=1024, imfeat_stride=16):
+        """cfg.gnet.imfeats=True: the batch carries `imfeats` = the trunk's NHWC feature map [1,H,W,imfeat_channels] at
+        `imfeat_stride` (the reference's ResNet-101 block3 output, stride 16, network.py:52-75 -- the trunk itself is
+        out of scope); crop_windows -> flatten -> reduce_imfeats FCs give block_feats[0]
+        (network.py:223-240) instead of zeros, with backward into both FCs."""
         self.num_classes = num_classes
         self.multiclass = num_classes > 1
-        if cfg.gnet.imfeats:
-            raise _lib.GnetError("cfg.gnet.imfeats=True needs the ResNet trunk (out of scope, SURVEY §2 row 12); "
-                                 "the roi_pool op itself is available in gossipnet_amd.roi_pooling_layer")
+        self._imfeats = bool(cfg.gnet.imfeats)
+        self.imfeat_channels, self.imfeat_stride = int(imfeat_channels), int(imfeat_stride)
+        self.imfeats_need_grad = False      # also compute d loss / d imfeats (through roi_pool_grad) in run()
         if cfg.gnet.neighbor_feats:
             raise _lib.GnetError("cfg.gnet.neighbor_feats=True is not compiled")
-        if cfg.gnet.weight_init != 'xavier':
-            raise ValueError('unknown weight init {}'.format(cfg.gnet.weight_init))
+        if cfg.gnet.weight_init not in ('xavier', 'caffe', 'msra'):
+            raise ValueError('unknown weight init {}'.format(cfg.gnet.weight_init))        # network.py:203-214
         self._lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda:0")
         g = cfg.gnet
@@ -161,7 +186,13 @@ class Gnet(object):
         self.num_blocks = g.num_blocks
         self._spec = param_spec(num_classes, g.num_blocks)
         assert sum(int(np.prod(s)) for _, s in self._spec) == n
-        key = (self.name, num_classes, g.num_blocks, str(self.device))
+        self._core_n = int(n)
+        if self._imfeats:
+            self._spec = self._spec + imfeat_param_spec(self.imfeat_channels)
+            n = sum(int(np.prod(s)) for _, s in self._spec)
+            from .fc import FcWorkspace
+            self._fc_ws = FcWorkspace(self.device)
+        key = (self.name, num_classes, g.num_blocks, str(self.device), self._imfeats, self.imfeat_channels)
         if reuse:
             if key not in Gnet._scopes:
                 raise ValueError("Variable scope gnet does not exist, cannot reuse")
@@ -207,15 +238,24 @@ class Gnet(object):
 
     # ------------------------------------------------------------------ parameters
     def _init_params(self, n):
-        """xavier-uniform, seed cfg.random_seed (network.py:203-205); biases const (network.py:215)."""
+        """network.py:203-215: 'xavier' = xavier-uniform (seed cfg.random_seed), 'caffe' = variance_scaling(1.0, FAN_IN,
+        uniform), 'msra' = variance_scaling(2.0, FAN_IN, truncated normal; tf.contrib.layers: stddev sqrt(1.3 f / n));
+        biases constant.  (TF's RNG streams cannot be reproduced: the seed fixes OUR stream.)"""
         gen = torch.Generator().manual_seed(int(cfg.random_seed))
         flat = torch.empty(n, dtype=torch.float32)
         off = 0
         for nm, shape in self._spec:
             k = int(np.prod(shape))
             if nm.endswith("weights"):
-                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
-                flat[off:off + k] = ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).reshape(-1)
+                kind = cfg.gnet.weight_init
+                if kind == 'msra':
+                    std = math.sqrt(1.3 * 2.0 / shape[0])
+                    w = torch.empty(shape, dtype=torch.float64)
+                    torch.nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+                    flat[off:off + k] = w.to(torch.float32).reshape(-1)
+                else:
+                    lim = math.sqrt(6.0 / (shape[0] + shape[1])) if kind == 'xavier' else math.sqrt(3.0 * 1.0 / shape[0])
+                    flat[off:off + k] = ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).reshape(-1)
             else:
                 flat[off:off + k] = float(cfg.gnet.bias_const_init)
             off += k
@@ -319,6 +359,8 @@ class Gnet(object):
         shape, buf = self._build_graph(db, training)
         inp = db.c_inputs()
         self._inputs = inp
+        if self._imfeats:
+            buf.start_feat = _vp(self._imfeat_forward(db))
         _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                     C.byref(buf), self._mode(training), s), "gnet_forward")
         if training:
@@ -327,12 +369,62 @@ class Gnet(object):
             if backward:
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                              C.byref(buf), _vp(self.grads), s), "gnet_backward")
+                if self._imfeats:
+                    self._imfeat_backward(db)
                 if self.weight_reg:
                     # slim get_total_loss adds sum(l2_regularizer(scale)(w)) -> d/dw = scale * w (train.py:231-238),
                     # ONCE per optimisation step whatever the number of images in it: not scaled by grad_scale.
                     # Under data parallelism every rank adds reg_scale = 1 / world of it (the all-reduce sums).
                     self.grads.addcmul_(self.params, self._reg_mask, value=float(self.weight_reg) * float(self.reg_scale))
         return self
+
+    # ------------------------------------------------------------------ image-feature start features
+    def _imfeat_layers(self):
+        names = [nm[:-len("weights")] for nm, _ in self._spec if nm.startswith("gnet/reduce_imfeats/") and nm.endswith("weights")]
+        return names        # one or two scopes, in order
+
+    def _imfeat_forward(self, db):
+        """network.py:223-240: roifeats = crop_windows(imfeats, dets) [N,7,7,C]; det_imfeats = flatten -> FC(s), ReLU."""
+        from .fc import fc_forward
+        from .roi_pooling_layer.roi_pooling_op import roi_pool_raw
+        if db.imfeats is None:
+            raise _lib.InvalidArgumentError("cfg.gnet.imfeats=True: every image of the batch needs `imfeats` [1,H,W,C]")
+        tops, self._roi_argmax, self._frcn_boxes = [], [], []
+        for i, fm in enumerate(db.imfeats):
+            if fm.shape[-1] != self.imfeat_channels:
+                raise _lib.InvalidArgumentError("imfeats has %d channels, Gnet was built for %d" % (fm.shape[-1], self.imfeat_channels))
+            d = db.dets[int(db.det_off_h[i]):int(db.det_off_h[i + 1])]
+            boxes = to_frcn_coords(enlarge_windows(d))
+            top, am = roi_pool_raw(fm, boxes, int(cfg.imfeat_crop_height), int(cfg.imfeat_crop_width), 1.0 / self.imfeat_stride)
+            tops.append(top); self._roi_argmax.append(am); self._frcn_boxes.append(boxes)
+        self.roifeats = torch.cat(tops, 0) if len(tops) > 1 else tops[0]
+        self.det_imfeats = self.roifeats.reshape(self.roifeats.shape[0], -1)          # tf.contrib.layers.flatten
+        x, acts = self.det_imfeats, []
+        for scope in self._imfeat_layers():
+            x = fc_forward(x, self.variables[scope + "weights"], self.variables[scope + "biases"], True, self._fc_ws)
+            acts.append(x)
+        self._imfeat_acts = acts
+        return acts[-1]
+
+    def _imfeat_backward(self, db):
+        from .fc import fc_backward
+        N = self._shape.n_det
+        dy = self._view(self._buf.d_x, N * 128, torch.float32).view(N, 128)           # gradient wrt the start features
+        scopes = self._imfeat_layers()
+        inputs = [self.det_imfeats] + self._imfeat_acts[:-1]
+        for li in range(len(scopes) - 1, -1, -1):
+            need_dx = li > 0 or self.imfeats_need_grad
+            dy = fc_backward(inputs[li], self.variables[scopes[li] + "weights"], self._imfeat_acts[li], dy, True,
+                             self.gradients[scopes[li] + "weights"], self.gradients[scopes[li] + "biases"], self._fc_ws, need_dx)
+        self.imfeats_grad = None
+        if self.imfeats_need_grad:
+            from .roi_pooling_layer.roi_pooling_op import roi_pool_grad
+            g = dy.view(-1, int(cfg.imfeat_crop_height), int(cfg.imfeat_crop_width), self.imfeat_channels)
+            self.imfeats_grad = []
+            for i, fm in enumerate(db.imfeats):
+                lo, hi = int(db.det_off_h[i]), int(db.det_off_h[i + 1])
+                self.imfeats_grad.append(roi_pool_grad(fm, self._frcn_boxes[i], self._roi_argmax[i], g[lo:hi].contiguous(),
+                                                       int(cfg.imfeat_crop_height), int(cfg.imfeat_crop_width), 1.0 / self.imfeat_stride))
 
     # ------------------------------------------------------------------ measurement
     @staticmethod
@@ -455,7 +547,7 @@ class Gnet(object):
     @property
     def block_feats(self):
         N = self._shape.n_det
-        out = [torch.zeros(N, 128, device=self.device)]
+        out = [self._imfeat_acts[-1] if self._imfeats else torch.zeros(N, 128, device=self.device)]
         if not self._training:
             out += [None] * (self.num_blocks - 1)
             out.append(self._view(self._buf.block_feats[self.num_blocks], N * 128, torch.float32).view(N, 128))

@@ -42,8 +42,9 @@ def roi_pool_raw(bottom_data, bottom_rois, pooled_height, pooled_width, spatial_
     return top, argmax
 
 
-def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_width, spatial_scale):
-    """output = roi_pool_grad(bottom_data, bottom_rois, argmax, grad, ...) (roi_pooling_op.cc:45-54)."""
+def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_width, spatial_scale, deterministic=True):
+    """output = roi_pool_grad(bottom_data, bottom_rois, argmax, grad, ...) (roi_pooling_op.cc:45-54).
+    deterministic=True sums in the CPU kernel's order (bit-exact, reproducible); False = float-atomic scatter."""
     _check(bottom_data, bottom_rois, pooled_height, pooled_width)
     if argmax.dim() != 4:
         raise _lib.InvalidArgumentError("argmax_data must be 4-dimensional")                 # :343-344
@@ -55,8 +56,9 @@ def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_
     am = argmax.detach().contiguous().to(torch.int32)
     g = grad.detach().contiguous().float()
     out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=bottom_data.device)
-    _lib.check(lib.roi_pool_bwd_f32(_p(g), _p(am), _p(rois), B, H, W, Cc, rois.shape[0], pooled_height, pooled_width,
-                                    float(spatial_scale), _p(out), _stream(out.device)), "roi_pool_bwd_f32")
+    fn = lib.roi_pool_bwd_f32 if deterministic else lib.roi_pool_bwd_atomic_f32
+    _lib.check(fn(_p(g), _p(am), _p(rois), B, H, W, Cc, rois.shape[0], pooled_height, pooled_width,
+                  float(spatial_scale), _p(out), _stream(out.device)), "roi_pool_bwd_f32")
     return out
 
 

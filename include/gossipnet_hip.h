@@ -138,6 +138,9 @@ typedef struct gnet_buffers {
   size_t match_ws_bytes;
   size_t arena_floats;
   void* profiler;     /* optional gnet_profiler (NULL = off); set by the caller after gnet_plan */
+  const float* start_feat; /* optional [n_det,128] block_feats[0] (image-feature variant, network.py:223-240); NULL = zeros
+                              (network.py:241-246).  Set by the caller after gnet_plan; gnet_backward then leaves the
+                              gradient wrt it in d_x. */
 } gnet_buffers;
 
 /* ---- parameters ------------------------------------------------------------
@@ -203,6 +206,18 @@ int gnet_momentum_step(float* params, const float* grads, float* accum, int64_t 
 int gnet_clip_by_norm(float* grads, const int64_t* tensor_offsets, int32_t n_tensors, float clip_norm,
                       gnet_stream_t stream);
 
+/* ---- dense FC layers of the image-feature start features ("reduce_imfeats", network.py:223-240):
+ * y = act(x . w + b), x [M,K], w [K,N] ([in,out] as tf.contrib.layers.fully_connected), y [M,N]; K and N multiples of 4.
+ * gnet_fc_backward: dy = gradient wrt y (post-activation; the ReLU mask is y > 0); dw [K,N], db [N] overwritten,
+ * dx [M,K] optional (NULL: not computed).  fp32 MFMA GEMMs, split-K partials added in a fixed order (reproducible).
+ * workspace: gnet_fc_workspace_bytes(M, K, N) for either call. */
+size_t gnet_fc_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int gnet_fc_forward(const float* x, const float* w, const float* b, int64_t M, int64_t K, int64_t N, int relu,
+                    float* y, void* workspace, size_t workspace_bytes, gnet_stream_t stream);
+int gnet_fc_backward(const float* x, const float* w, const float* y, const float* dy, int64_t M, int64_t K, int64_t N,
+                     int relu, float* dw, float* db, float* dx, void* workspace, size_t workspace_bytes,
+                     gnet_stream_t stream);
+
 /* ---- DetectionMatching (det_matching.cc:72-160).  iou [n_det,n_gt], score [n_det],
  * ignore [n_gt] (bool as u8) -> labels, weights (f32 [n_det]), assignment (i32 [n_det]).
  * Ties in score: higher index first; equal ignore flags: lower index first.
@@ -220,6 +235,13 @@ int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, int32_t W, 
 int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, const float* bottom_rois,
                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h,
                      int32_t pooled_w, float spatial_scale, float* bottom_diff, gnet_stream_t stream);
+/* roi_pool_bwd_f32 sums in the CPU kernel's order (ROI index, then bin): bit-exact and reproducible.  The _atomic
+ * variant scatters every pooled element's gradient to its arg-max with a float atomic: less traffic, summation
+ * order not fixed, and NOT the reference's result where its in-ROI / feasible-bin tests (roi_pooling_op.cc:405-431)
+ * drop an element (arg-max pixel one past the rounded ROI end). */
+int roi_pool_bwd_atomic_f32(const float* top_diff, const int32_t* argmax, const float* bottom_rois,
+                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h,
+                            int32_t pooled_w, float spatial_scale, float* bottom_diff, gnet_stream_t stream);
 
 /* ---- optional per-kernel timing (measurement only; no reference counterpart) -------------
  * A caller-owned pool of HIP event pairs recorded on the launch stream around every kernel of the

@@ -38,10 +38,25 @@ def pw_feat_dim(num_classes):
     return 2 * cp + 7
 
 
-def param_spec(num_classes, num_blocks):
+def imfeat_param_spec(imfeat):
+    """reduce_imfeats FCs (network.py:223-240).  imfeat = dict(channels, imfeat_dim, crop (7), stride (16)).  TF names
+    the first fully_connected of the scope `fully_connected`, a second one `fully_connected_1`."""
+    d_in = imfeat.get("crop", 7) ** 2 * imfeat["channels"]
+    spec, names = [], ["gnet/reduce_imfeats/fully_connected/", "gnet/reduce_imfeats/fully_connected_1/"]
+    if imfeat.get("imfeat_dim", -1) > 0:
+        spec += [(names[0] + "weights", (d_in, imfeat["imfeat_dim"])), (names[0] + "biases", (imfeat["imfeat_dim"],))]
+        d_in = imfeat["imfeat_dim"]
+        names = names[1:]
+    spec += [(names[0] + "weights", (d_in, SHORTCUT_DIM)), (names[0] + "biases", (SHORTCUT_DIM,))]
+    return spec
+
+
+def param_spec(num_classes, num_blocks, imfeat=None):
     """Ordered (TF variable name, shape) list; FC weights are [in, out]
     (tf.contrib.layers.fully_connected).  Scopes: network.py:167,218,260,267,
-    334,341,347,354,385,397,405; SURVEY.md §8f."""
+    334,341,347,354,385,397,405; SURVEY.md §8f.  imfeat: the reduce_imfeats variables follow."""
+    if imfeat is not None:
+        return param_spec(num_classes, num_blocks) + imfeat_param_spec(imfeat)
     spec = []
     d = pw_feat_dim(num_classes)
     dims = [d, PWFEAT_DIM, PWFEAT_DIM, PWFEAT_NARROW_DIM]
@@ -65,13 +80,13 @@ def param_spec(num_classes, num_blocks):
     return spec
 
 
-def init_params(num_classes, num_blocks, seed=42, bias_init=0.01):
+def init_params(num_classes, num_blocks, seed=42, bias_init=0.01, imfeat=None):
     """xavier-uniform weights (network.py:203-205, limit sqrt(6/(fan_in+fan_out))),
     constant biases (network.py:215).  TF's RNG stream cannot be reproduced; the
     seed only fixes OUR stream."""
     g = torch.Generator().manual_seed(seed)
     out = {}
-    for name, shape in param_spec(num_classes, num_blocks):
+    for name, shape in param_spec(num_classes, num_blocks, imfeat):
         if name.endswith("weights"):
             lim = math.sqrt(6.0 / (shape[0] + shape[1]))
             out[name] = ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).numpy()
@@ -307,7 +322,7 @@ class GnetOracle:
 
     def __init__(self, num_classes, num_blocks=16, params=None, class_weights=None,
                  dtype=torch.float32, thresh=NEIGHBOR_THRESH, normalize_loss=False,
-                 loss_multiplyer=1.0, bias_init=0.01, matching_fn=None, pw_feat_multiplyer=1.0):
+                 loss_multiplyer=1.0, bias_init=0.01, matching_fn=None, pw_feat_multiplyer=1.0, imfeat=None):
         self.num_classes = num_classes
         self.num_blocks = num_blocks
         self.dtype = dtype
@@ -316,8 +331,9 @@ class GnetOracle:
         self.normalize_loss = normalize_loss
         self.loss_multiplyer = loss_multiplyer
         self.pw_feat_multiplyer = pw_feat_multiplyer    # config.py:77, network.py:199-200
+        self.imfeat = imfeat                            # image-feature variant (network.py:223-240), see imfeat_param_spec
         if params is None:
-            params = init_params(num_classes, num_blocks, bias_init=bias_init)
+            params = init_params(num_classes, num_blocks, bias_init=bias_init, imfeat=imfeat)
         self.params = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True)
                        for k, v in params.items()}
         if class_weights is None:
@@ -354,14 +370,35 @@ class GnetOracle:
         f = torch.from_numpy(raw).to(self.dtype)          # stop_gradient (:454)
         # _pw_feats_fc network.py:324-342
         pin = (lambda key, i: None) if pins is None else (lambda key, i: torch.as_tensor(np.asarray(pins[key][i])))
-        own = {"pw": [], "r": [], "h1": [], "sel": [], "q": [], "x": []}   # this forward's own smooth piece (keep=True)
+        own = {"pw": [], "r": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}   # this forward's own smooth piece (keep=True)
         note = (lambda key, t: own[key].append((t.detach() > 0).numpy())) if keep else (lambda key, t: None)
+        note_im = lambda t: note("im", t)
         for i in range(1, NUM_PWFEAT_FC + 1):
             f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats, pin("pw", i - 1))
             note("pw", f)
         pw = f
         out["pw_feats"] = pw
-        x = torch.zeros(N, SHORTCUT_DIM, dtype=self.dtype)   # network.py:241-246
+        if self.imfeat is None:
+            x = torch.zeros(N, SHORTCUT_DIM, dtype=self.dtype)   # network.py:241-246
+        else:
+            # network.py:223-240: crop_windows (enlarge_windows :78-86, to_frcn_coords :97-100, RoiPool 7x7 at 1/stride)
+            # -> flatten -> fully_connected (ReLU) [-> fully_connected_1 (ReLU)]
+            from . import native
+            two = npd(2.0)
+            x1, y1, w_, h_, x2, y2 = db[0], db[1], db[2], db[3], db[4], db[5]
+            cx, cy = (x1 + x2) / two, (y1 + y2) / two
+            nw2, nh2 = w_ * npd(1.0), h_ * npd(1.0)              # w * (0.5 + padding), padding = 0.5
+            boxes = np.concatenate([np.zeros_like(cx), cx - nw2, cy - nh2, cx + nw2, cy + nh2], 1).astype(np.float32)
+            fmap = np.asarray(batch["imfeats"], np.float32)
+            fmap = fmap.reshape((1,) + fmap.shape[-3:])
+            crop = self.imfeat.get("crop", 7)
+            roifeats, _ = native.roi_pool(fmap, boxes, crop, crop, 1.0 / self.imfeat.get("stride", 16))
+            out["roifeats"] = roifeats
+            x = torch.from_numpy(roifeats.reshape(N, -1)).to(self.dtype)
+            scopes = sorted({n_.rsplit("/", 1)[0] for n_ in P if n_.startswith("gnet/reduce_imfeats/")})
+            for li, sc in enumerate(scopes):                    # fully_connected, fully_connected_1
+                x = _fc(x, P, sc, True, stats, pin("im", li))
+                note_im(x)
         block_feats = [x]
         is_id = (c_idx == n_idx).view(-1, 1)
         for b in range(1, self.num_blocks + 1):             # _block network.py:344-409
@@ -432,7 +469,7 @@ class GnetOracle:
         return out, grads
 
 
-def flatten(params_or_grads, num_classes, num_blocks):
+def flatten(params_or_grads, num_classes, num_blocks, imfeat=None):
     """Flat fp32 vector in param_spec order (the layout of include/gossipnet_hip.h)."""
     return np.concatenate([np.asarray(params_or_grads[n], dtype=np.float32).reshape(-1)
-                           for n, _ in param_spec(num_classes, num_blocks)])
+                           for n, _ in param_spec(num_classes, num_blocks, imfeat)])

@@ -6,11 +6,11 @@ import torch
 from . import gnet_oracle as go
 
 
-def grad_errors(net, gref, c, b):
+def grad_errors(net, gref, c, b, imfeat=None):
     """Per-tensor max |g_hip - g_ref| / max |g_ref| (TF variable name -> error)."""
     g = net.grads.cpu().numpy()
     off, errs = 0, {}
-    for name, shape in go.param_spec(c, b):
+    for name, shape in go.param_spec(c, b, imfeat):
         k = int(np.prod(shape))
         gr = np.asarray(gref[name], np.float64).reshape(-1)
         m = np.abs(gr).max() if k else 0.0
@@ -36,7 +36,9 @@ def gpu_pins(net, image=None):
     cpu = lambda t: t.cpu().numpy()
     pins = {"pw": [cpu(dv("pw_h1", E * 256).view(E, 256)[e0:e1] > 0), cpu(dv("pw_h2", E * 256).view(E, 256)[e0:e1] > 0),
                    cpu(net.pw_feats[e0:e1] > 0)],
-            "r": [], "h1": [], "sel": [], "q": [], "x": []}
+            "r": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}
+    if getattr(net, "_imfeats", False):
+        pins["im"] = [cpu(a_[d0:d1] > 0) for a_ in net._imfeat_acts]
     # winner sets: the recorded arg-max edge of every (detection, column) with a positive maximum, plus -- for
     # detections flagged as tied -- the extra winners of the tied columns (csrc/backward_edge.hip winners_mark)
     wl_stride = ((E + 64 + 63) // 64) * 64            # edge_geom(): xm_stride = wl_stride, tf_stride

@@ -308,3 +308,37 @@ def test_gradients_bitwise_reproducible():
         runs.append((net.grads.clone(), net.prediction.clone(), net.image_losses.clone()))
     for g, p, l in runs[1:]:
         assert torch.equal(g, runs[0][0]) and torch.equal(p, runs[0][1]) and torch.equal(l, runs[0][2])
+
+
+@pytest.mark.parametrize("imfeat_dim", [-1, 64])
+def test_imfeats_start_features(imfeat_dim):
+    """Image-feature variant (network.py:223-240): block_feats[0] = reduce_imfeats(flatten(crop_windows(imfeats, dets)))
+    from a caller-supplied feature map; forward <= 1e-5, gradients of EVERY tensor (both reduce_imfeats FCs included)
+    <= 1e-5 on the pinned piece."""
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet
+    c, b, ch = 80, 2, 32
+    imf = {"channels": ch, "imfeat_dim": imfeat_dim, "crop": 7, "stride": 16}
+    reset_cfg()
+    cfg.gnet.num_blocks = b
+    cfg.gnet.imfeats = True
+    cfg.gnet.imfeat_dim = imfeat_dim
+    params = go.init_params(c, b, imfeat=imf)
+    net = Gnet(c, imfeat_channels=ch, imfeat_stride=16)
+    net.keep_edge_activations = True
+    net.load_params(params)
+    orc = go.GnetOracle(c, b, params=params, imfeat=imf)
+    rng = np.random.default_rng(0)
+    batch = make_image(90, c, seed=7)
+    batch["imfeats"] = rng.normal(size=(1, 30, 40, ch)).astype(np.float32)
+    ref = orc.forward(batch)
+    net.run(batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(net.roifeats.cpu().numpy(), ref["roifeats"])
+    check_outputs(net, ref)
+    assert rel_err(net.block_feats[0].cpu().numpy(), ref["block_feats"][0].detach().numpy()) < 1e-5
+    _, gpin = orc.forward_backward(batch, pins=gpu_pins(net))
+    errs = grad_errors(net, gpin, c, b, imfeat=imf)
+    assert any(k.startswith("gnet/reduce_imfeats/") for k in errs)
+    assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
+    reset_cfg()

@@ -101,7 +101,26 @@ def test_roi_pool_random_vs_oracle(B, H, W, C, R, ph, pw, scale, seed):
     rgrad = native.roi_pool_grad((B, H, W, C), rois, ram, gtop, ph, pw, scale)
     top.backward(torch.tensor(gtop, device="cuda:0"))     # gradient registration: [data_grad, None]
     got = dd.grad.cpu().numpy()
-    assert np.abs(got - rgrad).max() <= 1e-5 * max(1.0, np.abs(rgrad).max())
+    assert np.array_equal(got, rgrad), "the default backward sums in the CPU kernel's order: bit-exact"
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool_grad
+    ga = roi_pool_grad(dd.detach(), torch.tensor(rois, device="cuda:0"), am, torch.tensor(gtop, device="cuda:0"), ph, pw, scale,
+                       deterministic=False).cpu().numpy()
+    assert np.abs(ga - _scatter_by_argmax(ram, gtop, rois, (B, H, W, C))).max() <= 1e-5 * max(1.0, np.abs(rgrad).max())
+
+
+def _scatter_by_argmax(argmax, grad, rois, shape):
+    """The plain arg-max scatter (what roi_pool_bwd_atomic_f32 computes).  The reference's RoiPoolGrad is NOT always this
+    sum: its feasible-bin / in-ROI tests (roi_pooling_op.cc:405-431) drop a pooled element whose arg-max pixel lies one
+    past the rounded ROI end (ceil((pw + 1) * bin) can exceed the ROI width in float) -- the default backward
+    reproduces that, bit for bit."""
+    B, H, W, C = shape
+    out = np.zeros((B, H * W * C), np.float64)
+    bidx = np.asarray(rois)[:, 0].astype(np.int64)
+    for r in range(argmax.shape[0]):
+        a = argmax[r].reshape(-1); g = grad[r].reshape(-1).astype(np.float64)
+        m = a >= 0
+        np.add.at(out[bidx[r]], a[m], g[m])
+    return out.reshape(shape)
 
 
 def test_roi_pool_attr_errors():
@@ -185,3 +204,56 @@ def test_crop_windows_matches_oracle():
     assert np.array_equal(boxes.cpu().numpy(), ref_boxes)
     rtop, _ = native.roi_pool(fmap, ref_boxes, 7, 7, 1.0 / 16)
     assert np.array_equal(feats.cpu().numpy(), rtop)
+
+
+@pytest.mark.parametrize("m,k,n,relu", [(37, 64, 128, 1), (300, 1568, 128, 1), (130, 392, 260, 0)])
+def test_fc_layers_against_torch(m, k, n, relu):
+    """csrc/fc.hip (reduce_imfeats FCs, network.py:223-240): y = act(x.w + b) and its gradients vs a plain fp64 reference."""
+    from gossipnet_amd.fc import fc_forward, fc_backward, FcWorkspace
+    rng = np.random.default_rng(m + k)
+    x = rng.normal(size=(m, k)).astype(np.float32); w = (rng.normal(size=(k, n)) / np.sqrt(k)).astype(np.float32)
+    b = rng.normal(size=n).astype(np.float32); dy = rng.normal(size=(m, n)).astype(np.float32)
+    d = "cuda:0"
+    ws = FcWorkspace(torch.device(d))
+    X, W, Bv, DY = (torch.tensor(a, device=d) for a in (x, w, b, dy))
+    y = fc_forward(X, W, Bv, relu, ws)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    dw = torch.empty(k, n, device=d); db = torch.empty(n, device=d)
+    dx = fc_backward(X, W, y, DY, relu, dw, db, ws, True)
+    dz = dy.astype(np.float64) * ((y.cpu().numpy() > 0) if relu else 1.0)
+    for got, want in ((dw, x.astype(np.float64).T @ dz), (db, dz.sum(0)), (dx, dz @ w.astype(np.float64).T)):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_roi_pool_contract_shape():
+    """SURVEY 8a R1 shape: R = 2000 enlarged detection windows on a [1, 38, 63, 1024] map, 7 x 7 at 1/16 (401 MB per
+    output): top / argmax bit-exact against the C oracle; the deterministic backward bit-exact, the atomic one <= 1e-5."""
+    from gossipnet_amd.network import crop_windows
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool_grad
+    from tests.util import make_image
+    rng = np.random.default_rng(1)
+    dets = make_image(2000, 80, seed=3)["dets"] * np.float32(1.5)          # boxes on a 1008 x 608 image -> 63 x 38 at 1/16
+    fmap = rng.normal(size=(1, 38, 63, 1024)).astype(np.float32)
+    fm = torch.tensor(fmap, device="cuda:0")
+    feats, boxes = crop_windows(fm, torch.tensor(dets, device="cuda:0"), 16)
+    torch.cuda.synchronize()
+    rb = boxes.cpu().numpy()
+    rtop, ram = native.roi_pool(fmap, rb, 7, 7, 1.0 / 16)
+    assert np.array_equal(feats.cpu().numpy(), rtop)
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool_raw
+    _, am = roi_pool_raw(fm, boxes, 7, 7, 1.0 / 16)
+    assert np.array_equal(am.cpu().numpy(), ram)
+    # backward on a channel slice of the oracle (the O(H W C R) CPU loop is slow): first 64 channels
+    g = rng.normal(size=rtop.shape).astype(np.float32)
+    got = roi_pool_grad(fm, boxes, am, torch.tensor(g, device="cuda:0"), 7, 7, 1.0 / 16).cpu().numpy()
+    got_a = roi_pool_grad(fm, boxes, am, torch.tensor(g, device="cuda:0"), 7, 7, 1.0 / 16, deterministic=False).cpu().numpy()
+    cs = 64
+    am_s = (ram[..., :cs] // 1024) * cs + (ram[..., :cs] % 1024)             # indices within the sliced image
+    am_s = np.where(ram[..., :cs] < 0, -1, am_s).astype(np.int32)
+    ref = native.roi_pool_grad((1, 38, 63, cs), rb, am_s, np.ascontiguousarray(g[..., :cs]), 7, 7, 1.0 / 16)
+    assert np.array_equal(got[..., :cs], ref)
+    exact = _scatter_by_argmax(ram[..., :cs] if False else am_s, np.ascontiguousarray(g[..., :cs]), rb, (1, 38, 63, cs))
+    assert np.abs(got_a[..., :cs] - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
