@@ -302,18 +302,18 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
 }
 
 constexpr int EFW_WAVES = 4;      // waves per workgroup; 2 workgroups per CU.  (6 waves = 3 per SIMD measured 28% SLOWER)
-constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 32 * E_LD2) * sizeof(float);
+constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 2 * D_P) * sizeof(float);
 
 // TRAIN: record the arg-max edge of every (centre, column) for the sparse SegmentMax backward.  The pw_fc1
 // activations are NOT kept: the backward pass recomputes them for the ~26 % of the edges that carry gradient
 // (backward_edge.hip) -- storing them cost 0.37 GB of HBM writes per launch (2.8 TB/s on an MFMA-bound kernel)
 // and 5.9 GB of workspace for the bench batch.  KEEP (tests / debugging) stores them after all.
 template <bool TRAIN, bool KEEP>
-__global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArgs a) {
+__global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sWp = smem;                           // [64][36]  Wp^T
-  float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T
-  float* sHw = sW2 + D_P * E_LD2;              // per wave [32][68]
+  float* sWp = smem;                           // [64][36]  Wp^T[f][pf]
+  float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T[j][f]
+  float* sHw = sW2 + D_P * E_LD2;              // per wave: rc rows of the tile's first two centres [2][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < D_P * D_E; i += 64 * EFW_WAVES) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
   for (int i = tid; i < D_P * D_P; i += 64 * EFW_WAVES) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
@@ -329,16 +329,22 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
   const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const int gw = lb * EFW_WAVES + wave;
   const int t0 = gw * per, t1 = min(ntiles, t0 + per);
-  float* sh = sHw + wave * (32 * E_LD2);
+  float* sRC = sHw + wave * (2 * D_P);
   if (t0 >= t1) return;
   const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
   // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
   // tools/mfma_valu_overlap.hip) -- every vector instruction in this loop is paid in MFMA time.  Hence:
-  //   * self pairs and the edge tail are resolved once per batch into edge_nz (index of a zero row of rn),
-  //     so the tile loop has no clamps and no (c != n) selects;
-  //   * neighbour indices arrive in the accumulator row layout (four int4 per lane), no cross-lane moves;
+  //   * LAYER 1 IS COMPUTED TRANSPOSED: h1^T[f][edge] = Wp^T . P^T (the MFMA's operands swapped), so that its
+  //     accumulators -- lane = edge, registers = features 8 g + 4 half + q -- ARE the A operand of layer 2
+  //     (lane = row, 4 consecutive k per 16-byte group: the k pairing of mma_abt).  No LDS round trip, no
+  //     barrier and no layout shuffle between the two layers; every element is the same chain of products in the
+  //     same order as before (bit-identical h1 and h2);
+  //   * the accumulators start from rc[c] + rn[n] read as the lane's OWN rows (eight 16-byte gathers of rn per
+  //     lane and tile instead of 32 4-byte ones; rc rows of the tile's first two centres go through 512 bytes of
+  //     LDS and come back as broadcast reads); self pairs and the edge tail are resolved once per batch into
+  //     edge_nz (index of a zero row of rn): no clamps, no (c != n) selects;
   //   * the segment maximum is taken on h2 + b2 and rectified once per segment, not per element.
-  // ---- prefetch state for the first tile
+  // ---- prefetch state for the first tile (lane = edge e0 + col, both half-waves alike)
   int nx_c = -1;
   { const int e = t0 * 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
   f32x4 pa[4];
@@ -347,30 +353,19 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
 #pragma unroll
     for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
   }
-  // neighbour rows of this lane's 16 accumulator rows crow(r, half) = 8 (r >> 2) + 4 half + (r & 3)
-  int4 nz4[4];
-#define EF_LOAD_NZ(tile_)                                                                              \
-  do {                                                                                                 \
-    const int4* np_ = reinterpret_cast<const int4*>(a.edge_nz + (size_t)(tile_) * 32 + 4 * half);      \
-    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) nz4[g_] = np_[2 * g_];                            \
-  } while (0)
-#define EF_NZ(r_) (((r_) & 3) == 0 ? nz4[(r_) >> 2].x : ((r_) & 3) == 1 ? nz4[(r_) >> 2].y : ((r_) & 3) == 2 ? nz4[(r_) >> 2].z : nz4[(r_) >> 2].w)
-  EF_LOAD_NZ(t0);
-  float rn0[16], rn1[16];
+  int nx_nz = a.edge_nz[t0 * 32 + col];                                // (the tail of edge_nz is padded)
+  float4 rnv[8];                                                       // rn[n][8 g + 4 half .. + 3]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const unsigned on = (unsigned)EF_NZ(r) * (D_P * 4u) + 4u * col;
-    rn0[r] = ldg_b(a.rn, on); rn1[r] = ldg_b(a.rn, on + 128u);
-  }
-  // centre rows of the first two segments of the next tile (A = first centre, B = second or the same)
+  for (int g = 0; g < 8; ++g) rnv[g] = ldg4_b(a.rn, (unsigned)nx_nz * (D_P * 4u) + 32u * g + 16u * half);
+  // centre rows of the first two segments of the next tile (A = first centre, B = second or the same): lanes
+  // 0-15 fetch the 16-byte chunks of A's row, lanes 16-31 those of B's
   int cA = __builtin_amdgcn_readfirstlane(nx_c), cB = cA, hiA = 32;
   {
     const int prev = __shfl_up(nx_c, 1);
     const unsigned hm = (unsigned)__ballot(col > 0 && nx_c != prev && nx_c >= 0);
     if (hm) { hiA = __builtin_ctz(hm); cB = __builtin_amdgcn_readlane(nx_c, hiA); }
   }
-  float rcA0 = a.rc[(unsigned)max(cA, 0) * D_P + col], rcA1 = a.rc[(unsigned)max(cA, 0) * D_P + 32 + col];
-  float rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col], rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
+  float4 rcAB = ldg4_b(a.rc, (unsigned)max((lane & 16) ? cB : cA, 0) * (D_P * 4u) + 16u * (lane & 15));
   int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
   int g0 = 0, g1 = 0;                                                  // edge that first attains m0 / m1 (TRAIN)
   // does the first centre of this range start in the previous wave's range?
@@ -381,7 +376,6 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
     const int my_c = nx_c;
     const int nrows = min(32, a.n_edge - e0);
     const int thiA = hiA;
-    const float trcA0 = rcA0, trcA1 = rcA1, trcB0 = rcB0, trcB1 = rcB1;
     // segment heads of THIS tile (bit r set = row r starts a new centre)
     unsigned heads;
     {
@@ -389,26 +383,30 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
       heads = (unsigned)__ballot(half == 0 && col < nrows && (col == 0 || my_c != prev));
     }
     const int nseg = __popc(heads);
+    // rc rows of centres A / B -> LDS (this wave's 512 bytes), read back as the lane's own centre row
+    if (lane < 32) *reinterpret_cast<float4*>(sRC + 4 * lane) = rcAB;
     nx_c = -1;
     if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
-    EF_LOAD_NZ(t + 1);                                 // the tail of edge_nz is padded: no bounds check
-    f32x16 h1a, h1b;
-    if (nseg == 1) {                                   // one centre fills the tile
+    nx_nz = a.edge_nz[e0 + 32 + col];
+    wave_lds_sync();
+    f32x16 h1a, h1b;                                   // h1^T: lane = edge, register r = feature 8 (r >> 2) + 4 half + (r & 3) [+ 32]
+    if (nseg <= 2) {                                   // centre rows were prefetched (A below thiA, B from it)
+      const float* rp = sRC + (col < thiA ? 0 : D_P) + 4 * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { h1a[r] = trcA0 + rn0[r]; h1b[r] = trcA1 + rn1[r]; }
-    } else if (nseg == 2) {                            // centre rows were prefetched (A below thiA, B from it)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool inA = crow(r, half) < thiA;
-        h1a[r] = (inA ? trcA0 : trcB0) + rn0[r];
-        h1b[r] = (inA ? trcA1 : trcB1) + rn1[r];
+      for (int g = 0; g < 4; ++g) {
+        const float4 ca = *reinterpret_cast<const float4*>(rp + 8 * g);
+        const float4 cb = *reinterpret_cast<const float4*>(rp + 32 + 8 * g);
+        h1a[4 * g + 0] = ca.x + rnv[g].x; h1a[4 * g + 1] = ca.y + rnv[g].y; h1a[4 * g + 2] = ca.z + rnv[g].z; h1a[4 * g + 3] = ca.w + rnv[g].w;
+        h1b[4 * g + 0] = cb.x + rnv[4 + g].x; h1b[4 * g + 1] = cb.y + rnv[4 + g].y; h1b[4 * g + 2] = cb.z + rnv[4 + g].z; h1b[4 * g + 3] = cb.w + rnv[4 + g].w;
       }
     } else {                                           // many short segments: gather the centre row per edge
+      const unsigned oc = (unsigned)max(my_c, 0) * (D_P * 4u) + 16u * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned oc = (unsigned)max(row_bcast(my_c, r, half), 0) * D_P + col;
-        h1a[r] = a.rc[oc] + rn0[r];
-        h1b[r] = a.rc[oc + 32] + rn1[r];
+      for (int g = 0; g < 4; ++g) {
+        const float4 ca = ldg4_b(a.rc, oc + 32u * g);
+        const float4 cb = ldg4_b(a.rc, oc + 128u + 32u * g);
+        h1a[4 * g + 0] = ca.x + rnv[g].x; h1a[4 * g + 1] = ca.y + rnv[g].y; h1a[4 * g + 2] = ca.z + rnv[g].z; h1a[4 * g + 3] = ca.w + rnv[g].w;
+        h1b[4 * g + 0] = cb.x + rnv[4 + g].x; h1b[4 * g + 1] = cb.y + rnv[4 + g].y; h1b[4 * g + 2] = cb.z + rnv[4 + g].z; h1b[4 * g + 3] = cb.w + rnv[4 + g].w;
       }
     }
     {
@@ -419,14 +417,14 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
         const f32x4 av = pa[k];
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.x, av.x, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.x, av.x, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.y, av.y, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.y, av.y, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.z, av.z, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.z, av.z, h1b, 0, 0, 0);
+        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.w, av.w, h1a, 0, 0, 0);
+        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.w, av.w, h1b, 0, 0, 0);
       }
     }
     // ---- prefetch for the next tile: P rows, neighbour rows, the first two centre rows
@@ -435,56 +433,55 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
 #pragma unroll
       for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
     }
-    wave_lds_sync();        // the previous tile's layer-2 reads of sh are complete
-    {
-      float* hp = sh + (4 * half) * E_LD2 + col;         // + crow(r, 0) * E_LD2: compile-time offsets
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        hp[crow(r, 0) * E_LD2] = relu_bits(h1a[r]);
-        hp[crow(r, 0) * E_LD2 + 32] = relu_bits(h1b[r]);
-      }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned on = (unsigned)EF_NZ(r) * (D_P * 4u) + 4u * col;
-      rn0[r] = ldg_b(a.rn, on); rn1[r] = ldg_b(a.rn, on + 128u);
-    }
+    for (int g = 0; g < 8; ++g) rnv[g] = ldg4_b(a.rn, (unsigned)nx_nz * (D_P * 4u) + 32u * g + 16u * half);
     {
       cA = __builtin_amdgcn_readfirstlane(nx_c); cB = cA; hiA = 32;
       const int prev = __shfl_up(nx_c, 1);
       const unsigned hm = (unsigned)__ballot(col > 0 && nx_c != prev && nx_c >= 0);
       if (hm) { hiA = __builtin_ctz(hm); cB = __builtin_amdgcn_readlane(nx_c, hiA); }
-      rcA0 = a.rc[(unsigned)max(cA, 0) * D_P + col]; rcA1 = a.rc[(unsigned)max(cA, 0) * D_P + 32 + col];
-      rcB0 = a.rc[(unsigned)max(cB, 0) * D_P + col]; rcB1 = a.rc[(unsigned)max(cB, 0) * D_P + 32 + col];
+      rcAB = ldg4_b(a.rc, (unsigned)max((lane & 16) ? cB : cA, 0) * (D_P * 4u) + 16u * (lane & 15));
     }
-    f32x16 h2a = zero16(), h2b = zero16();
-    {                                                   // both column tiles share the A fragments of h1
-      const float* ap = sh + col * E_LD2 + 4 * half;
-      const float* b0 = sW2 + col * E_LD2 + 4 * half;
-      const float* b1 = b0 + 32 * E_LD2;
-#pragma unroll 4
-      for (int k = 0; k < D_P; k += 8) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h1a[r] = relu_bits(h1a[r]); h1b[r] = relu_bits(h1b[r]); }
+    if (KEEP) {
+      // tests / debugging: relu(pw_fc1) rows, 16 bytes per (lane, feature group); rows past E land in the slack
+      float* dst = a.h1_out + (size_t)(e0 + col) * D_P + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(h1a[4 * g], h1a[4 * g + 1], h1a[4 * g + 2], h1a[4 * g + 3]);
+        *reinterpret_cast<float4*>(dst + 32 + 8 * g) = make_float4(h1b[4 * g], h1b[4 * g + 1], h1b[4 * g + 2], h1b[4 * g + 3]);
       }
     }
-    if (KEEP) {
-      // whole 256-byte rows, 16 B per lane; behind this tile's loads
-      float* dst = a.h1_out + (size_t)e0 * D_P;
+    f32x16 h2a = zero16(), h2b = zero16();
+    {                                                   // layer 2: A = the h1^T registers, B = W2^T from LDS
+      const float* b0 = sW2 + col * E_LD2 + 4 * half;
+      const float* b1 = b0 + 32 * E_LD2;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int row = 4 * q + (lane >> 4);
-        *reinterpret_cast<float4*>(dst + row * D_P + 4 * (lane & 15)) = *reinterpret_cast<const float4*>(sh + row * E_LD2 + 4 * (lane & 15));
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * g);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * g);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 0], bv0.x, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 0], bv1.x, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 1], bv0.y, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 1], bv1.y, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 2], bv0.z, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 2], bv1.z, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 3], bv0.w, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 3], bv1.w, h2b, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 32 + 8 * g);
+        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 32 + 8 * g);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 0], bv0.x, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 0], bv1.x, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 1], bv0.y, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 1], bv1.y, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 2], bv0.z, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 2], bv1.z, h2b, 0, 0, 0);
+        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 3], bv0.w, h2a, 0, 0, 0);
+        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 3], bv1.w, h2b, 0, 0, 0);
       }
     }
     // pre-activations; relu is monotone, so max(relu(v)) = relu(max(v)): rectify once per segment.  The
@@ -586,8 +583,6 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 2) edge_fwd_w(const EdgeFwdArg
       else __hip_atomic_fetch_max(ad, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-#undef EF_LOAD_NZ
-#undef EF_NZ
 }
 
 // ------------------------------------------------------------------------------------------
@@ -805,7 +800,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
 
   const int ntile_n = (N + 31) / 32;
   // edge_fwd_w partition (2 workgroups per CU): wave-owned contiguous tile ranges
-  const int ef_wg = max(1, min(2 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+  const int ef_wg = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
   const bool keep_h1 = training == 2;
   if (E > 0) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
