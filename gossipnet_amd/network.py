@@ -118,6 +118,10 @@ class DeviceBatch(object):
         self.dets, self.det_scores, self.det_classes = t(dets), t(scores), t(classes)
         self.gt_boxes, self.gt_crowd, self.gt_classes = t(gtb), t(crowd), t(gcls)
         self.det_off, self.gt_off, self.anno_off = t(self.det_off_h), t(self.gt_off_h), t(self.anno_off_h)
+        self.ready = None
+        if torch.device(device).type == "cuda":
+            self.ready = torch.cuda.Event()                 # the uploads above are complete once this event is
+            self.ready.record(torch.cuda.current_stream(device))
 
     def c_inputs(self):
         a = _lib.gnet_inputs()
@@ -224,8 +228,9 @@ class Gnet(object):
         self._ws = None
         self._buf = None
         self._shape = None
-        self._row_ptr_tmp = None
-        self._scratch_tmp = None
+        self._row_ptr_tmp = [None, None]
+        self._scratch_tmp = [None, None]
+        self._side = None
         self.grad_scale = 1.0      # scale of the data-loss gradient (1 / images of the global step: mean over images)
         self.reg_scale = 1.0       # scale of the l2-regulariser gradient (1 / world size under a SUM all-reduce)
         # tests / debugging: keep the per-block pw_fc1 activations [E,64] in HBM (Gnet.debug_view("blk_h1", ...));
@@ -291,21 +296,43 @@ class Gnet(object):
         return self._ws[off:off + count * esz].view(dtype)
 
     def _count_graph(self, db):
-        """Pass 1 of the graph build (asynchronous): per-row neighbour counts + scan."""
-        lib, s = self._lib, self._stream()
+        """Pass 1 of the graph build (per-row neighbour counts + scan) on a SIDE stream, with the edge count copied to
+        pinned host memory there.  The host then waits for that small kernel only -- never for the main stream -- so
+        the launches of step i+1 are issued while step i still runs (the edge count is the one value a step needs on
+        the host: it sizes the workspace and the grids).  Two alternating count buffers: the main stream may still be
+        reading the previous step's row_ptr copy."""
+        lib = self._lib
         N = db.n_det
-        if self._row_ptr_tmp is None or self._row_ptr_tmp.numel() < N + 1:
-            self._row_ptr_tmp = torch.empty(N + 1, dtype=torch.int32, device=self.device)
-            self._scratch_tmp = torch.empty(N + 1024, dtype=torch.int32, device=self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._e_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._rp_free = [None, None]
+        k = self._count_slot = (getattr(self, "_count_slot", 1) + 1) & 1
+        if self._row_ptr_tmp[k] is None or self._row_ptr_tmp[k].numel() < N + 1:
+            self._row_ptr_tmp[k] = torch.empty(N + 1, dtype=torch.int32, device=self.device)
+            self._scratch_tmp[k] = torch.empty(N + 1024, dtype=torch.int32, device=self.device)
         thr = float(cfg.gnet.neighbor_thresh)
-        _lib.check(lib.gnet_graph_count(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, _vp(self._row_ptr_tmp),
-                                        _vp(self._scratch_tmp), s), "gnet_graph_count")
+        if db.ready is not None:
+            self._side.wait_event(db.ready)  # the inputs' upload (recorded at DeviceBatch creation) -- NOT the main stream's queue
+        if self._rp_free[k] is not None:
+            self._side.wait_event(self._rp_free[k])
+        with torch.cuda.stream(self._side):
+            s = C.c_void_p(self._side.cuda_stream)
+            _lib.check(lib.gnet_graph_count(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, _vp(self._row_ptr_tmp[k]),
+                                            _vp(self._scratch_tmp[k]), s), "gnet_graph_count")
+            if N > 0:
+                self._e_host[k].copy_(self._row_ptr_tmp[k][N:N + 1], non_blocking=True)
+            self._count_done = torch.cuda.Event()
+            self._count_done.record(self._side)
 
     def _build_graph(self, db, training):
         lib, s = self._lib, self._stream()
         N = db.n_det
         thr = float(cfg.gnet.neighbor_thresh)
-        E = int(self._row_ptr_tmp[N].item()) if N > 0 else 0     # the one host sync of a step
+        k = self._count_slot
+        self._count_done.synchronize()                           # the one host wait of a step: the side stream's count only
+        E = int(self._e_host[k][0]) if N > 0 else 0
+        torch.cuda.current_stream(self.device).wait_event(self._count_done)
         shape = _lib.gnet_shape(db.n_img, N, db.n_gt, E, db.n_anno)
         training = self._mode(training)
         need = lib.gnet_workspace_bytes(C.byref(self._cfg), C.byref(shape), int(training))
@@ -317,7 +344,9 @@ class Gnet(object):
                                  C.byref(buf)), "gnet_plan")
         buf.profiler = self._profiler
         self._buf, self._shape, self._training = buf, shape, training
-        self._view(buf.row_ptr, N + 1, torch.int32).copy_(self._row_ptr_tmp[:N + 1])
+        self._view(buf.row_ptr, N + 1, torch.int32).copy_(self._row_ptr_tmp[k][:N + 1])
+        self._rp_free[k] = torch.cuda.Event()
+        self._rp_free[k].record(torch.cuda.current_stream(self.device))
         _lib.check(lib.gnet_graph_fill(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr, buf.edge_c,
                                        buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
         if training and E > 0:
