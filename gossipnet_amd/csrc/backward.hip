@@ -785,7 +785,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   const int g_node = min((N + 63) / 64, 256);                                           // node-kernel workgroups (64 detections each)
   const int g_head = min((N + 31) / 32, 256);
   const int etiles = (E + 31) / 32;
-  const int g_edge = E > 0 ? 256 : 0;                                                  // edge_bwd_w workgroups (one per CU)
+  const int g_edge = E > 0 ? 512 : 0;                                                  // edge_bwd_w workgroups (two per CU)
   const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
   const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (N + 3) / 4)) : 0;          // node-sum workgroups
   const int g_w1c = E > 0 ? max(1, min(128, 256 / (2 * L.cprime))) : 0;               // node chunks per class row

@@ -331,10 +331,9 @@ struct EdgeBwdWArgs {
 };
 
 constexpr int EBW_WAVES = 4;
-constexpr int EBW_LDP = D_E + 1;                                // P tile row stride (scalar accesses only)
 constexpr int EBW_SLOTS = 3;                                    // detections of a tile handled between two LDS hand-offs
-constexpr int EBW_WAVE_FLOATS = 32 * LD64 + 32 * EBW_LDP + 32 + EBW_SLOTS * 128;   // h1/g1 tile, P tile, edge ids [32], RJ/DV [slots][64]
-constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_E * LD64 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);
+constexpr int EBW_WAVE_FLOATS = 32 * LD64 + 32 + EBW_SLOTS * 128;   // h1/g1 tile, edge ids [32], RJ/DV [slots][64]
+constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);   // 68 KB: two workgroups per CU
 
 // Every wave owns whole 32-winner tiles of the block's winner list (rows sorted by centre), no workgroup barrier
 // in the tile loop.  Per tile:
@@ -351,21 +350,18 @@ constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_E * LD64 + D_P * LD64 +
 // right after the g1 MFMAs (in flight during the 64 d Wp / d P MFMAs).  d_pw[e] += d P uses returnless float
 // atomics: an edge is a row of exactly one tile per block and the blocks are separate launches, so every element
 // receives its additions in launch order -- the sum stays bitwise reproducible, and no old value has to be fetched.
-__global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWArgs a) {
+__global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sWpT = smem;                          // [64][36]  Wp^T[f][pf]: B operand of h1 (16-byte reads along pf)
-  float* sWp = sWpT + D_P * LD32;              // [32][68]  Wp[pf][f]:   B operand of d P (16-byte reads along f)
-  float* sW2 = sWp + D_E * LD64;               // [64][68]  W2[f][j]:    B operand of g1 (16-byte reads along j)
+  float* sW2 = sWpT + D_P * LD32;              // [64][68]  W2[f][j]:    B operand of g1 (16-byte reads along j)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* sH = sW2 + D_P * LD64 + wave * EBW_WAVE_FLOATS;   // [32][68] bias -> h1 -> g1 of this wave's tile
-  float* sPt = sH + 32 * LD64;                 // [32][33]  P rows of the tile
-  int* sE = reinterpret_cast<int*>(sPt + 32 * EBW_LDP);    // [32] edge of every tile row
+  int* sE = reinterpret_cast<int*>(sH + 32 * LD64);        // [32] edge of every tile row
   int* sRJ = sE + 32;                          // [slots][64] tile row of column j's winner (-1: not in this tile)
   float* sDV = reinterpret_cast<float*>(sRJ + EBW_SLOTS * 64);   // [slots][64] d_pc[c][j]
   for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) {
     const float v = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];          // W1[pf = i & 31][f = i >> 5]
     sWpT[(i >> 5) * LD32 + (i & 31)] = v;
-    sWp[(i & 31) * LD64 + (i >> 5)] = v;
   }
   for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
   __syncthreads();
@@ -388,8 +384,6 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
   // records of the next tile: edge, centre, neighbour row (lane = row, both half-waves alike), P in A layout
   int nx2_e = 0;                               // list entry two tiles ahead
   int nx_e = 0, nx_c = -1, nx_nz = 0;
-  f32x4 nx_pa[4];
-  float4 nx_x[8], nx_y[8];                     // rc[c] / rn[n] of rows 4 i + q4, chunk f4 (added at the top of the tile)
   // column records (lane = column j) of the first two detections of the next tile
   int apA = -1, apB = -1, apC = -1, tfA = 0, tfB = 0, tfC = 0;
   float dvA = 0.f, dvB = 0.f, dvC = 0.f;
@@ -399,17 +393,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
     nx_e = nx2_e;                                                                                       \
     nx_c = (tile_) * 32 + col < W ? a.edge_c[nx_e] : -1;                                                \
     nx_nz = a.edge_nz[nx_e];                                                                            \
-    const float* ap_ = a.pw + (size_t)nx_e * D_E + 4 * half;                                            \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) nx_pa[k_] = *reinterpret_cast<const f32x4*>(ap_ + 8 * k_); \
   } while (0)
-#define EBW_LOAD_BIAS()          /* uses nx_c / nx_nz of the next tile */                               \
+#define EBW_LOAD_BIAS()          /* column records of the next tile's first detections; uses nx_c */                               \
   do {                                                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
-      const int row_ = 4 * i_ + q4;                                                                     \
-      const int cr_ = max(__shfl(nx_c, row_), 0), nzr_ = __shfl(nx_nz, row_);                           \
-      nx_x[i_] = ldg4_b(a.rc, (unsigned)cr_ * (D_P * 4u) + 16u * f4);                                   \
-      nx_y[i_] = ldg4_b(a.rn, (unsigned)nzr_ * (D_P * 4u) + 16u * f4);                                  \
-    }                                                                                                   \
     int cA_ = __builtin_amdgcn_readfirstlane(nx_c), cB_ = cA_, cC_ = cA_;                               \
     {                                                                                                   \
       const int prev_ = __shfl_up(nx_c, 1);                                                             \
@@ -435,17 +421,31 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
     const int my_e = nx_e, my_c = nx_c;
     const int tapA = apA, tapB = apB, tapC = apC, ttfA = tfA, ttfB = tfB, ttfC = tfC;
     const float tdvA = dvA, tdvB = dvB, tdvC = dvC;
-    // ---- stage: edge ids, P tile, bias tile (rc + rn: the forward kernel's operand order)
+    // ---- stage: edge ids, bias tile (rc + rn: the forward kernel's operand order) in two batches of 16 rows (registers)
+    const int my_nz = nx_nz;
     if (half == 0) sE[col] = my_e;
+    f32x4 pa[4];
+    {
+      const float* ap = a.pw + (size_t)my_e * D_E + 4 * half;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float* pp = sPt + col * EBW_LDP + 4 * half + 8 * k;
-      pp[0] = nx_pa[k].x; pp[1] = nx_pa[k].y; pp[2] = nx_pa[k].z; pp[3] = nx_pa[k].w;
+      for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      *reinterpret_cast<float4*>(sH + (4 * i + q4) * LD64 + 4 * f4) =
-          make_float4(nx_x[i].x + nx_y[i].x, nx_x[i].y + nx_y[i].y, nx_x[i].z + nx_y[i].z, nx_x[i].w + nx_y[i].w);
+    for (int hb = 0; hb < 2; ++hb) {
+      float4 x[4], y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 4 * (4 * hb + i) + q4;
+        const int cr = max(__shfl(my_c, row), 0), nzr = __shfl(my_nz, row);
+        x[i] = ldg4_b(a.rc, (unsigned)cr * (D_P * 4u) + 16u * f4);
+        y[i] = ldg4_b(a.rn, (unsigned)nzr * (D_P * 4u) + 16u * f4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(sH + (4 * (4 * hb + i) + q4) * LD64 + 4 * f4) =
+            make_float4(x[i].x + y[i].x, x[i].y + y[i].y, x[i].z + y[i].z, x[i].w + y[i].w);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     wave_lds_sync();
     // ---- h1 = relu(P . Wp + (rc + rn)): the forward kernel's operation sequence (same bits)
     {
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
       const float* b1 = b0 + 32 * LD32;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 av = nx_pa[k];
+        const f32x4 av = pa[k];
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
         h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
@@ -532,6 +532,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
           w2acc[4 * q + 1] = fmaf(dm, hv.y, w2acc[4 * q + 1]);
           w2acc[4 * q + 2] = fmaf(dm, hv.z, w2acc[4 * q + 2]);
           w2acc[4 * q + 3] = fmaf(dm, hv.w, w2acc[4 * q + 3]);
+          if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight quads in flight (registers)
         }
       }
       wave_lds_sync();
@@ -631,29 +632,31 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
     if (t + 1 < t1) EBW_LOAD_BIAS();
     // ---- d Wp += P^T . g1
     {
-      const float* X = sPt + col;
+      // X = P^T: P[row][pf = col] gathered again (the rows were read for the h1 MFMAs: L1 / L2 hits)
       const float* Y = sH + col;
+      float xs[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) xs[kk] = ldg_b(a.pw, (unsigned)sE[2 * kk + half] * (D_E * 4u) + 4u * col);
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const int row = 2 * kk + half;
-        const float x = X[row * EBW_LDP];
-        aWp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, Y[row * LD64], aWp0, 0, 0, 0);
-        aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, Y[row * LD64 + 32], aWp1, 0, 0, 0);
+        aWp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64], aWp0, 0, 0, 0);
+        aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64 + 32], aWp1, 0, 0, 0);
       }
     }
     // ---- d P = g1 . Wp^T;  d_pw[e] += d P
     {
       f32x16 acc = zero16();
       const float* ap = sH + col * LD64 + 4 * half;
-      const float* bp = sWp + col * LD64 + 4 * half;                // B[k = f][n = pf] = Wp[pf = col][f]
+      const float* bp = sWpT + (4 * half) * LD32 + col;             // B[k = f][n = pf] = Wp[pf = col][f] = sWpT[f][pf]
 #pragma unroll
       for (int k = 0; k < D_P; k += 8) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + k);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD32], acc, 0, 0, 0);
+        if ((k & 8) != 0) __builtin_amdgcn_sched_barrier(0);
       }
       // rows past the list (last tile) go to the slack row E of d_pw: unconditional, no divergent branches
 #pragma unroll
@@ -679,7 +682,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 1) edge_bwd_w(const EdgeBwdWAr
 #undef EBW_LOAD_BIAS
   // ---- partial weight gradients of this workgroup: the four waves' accumulators are added in wave order
   __syncthreads();
-  float* red = sW2 + D_P * LD64;               // the waves' tile areas: 4 * 3648 floats >= 4096 + 2048 + 64
+  float* red = sW2;                            // W2 + the waves' tile areas: 4352 + 4 * 2592 floats >= 4096 + 2048 + 64
   float* redW2 = red;                          // [f][j]
   float* redWp = red + D_P * D_P;              // [2][16][64] accumulator registers
   float* redB = redWp + 2 * 16 * 64;           // [64]
