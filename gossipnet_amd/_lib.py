@@ -58,7 +58,7 @@ EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_grap
            "gnet_forward", "gnet_loss", "gnet_backward", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
            "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
-           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward"]
+           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
             "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials"]
@@ -139,6 +139,8 @@ def load():
     lib.gnet_fc_forward.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, vp, sz, vp]
     lib.gnet_fc_backward.restype = C.c_int
     lib.gnet_fc_backward.argtypes = [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp, vp, vp, vp, sz, vp]
+    lib.gnet_box_iou.restype = C.c_int
+    lib.gnet_box_iou.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]
     lib.gnet_version.restype = C.c_char_p
     lib.gnet_version.argtypes = []
     _lib = lib

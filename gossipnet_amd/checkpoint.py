@@ -1,17 +1,31 @@
 """Checkpoints keyed by the reference's TF variable names.
 
 The reference saves with tf.train.Saver under `gnet-<iteration>` and links the best model as `./gnet_best`
-(train.py:56-61,288,337,345).  TensorFlow checkpoints cannot be read without TensorFlow; the exchange
-format here is an .npz whose keys are exactly the TF variable names (`gnet/block3/pw_fc1/weights`, ...,
-`global_step`), which is what `tf.train.load_variable` / a one-line export script produces on the
-reference side.  Optimizer slots use TF's slot naming (`<var>/Adam`, `<var>/Adam_1`, `<var>/Momentum`).
+(train.py:56-61,288,337,345).  Two on-disk formats, same keys (exactly the TF variable names,
+`gnet/block3/pw_fc1/weights`, ..., `global_step`; optimizer slots `<var>/Adam`, `<var>/Adam_1`, `<var>/Momentum`):
+  * `<path>.npz` (default of save());
+  * the Saver V2 bundle itself, `<prefix>.index` + `<prefix>.data-00000-of-00001`, read and written WITHOUT TensorFlow
+    by gossipnet_amd/tf_bundle.py -- load() picks it when `<prefix>.index` exists, save(..., fmt="tf") writes it.
+    (Format restated from the TF sources; not validated against a real checkpoint: none is available here.)
 """
 import os
 
 import numpy as np
 
 
-def save(net, path, global_step=0, optimizer=None):
+def latest_checkpoint(directory="."):
+    """tf.train.get_checkpoint_state(dir).model_checkpoint_path (train.py:274-277): first line of the `checkpoint` file."""
+    f = os.path.join(directory, "checkpoint")
+    if not os.path.exists(f):
+        return None
+    for line in open(f):
+        if line.startswith("model_checkpoint_path:"):
+            p = line.split(":", 1)[1].strip().strip('"')
+            return p if os.path.isabs(p) else os.path.join(directory, p)
+    return None
+
+
+def save(net, path, global_step=0, optimizer=None, fmt="npz"):
     out = {k: v for k, v in net.state_dict().items()}
     out["global_step"] = np.int64(global_step)
     if optimizer is not None:
@@ -26,6 +40,12 @@ def save(net, path, global_step=0, optimizer=None):
             else:
                 out[name + "/Momentum"] = m[off:off + k].reshape(shape)
             off += k
+    if fmt == "tf":
+        from . import tf_bundle
+        tf_bundle.write_bundle(path, {k: np.asarray(v) for k, v in out.items()})
+        with open(os.path.join(os.path.dirname(path) or ".", "checkpoint"), "w") as f:     # CheckpointState, as Saver.save
+            f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (os.path.basename(path), os.path.basename(path)))
+        return path
     if not path.endswith(".npz"):
         path += ".npz"
     np.savez(path, **out)
@@ -36,7 +56,15 @@ def load(net, path, optimizer=None):
     """Restores variables (and optimizer slots when present); returns global_step.  Unknown keys are
     ignored, missing variables raise KeyError -- like a TF restore of a partial checkpoint would."""
     import torch
-    z = np.load(path if path.endswith(".npz") else path + ".npz")
+    from . import tf_bundle
+
+    class _Bundle(dict):
+        files = property(lambda self: list(self.keys()))
+
+    if tf_bundle.is_bundle(path):
+        z = _Bundle(tf_bundle.read_bundle(path))
+    else:
+        z = np.load(path if path.endswith(".npz") else path + ".npz")
     missing = [n for n, _ in net._spec if n not in z.files]
     if missing:
         raise KeyError("checkpoint lacks variables: %s" % ", ".join(missing[:4]))

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) anno_iou(const float4* __restrict__ dets,
   float* row = out + anno_off[img] + (long long)(d - det_off[img]) * m;
   const float4 a = dets[d];
   const float a_area = (a.z - a.x) * (a.w - a.y);
-  const int dc = det_classes[d];
+  const int dc = multiclass ? det_classes[d] : 0;
   for (int g = g0; g < g1; ++g) {
     const float4 b = gts[g];
     const float b_area = (b.z - b.x) * (b.w - b.y);
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) anno_iou(const float4* __restrict__ dets,
     const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
     const float inter = w * h;
     float v;
-    if (gt_crowd[g]) v = inter / a_area;                     // network.py:485-488
+    if (gt_crowd && gt_crowd[g]) v = inter / a_area;         // network.py:485-488
     else v = inter / ((a_area + b_area) - inter);            // network.py:480-481
     if (multiclass && dc != gt_classes[g]) v = 0.0f;         // network.py:182-187
     row[g - g0] = v;
@@ -325,5 +325,17 @@ extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const 
                                            in->det_off, in->gt_off, in->gt_crowd, in->gt_classes, class_weights,
                                            cfg->num_classes, cfg->normalize_loss, cfg->loss_multiplyer, grad_scale,
                                            buf->loss, buf->d_logits);
+  return launch_status();
+}
+
+// Plain box IoU [n_a_i, n_b_i] per image (network.py:475-481, no crowd columns, no class mask): Gnet.det_det_iou on demand.
+extern "C" int gnet_box_iou(const float* a_boxes, int32_t n_a, const float* b_boxes, int32_t n_b, const int32_t* a_off,
+                            const int32_t* b_off, const int64_t* out_off, int32_t n_img, float* out, gnet_stream_t stream) {
+  clear_hip_error();
+  if (n_a < 0 || n_b < 0 || n_img < 1) return GNET_ERR_INVALID;
+  if (n_a == 0 || n_b == 0) return GNET_OK;
+  if (!a_boxes || !b_boxes || !a_off || !b_off || !out_off || !out) return GNET_ERR_INVALID;
+  anno_iou<<<(n_a + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float4*)a_boxes, nullptr, a_off, (const float4*)b_boxes, nullptr,
+                                                                nullptr, b_off, (const long long*)out_off, n_a, n_img, 0, out);
   return launch_status();
 }

@@ -11,6 +11,7 @@ device memory and streams.  There is no CPU fallback.
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -141,7 +142,9 @@ class Gnet(object):
     gt_classes = None
     image = None
 
-    _scopes = {}   # variable scope 'gnet' -> shared parameter storage (tf.variable_scope(reuse=True))
+    # variable scope 'gnet' -> shared parameter storage (tf.variable_scope(reuse=True)); weak references: the storage
+    # lives as long as a Gnet that uses it, not for the life of the process
+    _scopes = weakref.WeakValueDictionary()
 
     @staticmethod
     def get_batch_spec(num_classes, is_training=True):
@@ -591,6 +594,24 @@ class Gnet(object):
         c = self._view(self._buf.edge_c, E, torch.int32)
         n = self._view(self._buf.edge_n, E, torch.int32)
         return torch.stack([c, n], 1).long()
+
+    @property
+    def det_det_iou(self):
+        """network.py:176 -- the dense [N, N] IoU matrix of a single-image batch, materialised on demand from the boxes
+        by the same kernel that builds det_anno_iou (no caller of the reference reads it; the hot path keeps only the
+        values at the neighbour pairs, `edge_iou`)."""
+        db = self._dbatch
+        if db.n_img != 1:
+            raise _lib.GnetError("det_det_iou is defined per image: feed one image")
+        n = db.n_det
+        out = torch.empty(n, n, dtype=torch.float32, device=self.device)
+        if n:
+            off = torch.tensor([0, n], dtype=torch.int32, device=self.device)
+            aoff = torch.tensor([0, n * n], dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.gnet_box_iou(_vp(db.dets), n, _vp(db.dets), n, _vp(off), _vp(off), _vp(aoff), 1, _vp(out),
+                                                  self._stream()), "gnet_box_iou")
+        return out
 
     @property
     def edge_iou(self):

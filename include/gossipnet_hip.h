@@ -167,6 +167,11 @@ int gnet_graph_fill(const float* dets, int32_t n_det, const int32_t* det_off, in
 int gnet_graph_transpose(const int32_t* row_ptr, const int32_t* edge_c, const int32_t* edge_n, int64_t n_edge,
                          int32_t* edge_t, gnet_stream_t stream);
 
+/* Dense box IoU per image (network.py:475-481; no crowd columns, no class mask): out + out_off[i] = [n_a_i, n_b_i] row-major.
+ * Gnet.det_det_iou (network.py:176) on demand -- the hot path never materialises N x N. */
+int gnet_box_iou(const float* a_boxes, int32_t n_a, const float* b_boxes, int32_t n_b, const int32_t* a_off,
+                 const int32_t* b_off, const int64_t* out_off, int32_t n_img, float* out, gnet_stream_t stream);
+
 /* ---- workspace -----------------------------------------------------------------
  * training: 0 = inference (two alternating sets of per-block tensors), 1 = training (everything the backward
  * pass re-reads), 2 = training + keep the per-block pw_fc1 activations blk_h1 (tests / debugging only). */

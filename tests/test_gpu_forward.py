@@ -23,6 +23,8 @@ def test_forward_parity(n, c, b, seed):
     assert np.array_equal(pairs, ref["neighbor_pair_idxs"]), "neighbour indices must be bit-exact"
     ious = ref["det_det_iou"][pairs[:, 0], pairs[:, 1]]
     assert np.array_equal(net.edge_iou.cpu().numpy(), ious)
+    if n <= 300:      # the dense matrix (Gnet.det_det_iou, network.py:176) on demand, bit-exact (NaN for degenerate pairs alike)
+        assert np.array_equal(net.det_det_iou.cpu().numpy(), ref["det_det_iou"], equal_nan=True)
     assert rel_err(net.pw_feats.cpu().numpy(), ref["pw_feats"].detach().numpy()) < TOL
     bf = net.block_feats
     for k in range(1, b + 1):

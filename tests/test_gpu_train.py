@@ -101,3 +101,27 @@ if use_dist: dist.destroy_process_group()
         subprocess.run([sys.executable, "-c", script, f, mode], check=True, cwd=root, timeout=600)
         outs.append(np.load(f))
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+def test_checkpoint_round_trip_tf_bundle(tmp_path):
+    """save(fmt="tf") writes a Saver V2 bundle keyed by the TF variable names (+ Adam slots, global_step); load() restores
+    it into a fresh Gnet / Optimizer: same parameters, same next step."""
+    from gossipnet_amd import checkpoint
+    from gossipnet_amd.config import cfg
+    from gossipnet_amd.train import Optimizer, train_step
+    from gossipnet_amd.network import Gnet
+    net, _ = make_pair(80, 2)
+    opt = Optimizer(net)
+    batch = make_image(80, 80, seed=0)
+    for _ in range(2):
+        train_step(net, opt, batch, 1e-3)
+    path = checkpoint.save(net, checkpoint.checkpoint_name(2, str(tmp_path)), global_step=2, optimizer=opt, fmt="tf")
+    assert checkpoint.latest_checkpoint(str(tmp_path)) == path
+    net2 = Gnet(80)
+    opt2 = Optimizer(net2)
+    assert checkpoint.load(net2, path, optimizer=opt2) == 2
+    assert torch.equal(net2.params, net.params) and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    train_step(net, opt, batch, 1e-3)
+    train_step(net2, opt2, batch, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(net2.params, net.params)
