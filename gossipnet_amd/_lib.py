@@ -28,7 +28,8 @@ class gnet_config(C.Structure):
                 ("shortcut_dim", C.c_int32), ("reduced_dim", C.c_int32), ("pairfeat_dim", C.c_int32),
                 ("pwfeat_dim", C.c_int32), ("pwfeat_narrow_dim", C.c_int32),
                 ("num_pwfeat_fc", C.c_int32), ("predict_fc_dim", C.c_int32), ("num_predict_fc", C.c_int32),
-                ("num_block_pw_fc", C.c_int32), ("num_block_fc", C.c_int32), ("pw_feat_multiplyer", C.c_float)]
+                ("num_block_pw_fc", C.c_int32), ("num_block_fc", C.c_int32), ("pw_feat_multiplyer", C.c_float),
+                ("neighbor_feats", C.c_int32)]
 
 
 class gnet_shape(C.Structure):
@@ -47,7 +48,7 @@ _PB = C.c_void_p * (GNET_MAX_BLOCKS + 1)
 class gnet_buffers(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "edge_t", "edge_nz", "geo", "einfo", "pw_h1", "pw_h2",
                                            "pw_feats")] +
-                [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_h1", "blk_parg")] +
+                [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_rnb", "blk_h1", "blk_parg")] +
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
                                            "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
                                            "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +

@@ -154,6 +154,9 @@ struct BlkNodeArgs {
   const float* r; const float* x_prev;        // x_prev = block_feats[b-1] (NULL = zeros); also x_out of the post stage
   const float* w1; const float* wr;           // natural [96,64] (rows 32-63 centre, 64-95 neighbour), [128,32]
   long long o_w1, o_b1, o_wr, o_br;
+  // neighbor_feats (network.py:356-365): the neighbour half of build_context comes from r_n = relu(x . Wrn + brn)
+  const float* r_nb; const float* wrn;        // [N,32] relu(reduce_dim_neighbor), natural [128,32]; NULL without neighbor_feats
+  long long o_wrn, o_brn;
   // post (block b-1)
   const float* q; const unsigned long long* pm;
   const float* w4; const float* w3;           // natural [64,128], [64,64]
@@ -162,8 +165,8 @@ struct BlkNodeArgs {
   float* arena; long long stride;
 };
 
-constexpr int BN_RT_FLOATS = 2 * 32 * LD128 + 2 * 32 * LD64 + 2 * 32 * LD32 + 4 * 32 * 32;   // per row tile: X, DZ, Rc|Rn, Rr|Dr, Part
-constexpr size_t kBlkNodeSmem = (size_t)(2 * BN_RT_FLOATS) * sizeof(float);
+constexpr int BN_RT_FLOATS = 2 * 32 * LD128 + 2 * 32 * LD64 + 3 * 32 * LD32 + 4 * 32 * 32;   // per row tile: X, DZ, Rc|Rn, Rr|Dr, Rrn, Part
+constexpr size_t kBlkNodeSmem = (size_t)(2 * BN_RT_FLOATS) * sizeof(float);     // 159 KB
 
 __device__ __forceinline__ unsigned long long bn_low_mask(int bit) { return bit ? (~0ull >> (64 - bit)) : 0ull; }
 __device__ __forceinline__ int bn_winner_pos(const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix, int e) {
@@ -238,10 +241,13 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
   float* sRn = sRc + 32 * LD64;              // [32][68]  d_rn          | post: p (segment max)
   float* sRr = sRn + 32 * LD64;              // [32][36]  r             | post: dq [32][68] over Rr + Dr
   float* sDr = sRr + 32 * LD32;              // [32][36]  drpre
-  float* sPart = sDr + 32 * LD32;            // [4][32][32] K-split partials | post: [2][32][64]
+  float* sRrn = sDr + 32 * LD32;             // [32][36]  r_n (neighbor_feats)
+  float* sPart = sRrn + 32 * LD32;           // [4][32][32] K-split partials | post: [2][32][64]
+  float* sDrn = sRn;                         // [32][36]  drpre of the neighbour reduce FC, over d_rn once that is consumed
+  const bool nf = a.wrn != nullptr;
   float* sQ = sRc; float* sP = sRn; float* sDq = sRr; float* sR = sPart;
-  f32x16 aWcn = zero16(), aWr = zero16(), aW4a = zero16(), aW4b = zero16(), aW3 = zero16();
-  float gb1 = 0.f, gbr = 0.f, gb4 = 0.f, gb3 = 0.f;
+  f32x16 aWcn = zero16(), aWr = zero16(), aWrn = zero16(), aW4a = zero16(), aW4b = zero16(), aW3 = zero16();
+  float gb1 = 0.f, gbr = 0.f, gbrn = 0.f, gb4 = 0.f, gb3 = 0.f;
   const int ntiles = (a.n_det + 63) / 64;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int row0 = t * 64 + 32 * rt;                    // first detection of this row tile
@@ -252,6 +258,7 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
     if (a.do_post || a.do_pre) load_tile<D_S, LD128>(sDZ, a.d_x, row0, a.n_det, lt, 256);
     if (a.do_pre) {
       load_tile<D_R, LD32>(sRr, a.r, row0, a.n_det, lt, 256);
+      if (nf) load_tile<D_R, LD32>(sRrn, a.r_nb, row0, a.n_det, lt, 256);
       if (a.d_rc) { load_tile<D_P, LD64>(sRc, a.d_rc, row0, a.n_det, lt, 256); load_tile<D_P, LD64>(sRn, a.d_rn, row0, a.n_det, lt, 256); }
       else { for (int i = lt; i < 2 * 32 * LD64; i += 256) sRc[i] = 0.f; }      // no edges
     }
@@ -265,24 +272,33 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sPart[(cw * 32 + crow(r, half)) * 32 + col] = acc[r];
       }
-      // d Wc += r^T . drc ; d Wn += r^T . drn : role = (term, column tile)
+      // d Wc += r^T . drc ; d Wn += r_n^T . drn (r_n = r without neighbor_feats) : role = (term, column tile)
       {
         const int term = cw >> 1, nj = cw & 1;
         const float* Y = term ? sRn : sRc;
+        const float* X = (term && nf) ? sRrn : sRr;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
           const int row = 2 * kk + half;
-          aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(sRr[row * LD32 + col], Y[row * LD64 + 32 * nj + col], aWcn, 0, 0, 0);
+          aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(X[row * LD32 + col], Y[row * LD64 + 32 * nj + col], aWcn, 0, 0, 0);
         }
       }
       if (lt < D_P) gb1 += col_sum32(sRc, LD64, lt);
       __syncthreads();
       for (int i = lt; i < 32 * D_R; i += 256) {
         const int row = i >> 5, ff = i & 31;
-        float v = sPart[(0 * 32 + row) * 32 + ff] + sPart[(1 * 32 + row) * 32 + ff];
-        v += sPart[(2 * 32 + row) * 32 + ff];
-        v += sPart[(3 * 32 + row) * 32 + ff];
-        sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? v : 0.f;    // ReLU of reduce_dim
+        // partials: roles 0 / 2 = drc . Wc^T (K halves), roles 1 / 3 = drn . Wn^T
+        if (nf) {
+          const float vc = sPart[(0 * 32 + row) * 32 + ff] + sPart[(2 * 32 + row) * 32 + ff];
+          const float vn = sPart[(1 * 32 + row) * 32 + ff] + sPart[(3 * 32 + row) * 32 + ff];
+          sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? vc : 0.f;      // ReLU of reduce_dim
+          sDrn[row * LD32 + ff] = sRrn[row * LD32 + ff] > 0.f ? vn : 0.f;    // ReLU of reduce_dim_neighbor
+        } else {
+          float v = sPart[(0 * 32 + row) * 32 + ff] + sPart[(1 * 32 + row) * 32 + ff];
+          v += sPart[(2 * 32 + row) * 32 + ff];
+          v += sPart[(3 * 32 + row) * 32 + ff];
+          sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? v : 0.f;    // ReLU of reduce_dim
+        }
       }
       __syncthreads();
       // d Wr += x_prev^T . drpre : role cw owns rows [32 cw, 32 cw + 32) of Wr
@@ -292,10 +308,19 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
         aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDr[row * LD32 + col], aWr, 0, 0, 0);
       }
       if (lt < D_R) gbr += col_sum32(sDr, LD32, lt);
+      if (nf) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int row = 2 * kk + half;
+          aWrn = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDrn[row * LD32 + col], aWrn, 0, 0, 0);
+        }
+        if (lt < D_R) gbrn += col_sum32(sDrn, LD32, lt);
+      }
       if (a.do_post || a.want_dx0) {
-        // d_x += drpre . Wr^T (columns [32 cw, 32 cw + 32))
+        // d_x += drpre . Wr^T [+ drpre_n . Wrn^T] (columns [32 cw, 32 cw + 32))
         f32x16 acc = zero16();
         mma_abt<D_R>(acc, sDr, LD32, a.wr + (size_t)(32 * cw) * D_R, D_R, lane);
+        if (nf) mma_abt<D_R>(acc, sDrn, LD32, a.wrn + (size_t)(32 * cw) * D_R, D_R, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
@@ -382,29 +407,33 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
   }
   // ---- partial weight gradients of this workgroup: row tile 1 is added to row tile 0 (fixed order), then stored
   __syncthreads();
-  float* red = smem;                           // [80][256] accumulator registers of row tile 1 + [4][256] bias sums
+  float* red = smem;                           // [96][256] accumulator registers of row tile 1 + [5][256] bias sums
   if (rt == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       red[(r) * 256 + lt] = aWcn[r]; red[(16 + r) * 256 + lt] = aWr[r]; red[(32 + r) * 256 + lt] = aW4a[r];
-      red[(48 + r) * 256 + lt] = aW4b[r]; red[(64 + r) * 256 + lt] = aW3[r];
+      red[(48 + r) * 256 + lt] = aW4b[r]; red[(64 + r) * 256 + lt] = aW3[r]; red[(80 + r) * 256 + lt] = aWrn[r];
     }
-    red[80 * 256 + lt] = gb1; red[81 * 256 + lt] = gbr; red[82 * 256 + lt] = gb4; red[83 * 256 + lt] = gb3;
+    red[96 * 256 + lt] = gb1; red[97 * 256 + lt] = gbr; red[98 * 256 + lt] = gb4; red[99 * 256 + lt] = gb3; red[100 * 256 + lt] = gbrn;
   }
   __syncthreads();
   if (rt == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       aWcn[r] += red[(r) * 256 + lt]; aWr[r] += red[(16 + r) * 256 + lt]; aW4a[r] += red[(32 + r) * 256 + lt];
-      aW4b[r] += red[(48 + r) * 256 + lt]; aW3[r] += red[(64 + r) * 256 + lt];
+      aW4b[r] += red[(48 + r) * 256 + lt]; aW3[r] += red[(64 + r) * 256 + lt]; aWrn[r] += red[(80 + r) * 256 + lt];
     }
-    gb1 += red[80 * 256 + lt]; gbr += red[81 * 256 + lt]; gb4 += red[82 * 256 + lt]; gb3 += red[83 * 256 + lt];
+    gb1 += red[96 * 256 + lt]; gbr += red[97 * 256 + lt]; gb4 += red[98 * 256 + lt]; gb3 += red[99 * 256 + lt]; gbrn += red[100 * 256 + lt];
     float* ar = a.arena + (size_t)blockIdx.x * a.stride;
     if (a.do_pre) {
       store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aWcn, lane);
       store_acc(ar + a.o_wr + (size_t)(32 * cw) * D_R, D_R, aWr, lane);
       if (lt < D_P) ar[a.o_b1 + lt] = gb1;
       if (lt < D_R) ar[a.o_br + lt] = gbr;
+      if (nf) {
+        store_acc(ar + a.o_wrn + (size_t)(32 * cw) * D_R, D_R, aWrn, lane);
+        if (lt < D_R) ar[a.o_brn + lt] = gbrn;
+      }
     }
     if (a.do_post) {
       store_acc(ar + a.o_w4 + 32 * cw, D_S, aW4a, lane);
@@ -827,7 +856,10 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       const BlockLayout& K = L.blk[b];
       n.r = buf->blk_r[b]; n.w1 = params + K.w1; n.wr = params + K.wr;
       n.o_w1 = K.w1; n.o_b1 = K.b1; n.o_wr = K.wr; n.o_br = K.br;
-    } else { n.r = nullptr; n.w1 = n.wr = nullptr; n.o_w1 = n.o_b1 = n.o_wr = n.o_br = 0; }
+      n.r_nb = cfg->neighbor_feats ? buf->blk_rnb[b] : nullptr;
+      n.wrn = cfg->neighbor_feats ? params + K.wrn : nullptr;
+      n.o_wrn = K.wrn; n.o_brn = K.brn;
+    } else { n.r = nullptr; n.w1 = n.wr = nullptr; n.o_w1 = n.o_b1 = n.o_wr = n.o_br = 0; n.r_nb = nullptr; n.wrn = nullptr; n.o_wrn = n.o_brn = 0; }
     if (b >= 2) {
       const BlockLayout& K = L.blk[b - 1];
       n.q = buf->blk_q[b - 1]; n.pm = (const unsigned long long*)buf->blk_pm[b - 1];

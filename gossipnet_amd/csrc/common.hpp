@@ -56,6 +56,7 @@ struct BlockLayout {
   int64_t w2, b2;    // pw_fc2 [64,64]
   int64_t w3, b3;    // fc1 [64,64]
   int64_t w4, b4;    // fc2 [64,128]
+  int64_t wrn, brn;  // reduce_dim_neighbor [128,32], [32] (neighbor_feats only; -1 otherwise)
 };
 struct ParamLayout {
   int dpw;           // 2*C' + 7
@@ -98,6 +99,7 @@ static inline ParamLayout make_layout(const gnet_config* c) {
     B.b3 = o; o += D_P;
     B.w4 = o; o += D_P * D_S;
     B.b4 = o; o += D_S;
+    if (c->neighbor_feats) { B.wrn = o; o += D_S * D_R; B.brn = o; o += D_R; } else { B.wrn = B.brn = -1; }
   }
   L.hw1 = o; o += D_S * D_HEAD;
   L.hb1 = o; o += D_HEAD;

@@ -16,17 +16,20 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // pack_transpose: matrix id -> (offset, in, out) computed from the flat layout.
-__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, long long* off, int* in, int* out) {
+__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, long long* off, int* in, int* out) {
   const long long pw_sz = (long long)dpw * D_H + D_H + D_H * D_H + D_H + D_H * D_E + D_E;
-  const long long blk_sz = D_S * D_R + D_R + (D_E + 2 * D_R) * D_P + D_P + D_P * D_P + D_P + D_P * D_P + D_P +
-                           D_P * D_S + D_S;
+  const long long blk_core = D_S * D_R + D_R + (D_E + 2 * D_R) * D_P + D_P + D_P * D_P + D_P + D_P * D_P + D_P +
+                             D_P * D_S + D_S;
+  const long long blk_sz = blk_core + (nf ? D_S * D_R + D_R : 0);      // reduce_dim_neighbor follows fc2
   if (id == 0) { *off = 0; *in = dpw; *out = D_H; return; }
   if (id == 1) { *off = (long long)dpw * D_H + D_H; *in = D_H; *out = D_H; return; }
   if (id == 2) { *off = (long long)dpw * D_H + D_H + D_H * D_H + D_H; *in = D_H; *out = D_E; return; }
   id -= 3;
-  if (id < 5 * nblocks) {
-    const int b = id / 5, m = id % 5;
+  const int mpb = 5 + (nf ? 1 : 0);
+  if (id < mpb * nblocks) {
+    const int b = id / mpb, m = id % mpb;
     long long o = pw_sz + (long long)b * blk_sz;
+    if (m == 5) { *off = o + blk_core; *in = D_S; *out = D_R; return; }
     if (m == 0) { *off = o; *in = D_S; *out = D_R; return; }
     o += D_S * D_R + D_R;
     if (m == 1) { *off = o; *in = D_E + 2 * D_R; *out = D_P; return; }
@@ -37,7 +40,7 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, long long
     o += D_P * D_P + D_P;
     *off = o; *in = D_P; *out = D_S; return;
   }
-  id -= 5 * nblocks;
+  id -= mpb * nblocks;
   long long o = pw_sz + (long long)nblocks * blk_sz;
   if (id == 0) { *off = o; *in = D_S; *out = D_HEAD; return; }
   o += D_S * D_HEAD + D_HEAD;
@@ -45,9 +48,9 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, long long
 }
 
 __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ params, float* __restrict__ packed,
-                                                      int dpw, int nblocks) {
+                                                      int dpw, int nblocks, int nf) {
   long long off; int in, out;
-  mat_info(blockIdx.y, dpw, nblocks, &off, &in, &out);
+  mat_info(blockIdx.y, dpw, nblocks, nf, &off, &in, &out);
   const int total = in * out;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int o = i / in, k = i - o * in;   // packed[o][k] = W[k][o]
@@ -603,7 +606,8 @@ struct NodeFwdArgs {
   float* q; float* x_out;
   const float* wrt; const float* br;   // next block reduce_dim transposed [32][128]
   const float* w1t; const float* b1;   // next block pw_fc1 transposed [64][96]
-  float* r; float* rc; float* rn;
+  const float* wrnt; const float* brn; // next block reduce_dim_neighbor transposed [32][128] (neighbor_feats; else NULL)
+  float* r; float* rc; float* rn; float* r_nb;
   // segment-max records of the NEXT block: rows of detections whose edges are split between two waves of
   // edge_fwd_w (combined atomically there) or that have no edge at all start from zero; every other row is
   // written by a plain store.  edge_span = edges per wave range of edge_fwd_w.
@@ -702,11 +706,34 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       if (a.training && row0 + row < a.n_det) a.r[(size_t)(row0 + row) * D_R + ff] = v;
     }
     __syncthreads();
-    // rc = r . W1[32:64] + b1 (waves 0,1) ; rn = r . W1[64:96] (waves 2,3)
+    const float* sYn = sY;                       // reduced features of the NEIGHBOUR side (network.py:356-365)
+    if (a.wrnt) {
+      // neighbor_feats: r_n = relu(x . Wrn + brn), the same K-split product through the same partial buffer
+      {
+        f32x16 acc = zero16();
+        mma_abt<32>(acc, sX + 32 * wave, N_LD, a.wrnt + 32 * wave, D_S, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sR[(wave * 32 + crow(r, half)) * 32 + col] = acc[r];
+      }
+      __syncthreads();
+      float* sY2 = sY + 32 * E_LD1;
+      for (int i = tid; i < 32 * D_R; i += 256) {
+        const int row = i >> 5, ff = i & 31;
+        float v = sR[(0 * 32 + row) * 32 + ff] + sR[(1 * 32 + row) * 32 + ff];
+        v += sR[(2 * 32 + row) * 32 + ff];
+        v += sR[(3 * 32 + row) * 32 + ff];
+        v = fmaxf(v + a.brn[ff], 0.f);
+        sY2[row * E_LD1 + ff] = v;
+        if (a.training && row0 + row < a.n_det) a.r_nb[(size_t)(row0 + row) * D_R + ff] = v;
+      }
+      __syncthreads();
+      sYn = sY2;
+    }
+    // rc = r . W1[32:64] + b1 (waves 0,1) ; rn = r_n . W1[64:96] (waves 2,3; r_n = r without neighbor_feats)
     {
       const int part = wave >> 1, nt = wave & 1;
       f32x16 acc = zero16();
-      mma_abt<D_R>(acc, sY, E_LD1, a.w1t + (size_t)(32 * nt) * (D_E + 2 * D_R) + D_E + part * D_R, D_E + 2 * D_R, lane);
+      mma_abt<D_R>(acc, part ? sYn : sY, E_LD1, a.w1t + (size_t)(32 * nt) * (D_E + 2 * D_R) + D_E + part * D_R, D_E + 2 * D_R, lane);
       const float bb = part == 0 ? a.b1[32 * nt + col] : 0.f;
       float* dst = part == 0 ? a.rc : a.rn;
 #pragma unroll
@@ -776,7 +803,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   float* pt = buf->packed_t;
 
   void* prof = buf->profiler;
-  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + 5 * B + 2), 256, 0, s>>>(params, pt, L.dpw, B));
+  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats));
 
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
@@ -825,7 +852,10 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
       n.wrt = pt + L.blk[b + 1].wr; n.br = params + L.blk[b + 1].br;
       n.w1t = pt + L.blk[b + 1].w1; n.b1 = params + L.blk[b + 1].b1;
       n.r = buf->blk_r[b + 1]; n.rc = buf->blk_rc[b + 1]; n.rn = buf->blk_rn[b + 1];
-    } else { n.wrt = n.br = n.w1t = n.b1 = nullptr; n.r = n.rc = n.rn = nullptr; }
+      n.wrnt = cfg->neighbor_feats ? pt + L.blk[b + 1].wrn : nullptr;
+      n.brn = cfg->neighbor_feats ? params + L.blk[b + 1].brn : nullptr;
+      n.r_nb = buf->blk_rnb[b + 1];
+    } else { n.wrt = n.br = n.w1t = n.b1 = nullptr; n.r = n.rc = n.rn = nullptr; n.wrnt = n.brn = nullptr; n.r_nb = nullptr; }
     n.pm_next = b < B ? (unsigned long long*)buf->blk_pm[b + 1] : nullptr;
     n.parg_next = (b < B && training) ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
     n.row_ptr = buf->row_ptr; n.edge_span = ef_span;

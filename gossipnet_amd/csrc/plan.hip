@@ -56,6 +56,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.blk_pm[k] = c.take<uint64_t>(2 * Np * D_P);      // pm, then parg (one memset clears both)
       b.blk_parg[k] = b.blk_pm[k] + Np * D_P;
       b.blk_q[k] = c.take<float>(Np * D_P);
+      if (cfg->neighbor_feats) b.blk_rnb[k] = c.take<float>(Np * D_R);
       if (training == 2) b.blk_h1[k] = c.take<float>(Ep * D_P);     // tests / debugging only
     }
     b.head1 = c.take<float>(Np * D_HEAD);

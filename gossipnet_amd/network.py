@@ -59,6 +59,9 @@ def param_spec(num_classes, num_blocks):
             (p + "fc1/weights", (g.pairfeat_dim, g.pairfeat_dim)), (p + "fc1/biases", (g.pairfeat_dim,)),
             (p + "fc2/weights", (g.pairfeat_dim, g.shortcut_dim)), (p + "fc2/biases", (g.shortcut_dim,)),
         ]
+        if g.neighbor_feats:       # network.py:356-365 (flat-buffer position: behind fc2 of the block)
+            spec += [(p + "reduce_dim_neighbor/weights", (g.shortcut_dim, g.reduced_dim)),
+                     (p + "reduce_dim_neighbor/biases", (g.reduced_dim,))]
     for i in (1, 2):
         p = "gnet/predict/fc%d/fully_connected/" % i
         spec += [(p + "weights", (g.predict_fc_dim, g.predict_fc_dim)), (p + "biases", (g.predict_fc_dim,))]
@@ -175,8 +178,6 @@ class Gnet(object):
         self._imfeats = bool(cfg.gnet.imfeats)
         self.imfeat_channels, self.imfeat_stride = int(imfeat_channels), int(imfeat_stride)
         self.imfeats_need_grad = False      # also compute d loss / d imfeats (through roi_pool_grad) in run()
-        if cfg.gnet.neighbor_feats:
-            raise _lib.GnetError("cfg.gnet.neighbor_feats=True is not compiled")
         if cfg.gnet.weight_init not in ('xavier', 'caffe', 'msra'):
             raise ValueError('unknown weight init {}'.format(cfg.gnet.weight_init))        # network.py:203-214
         self._lib = _lib.load()
@@ -186,7 +187,7 @@ class Gnet(object):
             num_classes, g.num_blocks, g.neighbor_thresh, int(bool(cfg.train.normalize_loss)),
             float(cfg.train.loss_multiplyer), g.shortcut_dim, g.reduced_dim, g.pairfeat_dim, g.pwfeat_dim,
             g.pwfeat_narrow_dim, g.num_pwfeat_fc, g.predict_fc_dim, g.num_predict_fc, g.num_block_pw_fc,
-            g.num_block_fc, float(g.pw_feat_multiplyer))
+            g.num_block_fc, float(g.pw_feat_multiplyer), int(bool(g.neighbor_feats)))
         n = self._lib.gnet_param_count(C.byref(self._cfg))
         if n < 0:
             _lib.check(int(n), "gnet_param_count")
@@ -199,7 +200,7 @@ class Gnet(object):
             n = sum(int(np.prod(s)) for _, s in self._spec)
             from .fc import FcWorkspace
             self._fc_ws = FcWorkspace(self.device)
-        key = (self.name, num_classes, g.num_blocks, str(self.device), self._imfeats, self.imfeat_channels)
+        key = (self.name, num_classes, g.num_blocks, str(self.device), self._imfeats, self.imfeat_channels, bool(g.neighbor_feats))
         if reuse:
             if key not in Gnet._scopes:
                 raise ValueError("Variable scope gnet does not exist, cannot reuse")

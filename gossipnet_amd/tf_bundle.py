@@ -49,10 +49,6 @@ def crc32c(data, crc=0):
     return crc ^ 0xFFFFFFFF
 
 
-def crc32c_np(buf):
-    """CRC-32C of a large buffer (table-driven over 64 KiB strides of numpy look-ups would still be slow in pure
-    Python; tensors are only checked when small -- see read_bundle(verify=...))."""
-    return crc32c(buf)
 
 
 def mask_crc(c):

@@ -52,6 +52,8 @@ typedef struct gnet_config {
   int32_t shortcut_dim, reduced_dim, pairfeat_dim, pwfeat_dim, pwfeat_narrow_dim;
   int32_t num_pwfeat_fc, predict_fc_dim, num_predict_fc, num_block_pw_fc, num_block_fc;
   float pw_feat_multiplyer; /* cfg.gnet.pw_feat_multiplyer: factor on every _geometry_feats column (network.py:199-200) */
+  int32_t neighbor_feats;   /* cfg.gnet.neighbor_feats: a second reduce FC `reduce_dim_neighbor` feeds the neighbour half of
+                               build_context (network.py:356-365); its variables follow fc2 in every block's group */
 } gnet_config;
 
 /* Sizes of one batch: n_img images concatenated (the reference runs n_img = 1,
@@ -100,6 +102,7 @@ typedef struct gnet_buffers {
   float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[64:96]             */
   uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count */
   float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
+  float* blk_rnb[GNET_MAX_BLOCKS + 1];     /* [n_det,32]  relu(reduce_dim_neighbor) (neighbor_feats, training)   */
   float* blk_h1[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] relu(pw_fc1) per edge -- only when planned with training == 2 (tests / debugging: the backward pass recomputes the rows it needs) */
   uint64_t* blk_parg[GNET_MAX_BLOCKS + 1]; /* [n_det,64] (segment-max bits << 32) | index of the first edge that attains it (training) */
   float* head1;       /* [n_det,128] predict/fc1 */
@@ -146,7 +149,7 @@ typedef struct gnet_buffers {
 /* ---- parameters ------------------------------------------------------------
  * One flat fp32 buffer in TF-variable order, weights [in,out]:
  *   gnet/pw_feats/fc{1,2,3}/{weights,biases}
- *   gnet/block{k}/{reduce_dim,pw_fc1,pw_fc2,fc1,fc2}/{weights,biases}   k = 1..B
+ *   gnet/block{k}/{reduce_dim,pw_fc1,pw_fc2,fc1,fc2[,reduce_dim_neighbor]}/{weights,biases}   k = 1..B
  *   gnet/predict/fc{1,2}/fully_connected/{weights,biases}
  *   gnet/predict/logits/fully_connected/{weights,biases}
  * gnet_param_count returns <0 on an unsupported config. */

@@ -51,12 +51,12 @@ def imfeat_param_spec(imfeat):
     return spec
 
 
-def param_spec(num_classes, num_blocks, imfeat=None):
+def param_spec(num_classes, num_blocks, imfeat=None, neighbor_feats=False):
     """Ordered (TF variable name, shape) list; FC weights are [in, out]
     (tf.contrib.layers.fully_connected).  Scopes: network.py:167,218,260,267,
     334,341,347,354,385,397,405; SURVEY.md §8f.  imfeat: the reduce_imfeats variables follow."""
     if imfeat is not None:
-        return param_spec(num_classes, num_blocks) + imfeat_param_spec(imfeat)
+        return param_spec(num_classes, num_blocks, None, neighbor_feats) + imfeat_param_spec(imfeat)
     spec = []
     d = pw_feat_dim(num_classes)
     dims = [d, PWFEAT_DIM, PWFEAT_DIM, PWFEAT_NARROW_DIM]
@@ -72,6 +72,8 @@ def param_spec(num_classes, num_blocks, imfeat=None):
             (p + "fc1/weights", (PAIRFEAT_DIM, PAIRFEAT_DIM)), (p + "fc1/biases", (PAIRFEAT_DIM,)),
             (p + "fc2/weights", (PAIRFEAT_DIM, SHORTCUT_DIM)), (p + "fc2/biases", (SHORTCUT_DIM,)),
         ]
+        if neighbor_feats:   # network.py:356-365
+            spec += [(p + "reduce_dim_neighbor/weights", (SHORTCUT_DIM, REDUCED_DIM)), (p + "reduce_dim_neighbor/biases", (REDUCED_DIM,))]
     for i in (1, 2):
         p = "gnet/predict/fc%d/fully_connected/" % i
         spec += [(p + "weights", (PREDICT_FC_DIM, PREDICT_FC_DIM)), (p + "biases", (PREDICT_FC_DIM,))]
@@ -80,13 +82,13 @@ def param_spec(num_classes, num_blocks, imfeat=None):
     return spec
 
 
-def init_params(num_classes, num_blocks, seed=42, bias_init=0.01, imfeat=None):
+def init_params(num_classes, num_blocks, seed=42, bias_init=0.01, imfeat=None, neighbor_feats=False):
     """xavier-uniform weights (network.py:203-205, limit sqrt(6/(fan_in+fan_out))),
     constant biases (network.py:215).  TF's RNG stream cannot be reproduced; the
     seed only fixes OUR stream."""
     g = torch.Generator().manual_seed(seed)
     out = {}
-    for name, shape in param_spec(num_classes, num_blocks, imfeat):
+    for name, shape in param_spec(num_classes, num_blocks, imfeat, neighbor_feats):
         if name.endswith("weights"):
             lim = math.sqrt(6.0 / (shape[0] + shape[1]))
             out[name] = ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).numpy()
@@ -322,7 +324,8 @@ class GnetOracle:
 
     def __init__(self, num_classes, num_blocks=16, params=None, class_weights=None,
                  dtype=torch.float32, thresh=NEIGHBOR_THRESH, normalize_loss=False,
-                 loss_multiplyer=1.0, bias_init=0.01, matching_fn=None, pw_feat_multiplyer=1.0, imfeat=None):
+                 loss_multiplyer=1.0, bias_init=0.01, matching_fn=None, pw_feat_multiplyer=1.0, imfeat=None,
+                 neighbor_feats=False):
         self.num_classes = num_classes
         self.num_blocks = num_blocks
         self.dtype = dtype
@@ -332,8 +335,9 @@ class GnetOracle:
         self.loss_multiplyer = loss_multiplyer
         self.pw_feat_multiplyer = pw_feat_multiplyer    # config.py:77, network.py:199-200
         self.imfeat = imfeat                            # image-feature variant (network.py:223-240), see imfeat_param_spec
+        self.neighbor_feats = neighbor_feats            # config.py:72, network.py:356-365
         if params is None:
-            params = init_params(num_classes, num_blocks, bias_init=bias_init, imfeat=imfeat)
+            params = init_params(num_classes, num_blocks, bias_init=bias_init, imfeat=imfeat, neighbor_feats=neighbor_feats)
         self.params = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True)
                        for k, v in params.items()}
         if class_weights is None:
@@ -370,7 +374,7 @@ class GnetOracle:
         f = torch.from_numpy(raw).to(self.dtype)          # stop_gradient (:454)
         # _pw_feats_fc network.py:324-342
         pin = (lambda key, i: None) if pins is None else (lambda key, i: torch.as_tensor(np.asarray(pins[key][i])))
-        own = {"pw": [], "r": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}   # this forward's own smooth piece (keep=True)
+        own = {"pw": [], "r": [], "rn": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}   # this forward's own smooth piece (keep=True)
         note = (lambda key, t: own[key].append((t.detach() > 0).numpy())) if keep else (lambda key, t: None)
         note_im = lambda t: note("im", t)
         for i in range(1, NUM_PWFEAT_FC + 1):
@@ -406,7 +410,12 @@ class GnetOracle:
             r = _fc(x, P, s + "reduce_dim", True, stats if b > 1 else None, pin("r", b - 1))
             note("r", r)
             cf = r[c_idx]
-            nf = torch.where(is_id, torch.zeros((), dtype=self.dtype), r[n_idx])
+            if self.neighbor_feats:                      # network.py:356-365: a second reduce FC for the neighbour side
+                rnb = _fc(x, P, s + "reduce_dim_neighbor", True, stats if b > 1 else None, pin("rn", b - 1))
+                note("rn", rnb)
+            else:
+                rnb = r
+            nf = torch.where(is_id, torch.zeros((), dtype=self.dtype), rnb[n_idx])
             h = torch.cat([pw, cf, nf], 1)
             h = _fc(h, P, s + "pw_fc1", True, stats, pin("h1", b - 1))
             note("h1", h)
@@ -469,7 +478,7 @@ class GnetOracle:
         return out, grads
 
 
-def flatten(params_or_grads, num_classes, num_blocks, imfeat=None):
+def flatten(params_or_grads, num_classes, num_blocks, imfeat=None, neighbor_feats=False):
     """Flat fp32 vector in param_spec order (the layout of include/gossipnet_hip.h)."""
     return np.concatenate([np.asarray(params_or_grads[n], dtype=np.float32).reshape(-1)
-                           for n, _ in param_spec(num_classes, num_blocks, imfeat)])
+                           for n, _ in param_spec(num_classes, num_blocks, imfeat, neighbor_feats)])

@@ -6,11 +6,11 @@ import torch
 from . import gnet_oracle as go
 
 
-def grad_errors(net, gref, c, b, imfeat=None):
+def grad_errors(net, gref, c, b, imfeat=None, neighbor_feats=False):
     """Per-tensor max |g_hip - g_ref| / max |g_ref| (TF variable name -> error)."""
     g = net.grads.cpu().numpy()
     off, errs = 0, {}
-    for name, shape in go.param_spec(c, b, imfeat):
+    for name, shape in go.param_spec(c, b, imfeat, neighbor_feats):
         k = int(np.prod(shape))
         gr = np.asarray(gref[name], np.float64).reshape(-1)
         m = np.abs(gr).max() if k else 0.0
@@ -36,7 +36,7 @@ def gpu_pins(net, image=None):
     cpu = lambda t: t.cpu().numpy()
     pins = {"pw": [cpu(dv("pw_h1", E * 256).view(E, 256)[e0:e1] > 0), cpu(dv("pw_h2", E * 256).view(E, 256)[e0:e1] > 0),
                    cpu(net.pw_feats[e0:e1] > 0)],
-            "r": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}
+            "r": [], "rn": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}
     if getattr(net, "_imfeats", False):
         pins["im"] = [cpu(a_[d0:d1] > 0) for a_ in net._imfeat_acts]
     # winner sets: the recorded arg-max edge of every (detection, column) with a positive maximum, plus -- for
@@ -61,6 +61,8 @@ def gpu_pins(net, image=None):
     bf = net.block_feats
     for b in range(1, B + 1):
         pins["r"].append(cpu(dv("blk_r", N * 32, index=b).view(N, 32)[d0:d1] > 0))
+        if net._buf.blk_rnb[b]:
+            pins["rn"].append(cpu(dv("blk_rnb", N * 32, index=b).view(N, 32)[d0:d1] > 0))
         pins["h1"].append(cpu(dv("blk_h1", E * 64, index=b).view(E, 64)[e0:e1] > 0))
         pins["sel"].append(cpu(winner_sets(b)[e0:e1]))
         pins["q"].append(cpu(dv("blk_q", N * 64, index=b).view(N, 64)[d0:d1] > 0))

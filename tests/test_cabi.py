@@ -30,17 +30,17 @@ def test_library_exports_every_declared_symbol():
 
 def test_param_count_and_unsupported_config():
     lib = _lib.load()
-    ok = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0)
+    ok = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0, 0)
     assert lib.gnet_param_count(C.byref(ok)) == 581793          # multiclass, B = 16
-    one = _lib.gnet_config(1, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0)
+    one = _lib.gnet_config(1, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0, 0)
     assert lib.gnet_param_count(C.byref(one)) == 541345
-    bad = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 64, 0, 128, 3, 2, 2, 1.0)   # reference default
+    bad = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 64, 0, 128, 3, 2, 2, 1.0, 0)   # reference default
     assert lib.gnet_param_count(C.byref(bad)) == _lib.ERR_UNSUPPORTED
 
 
 def test_workspace_query_and_plan_argument_checks():
     lib = _lib.load()
-    cfg = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0)
+    cfg = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0, 0)
     sh = _lib.gnet_shape(1, 2000, 80, 158724, 160000)
     train = lib.gnet_workspace_bytes(C.byref(cfg), C.byref(sh), 1)
     infer = lib.gnet_workspace_bytes(C.byref(cfg), C.byref(sh), 0)

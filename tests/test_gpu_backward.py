@@ -342,3 +342,36 @@ def test_imfeats_start_features(imfeat_dim):
     assert any(k.startswith("gnet/reduce_imfeats/") for k in errs)
     assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
     reset_cfg()
+
+
+def test_neighbor_feats():
+    """cfg.gnet.neighbor_feats=True (network.py:356-365): the neighbour half of build_context comes from a second reduce
+    FC `reduce_dim_neighbor`; forward <= 1e-5, gradients of every tensor <= 1e-5 on the pinned piece."""
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet
+    c, b = 80, 3
+    reset_cfg()
+    cfg.gnet.num_blocks = b
+    cfg.gnet.neighbor_feats = True
+    params = go.init_params(c, b, neighbor_feats=True)
+    net = Gnet(c)
+    net.keep_edge_activations = True
+    net.load_params(params)
+    orc = go.GnetOracle(c, b, params=params, neighbor_feats=True)
+    for seed in (0, 1):
+        batch = make_image(150, c, seed=seed)
+        ref = orc.forward(batch)
+        net.run(batch)
+        torch.cuda.synchronize()
+        check_outputs(net, ref)
+        for k in range(1, b + 1):
+            assert rel_err(net.block_feats[k].cpu().numpy(), ref["block_feats"][k].detach().numpy()) < 1e-5
+        _, gpin = orc.forward_backward(batch, pins=gpu_pins(net))
+        errs = grad_errors(net, gpin, c, b, neighbor_feats=True)
+        assert any("reduce_dim_neighbor" in k for k in errs)
+        assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
+    # inference mode agrees with training mode
+    p1 = net.prediction.cpu().numpy().copy()
+    net.run({k: batch[k] for k in ("dets", "det_scores", "det_classes")})
+    assert np.array_equal(net.prediction.cpu().numpy(), p1)
+    reset_cfg()
