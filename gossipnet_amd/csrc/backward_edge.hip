@@ -43,10 +43,12 @@ __device__ __forceinline__ int winner_pos(const unsigned long long* __restrict__
 // ------------------------------------------------------------------------------------------
 struct WinArgs {
   int n_det;
-  long long bm_stride, xm_stride, tf_stride;
+  long long bm_stride, xm_stride, tf_stride, tl_stride;
   unsigned long long* ewin;         // [B][bm_stride] zeroed
   unsigned long long* xmask;        // [B][xm_stride] extra winners of tied columns (valid on rows of flagged detections only)
   unsigned char* tflag;             // [B][tf_stride] detection has a tied column in this block
+  int* tlist;                       // [B][tl_stride] indices of the flagged detections
+  int* tcount;                      // [B] their number (zeroed)
   const int* row_ptr; const int* edge_nz; const float* pw;
   const unsigned long long* pm[GNET_MAX_BLOCKS];     // [N,64] (max bits << 32) | tie count
   const unsigned long long* parg[GNET_MAX_BLOCKS];   // [N,64] (max bits << 32) | first edge attaining it
@@ -87,7 +89,12 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
       if (m) { atomicOr(ewin + w0 + lane, m); sbm[wave][lane] = 0ull; }
     }
     wave_lds_sync();
-    if (lane == 0) tflag[node] = ties ? 1 : 0;
+    if (lane == 0) {
+      tflag[node] = ties ? 1 : 0;
+      if (ties) {                      // (order of the list is irrelevant: winners_ties only sets bits)
+        a.tlist[(size_t)blk * a.tl_stride + atomicAdd(a.tcount + blk, 1)] = node;
+      }
+    }
   }
 }
 
@@ -105,11 +112,11 @@ __global__ void __launch_bounds__(256) winners_ties(const WinArgs a) {
   const int blk = blockIdx.y;
   unsigned long long* ewin = a.ewin + (size_t)blk * a.bm_stride;
   unsigned long long* xmask = a.xmask + (size_t)blk * a.xm_stride;
-  const unsigned char* tflag = a.tflag + (size_t)blk * a.tf_stride;
   float* sh = sh_all[wave];
-  for (int node0 = blockIdx.x * 4 + wave; node0 < a.n_det; node0 += nwaves) {
-    const int node = __builtin_amdgcn_readfirstlane(node0);
-    if (!tflag[node]) continue;
+  const int* tl = a.tlist + (size_t)blk * a.tl_stride;
+  const int n_tied = a.tcount[blk];
+  for (int li = blockIdx.x * 4 + wave; li < n_tied; li += nwaves) {
+    const int node = __builtin_amdgcn_readfirstlane(tl[li]);
     const unsigned long long pv = a.parg[blk][(size_t)node * D_P + lane];
     const unsigned long long pc = a.pm[blk][(size_t)node * D_P + lane];
     const bool valid = (pv >> 32) != 0ull;
@@ -721,6 +728,11 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   WinArgs w;
   w.n_det = N; w.bm_stride = (long long)G.bm_stride; w.xm_stride = (long long)G.xm_stride; w.tf_stride = (long long)G.tf_stride;
   w.ewin = (unsigned long long*)buf->ewin; w.xmask = (unsigned long long*)buf->xmask; w.tflag = (unsigned char*)buf->tflag;
+  // list of the detections with tied maxima: the arg-max position array apos is written after winners_ties, its
+  // first N ints per block serve as the list until then; the counters live in the slack of the scan scratch
+  w.tlist = buf->apos; w.tl_stride = (long long)G.ap_stride;
+  w.tcount = buf->rl_scratch + (size_t)(B + 1) * (2 * G.n_wg + 1);
+  HIP_CHECK_RET(hipMemsetAsync(w.tcount, 0, (size_t)GNET_MAX_BLOCKS * sizeof(int), s));
   w.row_ptr = buf->row_ptr; w.edge_nz = buf->edge_nz; w.pw = buf->pw_feats;
   for (int b = 1; b <= B; ++b) {
     w.pm[b - 1] = (const unsigned long long*)buf->blk_pm[b]; w.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
@@ -728,7 +740,7 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
     w.w1t[b - 1] = pt + L.blk[b].w1; w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
   }
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
-  GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_ties<<<dim3(min((N + 3) / 4, 256), B), 256, 0, s>>>(w));
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_ties<<<dim3(16, B), 256, 0, s>>>(w));
   ListArgs l;
   l.n_words = (int)G.n_words; l.n_edge = E; l.n_wg = (int)G.n_wg; l.n_lists = B + 1;
   l.bm_stride = (long long)G.bm_stride; l.wl_stride = (long long)G.wl_stride;
