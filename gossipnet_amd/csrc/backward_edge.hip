@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     const int my_e = nx_e, my_c = nx_c;
     const int tapA = apA, tapB = apB, tapC = apC, ttfA = tfA, ttfB = tfB, ttfC = tfC;
     const float tdvA = dvA, tdvB = dvB, tdvC = dvC;
-    // ---- stage: edge ids, bias tile (rc + rn: the forward kernel's operand order) in two batches of 16 rows (registers)
+    // ---- stage: edge ids, bias tile (rc + rn: the forward kernel's operand order)
     const int my_nz = nx_nz;
     if (half == 0) sE[col] = my_e;
     f32x4 pa[4];
@@ -437,21 +437,19 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
 #pragma unroll
       for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
     }
+    {
+      float4 x[8], y[8];                                  // all sixteen row requests in flight: one exposed latency per tile
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      float4 x[4], y[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = 4 * (4 * hb + i) + q4;
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + q4;
         const int cr = max(__shfl(my_c, row), 0), nzr = __shfl(my_nz, row);
         x[i] = ldg4_b(a.rc, (unsigned)cr * (D_P * 4u) + 16u * f4);
         y[i] = ldg4_b(a.rn, (unsigned)nzr * (D_P * 4u) + 16u * f4);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(sH + (4 * (4 * hb + i) + q4) * LD64 + 4 * f4) =
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(sH + (4 * i + q4) * LD64 + 4 * f4) =
             make_float4(x[i].x + y[i].x, x[i].y + y[i].y, x[i].z + y[i].z, x[i].w + y[i].w);
-      __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_sync();
     // ---- h1 = relu(P . Wp + (rc + rn)): the forward kernel's operation sequence (same bits)
