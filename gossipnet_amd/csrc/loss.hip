@@ -6,8 +6,8 @@
 //   match_cand    per detection: best two non-crowd candidates (iou >= 0.5) and first crowd hit
 //   match_rank    score order: rank = #{j : s_j > s_i or (s_j == s_i and j > i)}
 //                 (std::sort ascending + reverse with ties resolved "higher index first")
-//   match_greedy  one wave per image walks the detections in score order; only detections with a
-//                 non-crowd candidate touch the sequential state (a GT bitmask held in registers)
+//   match_greedy  one wave per image walks the detections in score order, 64 at a time, resolving each batch in
+//                 parallel rounds that reproduce the sequential decisions
 //   loss_kernel   class weighting, sigmoid cross-entropy, per-image sums, d loss / d logit
 #include "common.hpp"
 
@@ -110,8 +110,18 @@ __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ scor
   if (q == 0 && d < n_det) order[lo + rank] = d;
 }
 
-// One wave per image.  matched GT flags live in a per-lane bitmask: GT g -> lane g & 63, bit g >> 6
-// (up to 2048 GT per image; larger images take the LDS-free slow path below too, via global flags).
+// One wave per image walks the detections in score order, 64 at a time.  The reference loop (det_matching.cc:118-157)
+// is sequential, but within a batch most decisions do not depend on each other, so the batch is resolved in rounds:
+//   - a detection's wish is its best candidate that is still free (c1, else c2);
+//   - every unresolved detection registers as "interested" in each of its free candidates (LDS atomicMin of the
+//     lane id per GT); a detection whose wish is owned by itself cannot lose it to an earlier one -> it commits;
+//   - a detection with no free candidate among <= 2 falls to its crowd hit (state-independent);
+//   - a detection with more than two candidates may want GTs the two keys do not name: while it is unresolved
+//     and not committing, no later detection commits; when it is the first unresolved one and both keys are
+//     taken, its IoU row is scanned by the whole wave.
+// The first unresolved detection always resolves, so the rounds terminate; every commit is the decision the
+// sequential loop takes at that detection's turn (its wish is free then, and nobody before it asked for it).
+constexpr int kMaxGt = 2048;
 __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou, const long long* __restrict__ anno_off,
                                                    const int* __restrict__ det_off, const int* __restrict__ gt_off,
                                                    const unsigned char* __restrict__ ignore,
@@ -120,21 +130,24 @@ __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou
                                                    const int* __restrict__ ncand, const int* __restrict__ cfirst,
                                                    float* __restrict__ labels, float* __restrict__ weights,
                                                    int* __restrict__ assign) {
+  __shared__ unsigned char taken[kMaxGt];
+  __shared__ int owner[kMaxGt];
   const int img = blockIdx.x, lane = threadIdx.x;
   const int d0 = det_off[img], d1 = det_off[img + 1];
   const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
   const float* ibase = iou + anno_off[img];
-  unsigned matched = 0;   // bit b of lane l: GT (b*64 + l) is taken
+  for (int g = lane; g < m; g += 64) { taken[g] = 0; owner[g] = 64; }
   // the records of the next 64 detections (two dependent loads: order -> k1/k2/ncand/cfirst) are requested
-  // before the sequential loop over the current ones
+  // before the current ones are resolved
   int n_det_ = d0 + lane < d1 ? order[d0 + lane] : -1;
   unsigned long long n_c1 = n_det_ >= 0 ? k1[n_det_] : 0ull, n_c2 = n_det_ >= 0 ? k2[n_det_] : 0ull;
   int n_nc = n_det_ >= 0 ? ncand[n_det_] : 0, n_cf = n_det_ >= 0 ? cfirst[n_det_] : -1;
+  __syncthreads();
   for (int p0 = d0; p0 < d1; p0 += 64) {
     const int p = p0 + lane;
     const bool act = p < d1;
     const int det = n_det_;
-    const unsigned long long c1 = n_c1, c2 = n_c2;
+    const int ga = (int)(unsigned)n_c1, gb = (int)(unsigned)n_c2;
     const int nc = n_nc, cf = n_cf;
     {
       const int pn = p0 + 64 + lane;
@@ -142,50 +155,50 @@ __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou
       n_c1 = n_det_ >= 0 ? k1[n_det_] : 0ull; n_c2 = n_det_ >= 0 ? k2[n_det_] : 0ull;
       n_nc = n_det_ >= 0 ? ncand[n_det_] : 0; n_cf = n_det_ >= 0 ? cfirst[n_det_] : -1;
     }
-    const unsigned c1lo = (unsigned)c1, c2lo = (unsigned)c2;
     int res = (act && nc == 0) ? cf : -1;     // no regular candidate: state-independent
-    unsigned long long todo = __ballot(act && nc > 0);
-    while (todo) {
-      const int l = __builtin_ctzll(todo);    // wave-uniform: broadcasts below are v_readlane, not LDS permutes
-      todo &= todo - 1;
-      const int ga = (int)__builtin_amdgcn_readlane(c1lo, l);
-      const int nl = __builtin_amdgcn_readlane(nc, l);
-      int mt = -1;
-      if (!((__builtin_amdgcn_readlane(matched, ga & 63) >> (ga >> 6)) & 1u)) {
-        mt = ga;
-      } else if (nl >= 2) {
-        const int gb = (int)__builtin_amdgcn_readlane(c2lo, l);
-        if (!((__builtin_amdgcn_readlane(matched, gb & 63) >> (gb >> 6)) & 1u)) mt = gb;
-        else if (nl > 2) {
-          // rare: more than two candidates and the best two are taken -> scan the row
-          const int dl = __builtin_amdgcn_readlane(det, l);
-          const float* row = ibase + (long long)(dl - d0) * m;
-          unsigned long long best = 0;
-          for (int gbase = 0; gbase < m; gbase += 64) {
-            const int g = gbase + lane;
-            if (g < m) {
-              const float v = row[g];
-              const bool taken = (matched >> (gbase >> 6)) & 1u;
-              if (v >= 0.5f && !ignore[g0 + g] && !taken) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)g;
-                best = key > best ? key : best;
-              }
-            }
+    bool open = act && nc > 0;
+    while (__ballot(open)) {
+      const bool f1 = open && !taken[ga];
+      const bool f2 = open && nc >= 2 && !taken[gb];
+      const int wish = f1 ? ga : (f2 ? gb : -1);
+      if (open && wish < 0 && nc <= 2) { res = cf; open = false; }   // det_matching.cc:134-148 fall-through
+      if (f1) atomicMin(&owner[ga], lane);
+      if (f2) atomicMin(&owner[gb], lane);
+      __syncthreads();
+      const bool mine = open && wish >= 0 && owner[wish] == lane;
+      __syncthreads();
+      if (f1) owner[ga] = 64;
+      if (f2) owner[gb] = 64;
+      const unsigned long long hold = __ballot(open && nc > 2 && !mine);
+      const int fence = hold ? __builtin_ctzll(hold) : 64;
+      if (mine && lane < fence) { taken[wish] = 1; res = wish; open = false; }
+      __syncthreads();
+      const unsigned long long rest = __ballot(open);
+      if (rest && __builtin_ctzll(rest) == fence && __builtin_amdgcn_readlane((int)(wish < 0), fence)) {
+        // more than two candidates and the best two are taken: scan the row of that detection
+        const int dl = __builtin_amdgcn_readlane(det, fence);
+        const float* row = ibase + (long long)(dl - d0) * m;
+        unsigned long long best = 0;
+        for (int g = lane; g < m; g += 64) {
+          const float v = row[g];
+          if (v >= 0.5f && !ignore[g0 + g] && !taken[g]) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)g;
+            best = key > best ? key : best;
           }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o);
-            best = other > best ? other : best;
-          }
-          if (best) mt = (int)(unsigned)best;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long other = __shfl_xor(best, o);
+          best = other > best ? other : best;
+        }
+        const int mt = best ? (int)(unsigned)best : -1;
+        if (lane == fence) {
+          if (mt >= 0) taken[mt] = 1;
+          res = mt >= 0 ? mt : cf;
+          open = false;
+        }
+        __syncthreads();
       }
-      if (mt >= 0) {
-        if (lane == (mt & 63)) matched |= 1u << (mt >> 6);
-      } else {
-        mt = __builtin_amdgcn_readlane(cf, l);    // fall through to the crowd GTs (det_matching.cc:134-148)
-      }
-      if (lane == l) res = mt;
     }
     if (act) {
       assign[det] = res;
@@ -259,10 +272,11 @@ MatchWs carve_match(void* ws, int n_det) {
 
 int run_matching(const float* iou, const long long* anno_off, const int* det_off, const int* gt_off,
                  const unsigned char* ignore, const float* score, int n_det, int n_img, void* ws, float* labels,
-                 float* weights, int* assign, hipStream_t s) {
+                 float* weights, int* assign, bool have_cand, hipStream_t s) {
   const MatchWs w = carve_match(ws, n_det);
   const int grid = (n_det + 255) / 256;
-  match_cand<<<grid, 256, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, n_det, n_img, w.k1, w.k2, w.ncand, w.cfirst);
+  if (!have_cand)
+    match_cand<<<grid, 256, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, n_det, n_img, w.k1, w.k2, w.ncand, w.cfirst);
   match_rank<<<(n_det + 63) / 64, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
   match_greedy<<<n_img, 64, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
                                     labels, weights, assign);
@@ -286,7 +300,7 @@ extern "C" int det_matching_f32(const float* iou, const float* score, const uint
   if (n_det == 0) return GNET_OK;
   if (!score || !labels || !weights || !assignment || !workspace) return GNET_ERR_INVALID;
   if (n_gt > 0 && (!iou || !ignore)) return GNET_ERR_INVALID;
-  if (n_gt > 2048) return GNET_ERR_UNSUPPORTED;
+  if (n_gt > kMaxGt) return GNET_ERR_UNSUPPORTED;
   if (workspace_bytes < det_matching_workspace_bytes(n_det, n_gt)) return GNET_ERR_WORKSPACE;
   if (((uintptr_t)workspace & 255) != 0) return GNET_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
@@ -299,17 +313,25 @@ extern "C" int det_matching_f32(const float* iou, const float* score, const uint
   const int* det_off = (const int*)((char*)workspace + 16);
   const int* gt_off = (const int*)((char*)workspace + 24);
   return run_matching(iou, anno_off, det_off, gt_off, ignore, score, n_det, 1, (char*)workspace + 1024, labels, weights,
-                      assignment, s);
+                      assignment, false, s);
 }
 
-extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-                         const float* class_weights, float grad_scale, gnet_buffers* buf, gnet_stream_t stream) {
-  clear_hip_error();
+namespace {
+int check_loss_args(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in, const gnet_buffers* buf) {
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !buf || !buf->labels || !buf->match_ws) return GNET_ERR_INVALID;
   if (shape->n_det == 0) return GNET_OK;
   if (!in->gt_off || !in->anno_off || !in->det_off) return GNET_ERR_INVALID;
   if (shape->n_gt > 0 && (!in->gt_boxes || !in->gt_crowd || !in->gt_classes)) return GNET_ERR_INVALID;
+  return GNET_OK;
+}
+}  // namespace
+
+extern "C" int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                                  gnet_buffers* buf, gnet_stream_t stream) {
+  clear_hip_error();
+  const int st = check_loss_args(cfg, shape, in, buf);
+  if (st != GNET_OK || shape->n_det == 0) return st;
   hipStream_t s = (hipStream_t)stream;
   const int N = shape->n_det;
   const int grid = (N + 255) / 256;
@@ -317,9 +339,27 @@ extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const 
     anno_iou<<<grid, 256, 0, s>>>((const float4*)in->dets, in->det_classes, in->det_off, (const float4*)in->gt_boxes,
                                   in->gt_crowd, in->gt_classes, in->gt_off, (const long long*)in->anno_off, N,
                                   shape->n_img, cfg->num_classes > 1, buf->det_anno_iou);
-  int st = run_matching(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
-                        buf->prediction, N, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
-                        buf->det_gt_matching, s);
+  const MatchWs w = carve_match((char*)buf->match_ws + 1024, N);
+  match_cand<<<grid, 256, 0, s>>>(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
+                                  N, shape->n_img, w.k1, w.k2, w.ncand, w.cfirst);
+  return launch_status();
+}
+
+extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                         const float* class_weights, float grad_scale, gnet_buffers* buf, int32_t prepared,
+                         gnet_stream_t stream) {
+  clear_hip_error();
+  int st = check_loss_args(cfg, shape, in, buf);
+  if (st != GNET_OK || shape->n_det == 0) return st;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = shape->n_det;
+  if (!prepared) {
+    st = gnet_match_prepare(cfg, shape, in, buf, stream);
+    if (st != GNET_OK) return st;
+  }
+  st = run_matching(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
+                    buf->prediction, N, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
+                    buf->det_gt_matching, true, s);
   if (st != GNET_OK) return st;
   loss_kernel<<<shape->n_img, 256, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,
                                            in->det_off, in->gt_off, in->gt_crowd, in->gt_classes, class_weights,

@@ -358,6 +358,20 @@ class Gnet(object):
         self.num_edges = E
         return shape, buf
 
+    def _prepare_matching(self, shape, inp, buf):
+        """det_anno_iou and the matching's candidate keys depend on the inputs only: they run on the side stream
+        while the forward pass runs on the main one (ordered after everything the main stream has queued so far --
+        the previous step's readers of these buffers -- and before gnet_loss through `_prep_done`)."""
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_prep_done", None) is None:
+            self._plan_done, self._prep_done = torch.cuda.Event(), torch.cuda.Event()
+        self._plan_done.record(main)
+        self._side.wait_event(self._plan_done)
+        with torch.cuda.stream(self._side):
+            _lib.check(self._lib.gnet_match_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), C.byref(buf),
+                                                    C.c_void_p(self._side.cuda_stream)), "gnet_match_prepare")
+            self._prep_done.record(self._side)
+
     def _mode(self, training):
         """`training` argument of the C ABI: 0 inference, 1 training, 2 training + per-block pw_fc1 activations kept."""
         return 0 if not training else (2 if self.keep_edge_activations else 1)
@@ -394,11 +408,14 @@ class Gnet(object):
         self._inputs = inp
         if self._imfeats:
             buf.start_feat = _vp(self._imfeat_forward(db))
+        if training:
+            self._prepare_matching(shape, inp, buf)
         _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                     C.byref(buf), self._mode(training), s), "gnet_forward")
         if training:
+            torch.cuda.current_stream(self.device).wait_event(self._prep_done)
             _lib.check(lib.gnet_loss(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.class_weights),
-                                     float(self.grad_scale), C.byref(buf), s), "gnet_loss")
+                                     float(self.grad_scale), C.byref(buf), 1, s), "gnet_loss")
             if backward:
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                              C.byref(buf), _vp(self.grads), s), "gnet_backward")

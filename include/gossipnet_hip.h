@@ -191,7 +191,15 @@ int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inp
  * (network.py:174-187,275-313); also seeds d_logits = grad_scale * dloss/dlogit.
  * class_weights: [num_classes+1] device, or NULL for ones (network.py:282-284). */
 int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-              const float* class_weights, float grad_scale, gnet_buffers* buf, gnet_stream_t stream);
+              const float* class_weights, float grad_scale, gnet_buffers* buf, int32_t prepared,
+              gnet_stream_t stream);
+
+/* The score-independent half of gnet_loss -- det_anno_iou (network.py:174-187) and the per-detection
+ * candidate keys of the matching (det_matching.cc:128-148) -- depends on the inputs only: a caller may
+ * run it on another stream while gnet_forward runs and then pass prepared = 1 to gnet_loss (after
+ * ordering the two streams).  With prepared = 0 gnet_loss does this work itself. */
+int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                       gnet_buffers* buf, gnet_stream_t stream);
 
 /* ---- backward: d loss / d params -> grads[param_count] (overwritten).
  * Reproducible: no float atomics, fixed summation order (per-workgroup partials, summed in index order).
