@@ -168,6 +168,28 @@ __device__ __forceinline__ void mma_abt(f32x16& acc, const float* A, int lda, co
   }
 }
 
+// The same product with the B operand already in registers: kernels whose stages are separated by barriers
+// request every weight slice they will need at their top (load_bt), so that no stage waits for its own loads.
+template <int K> struct BtRegs { f32x4 v[K / 8]; };
+template <int K>
+__device__ __forceinline__ void load_bt(BtRegs<K>& b, const float* __restrict__ Bt, int ldb, int lane) {
+  const float* bp = Bt + (size_t)(lane & 31) * ldb + 4 * (lane >> 5);
+#pragma unroll
+  for (int k = 0; k < K; k += 8) b.v[k / 8] = *reinterpret_cast<const f32x4*>(bp + k);
+}
+template <int K>
+__device__ __forceinline__ void mma_abt_r(f32x16& acc, const float* A, int lda, const BtRegs<K>& b, int lane) {
+  const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
+#pragma unroll
+  for (int k = 0; k < K; k += 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[k / 8].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.v[k / 8].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.v[k / 8].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.v[k / 8].w, acc, 0, 0, 0);
+  }
+}
+
 // Global accesses as (uniform base pointer) + (32-bit byte offset): selects the "saddr + voffset" form of
 // global_load / global_store, one 32-bit VALU op per address instead of the 64-bit pointer arithmetic of
 // base[index] (3-4 VALU ops).  Vector instructions are paid in MFMA time (the fp32 MFMA shares the FP32 lanes).

@@ -623,6 +623,28 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int row0 = blockIdx.x * 32;
+  // every global operand of the stages below is requested here, before the first barrier: the stages are a chain
+  // of small products separated by barriers, and a load issued inside a stage costs that stage a memory latency
+  BtRegs<D_P> gW3, gW4; BtRegs<32> gWr, gWrn, gW1;
+  float gB3 = 0.f, gB4 = 0.f, gB1 = 0.f, gBr = 0.f, gBrn = 0.f, gXin[16];
+  if (a.do_post) {
+    if (wave < 2) { load_bt<D_P>(gW3, a.w3t + (size_t)(32 * wave) * D_P, D_P, lane); gB3 = a.b3[32 * wave + col]; }
+    load_bt<D_P>(gW4, a.w4t + (size_t)(32 * wave) * D_P, D_P, lane);
+    gB4 = a.b4[32 * wave + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int node = row0 + crow(r, half);
+      gXin[r] = (a.x_prev && node < a.n_det) ? a.x_prev[(size_t)node * D_S + 32 * wave + col] : 0.f;
+    }
+  }
+  if (a.do_pre) {
+    load_bt<32>(gWr, a.wrt + 32 * wave, D_S, lane);
+    if (a.wrnt) load_bt<32>(gWrn, a.wrnt + 32 * wave, D_S, lane);
+    load_bt<D_R>(gW1, a.w1t + (size_t)(32 * (wave & 1)) * (D_E + 2 * D_R) + D_E + (wave >> 1) * D_R, D_E + 2 * D_R, lane);
+    if (wave < 2) gB1 = a.b1[32 * wave + col];
+    gBr = a.br[col];
+    if (a.wrnt) gBrn = a.brn[col];
+  }
   if (a.do_post) {
     // p tile (segment max) -> sY[32][68]
     for (int i = tid; i < 32 * D_P; i += 256) {
@@ -632,10 +654,10 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     }
     __syncthreads();
     f32x16 acc = zero16();
-    if (wave < 2) mma_abt<D_P>(acc, sY, E_LD2, a.w3t + (size_t)(32 * wave) * D_P, D_P, lane);
+    if (wave < 2) mma_abt_r<D_P>(acc, sY, E_LD2, gW3, lane);
     __syncthreads();
     if (wave < 2) {
-      const float bb = a.b3[32 * wave + col];
+      const float bb = gB3;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow(r, half);
@@ -646,16 +668,15 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     }
     __syncthreads();
     acc = zero16();
-    mma_abt<D_P>(acc, sX, E_LD2, a.w4t + (size_t)(32 * wave) * D_P, D_P, lane);
+    mma_abt_r<D_P>(acc, sX, E_LD2, gW4, lane);
     __syncthreads();
     {
-      const float bb = a.b4[32 * wave + col];
+      const float bb = gB4;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow(r, half);
         const int node = row0 + row;
-        float xin = 0.f;
-        if (a.x_prev && node < a.n_det) xin = a.x_prev[(size_t)node * D_S + 32 * wave + col];
+        const float xin = gXin[r];
         const float v = fmaxf(xin + (acc[r] + bb), 0.f);   // relu(infeats + feats) network.py:408
         sX[row * N_LD + 32 * wave + col] = v;
         if (node < a.n_det) a.x_out[(size_t)node * D_S + 32 * wave + col] = v;
@@ -691,7 +712,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     // r = relu(x . Wr + br): K = 128 split over the 4 waves
     {
       f32x16 acc = zero16();
-      mma_abt<32>(acc, sX + 32 * wave, N_LD, a.wrt + 32 * wave, D_S, lane);
+      mma_abt_r<32>(acc, sX + 32 * wave, N_LD, gWr, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sR[(wave * 32 + crow(r, half)) * 32 + col] = acc[r];
     }
@@ -701,7 +722,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       float v = sR[(0 * 32 + row) * 32 + ff] + sR[(1 * 32 + row) * 32 + ff];
       v += sR[(2 * 32 + row) * 32 + ff];
       v += sR[(3 * 32 + row) * 32 + ff];
-      v = fmaxf(v + a.br[ff], 0.f);
+      v = fmaxf(v + gBr, 0.f);          // ff == col for every i of this thread
       sY[row * E_LD1 + ff] = v;
       if (a.training && row0 + row < a.n_det) a.r[(size_t)(row0 + row) * D_R + ff] = v;
     }
@@ -711,7 +732,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       // neighbor_feats: r_n = relu(x . Wrn + brn), the same K-split product through the same partial buffer
       {
         f32x16 acc = zero16();
-        mma_abt<32>(acc, sX + 32 * wave, N_LD, a.wrnt + 32 * wave, D_S, lane);
+        mma_abt_r<32>(acc, sX + 32 * wave, N_LD, gWrn, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sR[(wave * 32 + crow(r, half)) * 32 + col] = acc[r];
       }
@@ -722,7 +743,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
         float v = sR[(0 * 32 + row) * 32 + ff] + sR[(1 * 32 + row) * 32 + ff];
         v += sR[(2 * 32 + row) * 32 + ff];
         v += sR[(3 * 32 + row) * 32 + ff];
-        v = fmaxf(v + a.brn[ff], 0.f);
+        v = fmaxf(v + gBrn, 0.f);
         sY2[row * E_LD1 + ff] = v;
         if (a.training && row0 + row < a.n_det) a.r_nb[(size_t)(row0 + row) * D_R + ff] = v;
       }
@@ -733,8 +754,8 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     {
       const int part = wave >> 1, nt = wave & 1;
       f32x16 acc = zero16();
-      mma_abt<D_R>(acc, part ? sYn : sY, E_LD1, a.w1t + (size_t)(32 * nt) * (D_E + 2 * D_R) + D_E + part * D_R, D_E + 2 * D_R, lane);
-      const float bb = part == 0 ? a.b1[32 * nt + col] : 0.f;
+      mma_abt_r<D_R>(acc, part ? sYn : sY, E_LD1, gW1, lane);
+      const float bb = gB1;
       float* dst = part == 0 ? a.rc : a.rn;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
