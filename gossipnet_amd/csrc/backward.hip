@@ -648,49 +648,54 @@ __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
       const int tt = in ? a.edge_t[el] : 0;
       unsigned long long mo = __ballot(in && W1_BIT(el));
       unsigned long long mr = __ballot(in && W1_BIT(tt));
-      // four rows in flight per wave (the sums are latency-bound: 2 rows per round trip kept the kernel at 2.5 TB/s);
-      // rows are taken in ascending edge order, missing slots re-read the last row with weight 0
+      // eight rows in flight per wave (the sums are latency-bound: 2 rows per round trip kept the kernel at 2.5 TB/s,
+      // 4 at 3.9); rows are taken in ascending edge order, missing slots re-read the last row and are skipped.
+      // The geometry columns of the 64 edges of this pass sit in two registers per lane (one coalesced load) and
+      // reach the sums through v_readlane.
+      float4 geA = make_float4(0.f, 0.f, 0.f, 0.f), geB = geA;
+      if (in) {
+        geA = *reinterpret_cast<const float4*>(a.geo + (size_t)el * 8);
+        geB = *reinterpret_cast<const float4*>(a.geo + (size_t)el * 8 + 4);
+      }
       while (mo) {
-        int e[4]; float wgt[4];
+        int j[8]; bool hv[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool have = mo != 0ull;
-          const int j = have ? __builtin_ctzll(mo) : 0;
-          if (have) mo &= mo - 1;
-          e[q] = have ? base + j : (q ? e[q - 1] : base);
-          wgt[q] = have ? 1.f : 0.f;
+        for (int q = 0; q < 8; ++q) {
+          hv[q] = mo != 0ull;
+          j[q] = hv[q] ? __builtin_ctzll(mo) : (q ? j[q - 1] : 0);
+          if (hv[q]) mo &= mo - 1;
         }
-        float4 d[4], ga[4], gc[4];
+        float4 d[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          d[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)e[q] * D_H + 4 * lane);
-          ga[q] = *reinterpret_cast<const float4*>(a.geo + (size_t)e[q] * 8);
-          gc[q] = *reinterpret_cast<const float4*>(a.geo + (size_t)e[q] * 8 + 4);
-        }
+        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)(base + j[q]) * D_H + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (wgt[q] != 0.f) {                              // wave-uniform
+        for (int q = 0; q < 8; ++q) {
+          if (hv[q]) {                                      // wave-uniform
             const float4 dq = d[q];
+            const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geA.x), j[q])), g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geA.y), j[q]));
+            const float g2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geA.z), j[q])), g3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geA.w), j[q]));
+            const float g4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geB.x), j[q])), g5 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geB.y), j[q]));
+            const float g6 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geB.z), j[q]));
             S.x += dq.x; S.y += dq.y; S.z += dq.z; S.w += dq.w;
-            ACC4(g[0], ga[q].x, dq); ACC4(g[1], ga[q].y, dq); ACC4(g[2], ga[q].z, dq); ACC4(g[3], ga[q].w, dq);
-            ACC4(g[4], gc[q].x, dq); ACC4(g[5], gc[q].y, dq); ACC4(g[6], gc[q].z, dq);
+            ACC4(g[0], g0, dq); ACC4(g[1], g1, dq); ACC4(g[2], g2, dq); ACC4(g[3], g3, dq);
+            ACC4(g[4], g4, dq); ACC4(g[5], g5, dq); ACC4(g[6], g6, dq);
           }
         }
       }
       while (mr) {
-        int r[4]; bool hv[4];
+        int r[8]; bool hv[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
           hv[q] = mr != 0ull;
-          const int j = hv[q] ? __builtin_ctzll(mr) : 0;
+          const int jj = hv[q] ? __builtin_ctzll(mr) : 0;
           if (hv[q]) mr &= mr - 1;
-          r[q] = hv[q] ? __builtin_amdgcn_readlane(tt, j) : (q ? r[q - 1] : 0);
+          r[q] = hv[q] ? __builtin_amdgcn_readlane(tt, jj) : (q ? r[q - 1] : 0);
         }
-        float4 tq[4];
+        float4 tq[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r[q] * D_H + 4 * lane);
+        for (int q = 0; q < 8; ++q) tq[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r[q] * D_H + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 8; ++q)
           if (hv[q]) { T.x += tq[q].x; T.y += tq[q].y; T.z += tq[q].z; T.w += tq[q].w; }
       }
     }
