@@ -206,16 +206,19 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
     }
     unsigned long long mr = __ballot(tp >= 0);
     while (mr) {
-      // next 8 reversed rows: two per quarter-wave
-      int j[2] = {-1, -1};
+      // next 16 reversed rows: four per quarter-wave
+      int j[4] = {-1, -1, -1, -1};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if ((q & 3) == sub) j[q >> 2] = b; } }
-      const int pa = __shfl(tp, j[0] < 0 ? 0 : j[0]), pb = __shfl(tp, j[1] < 0 ? 0 : j[1]);
-      const float4 va = *reinterpret_cast<const float4*>(g1c + (size_t)max(pa, 0) * D_P + 4 * f4);
-      const float4 vb = *reinterpret_cast<const float4*>(g1c + (size_t)max(pb, 0) * D_P + 4 * f4);
-      const float wa = j[0] >= 0 ? 1.f : 0.f, wb = j[1] >= 0 ? 1.f : 0.f;
-      sn.x = fmaf(wa, va.x, sn.x); sn.y = fmaf(wa, va.y, sn.y); sn.z = fmaf(wa, va.z, sn.z); sn.w = fmaf(wa, va.w, sn.w);
-      sn.x = fmaf(wb, vb.x, sn.x); sn.y = fmaf(wb, vb.y, sn.y); sn.z = fmaf(wb, vb.z, sn.z); sn.w = fmaf(wb, vb.w, sn.w);
+      for (int q = 0; q < 16; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if ((q & 3) == sub) j[q >> 2] = b; } }
+      float4 v[4]; float w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pq = __shfl(tp, j[q] < 0 ? 0 : j[q]);
+        w[q] = j[q] >= 0 ? 1.f : 0.f;
+        v[q] = *reinterpret_cast<const float4*>(g1c + (size_t)max(pq, 0) * D_P + 4 * f4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sn.x = fmaf(w[q], v[q].x, sn.x); sn.y = fmaf(w[q], v[q].y, sn.y); sn.z = fmaf(w[q], v[q].z, sn.z); sn.w = fmaf(w[q], v[q].w, sn.w); }
     }
   }
 #pragma unroll
