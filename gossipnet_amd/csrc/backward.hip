@@ -165,8 +165,8 @@ struct BlkNodeArgs {
   float* arena; long long stride;
 };
 
-constexpr int BN_RT_FLOATS = 2 * 32 * LD128 + 2 * 32 * LD64 + 3 * 32 * LD32 + 4 * 32 * 32;   // per row tile: X, DZ, Rc|Rn, Rr|Dr, Rrn, Part
-constexpr size_t kBlkNodeSmem = (size_t)(2 * BN_RT_FLOATS) * sizeof(float);     // 159 KB
+constexpr int BN_FLOATS = 2 * 32 * LD128 + 2 * 32 * LD64 + 3 * 32 * LD32 + 4 * 32 * 32;   // X, DZ, Rc|Rn, Rr|Dr, Rrn, Part
+constexpr size_t kBlkNodeSmem = (size_t)BN_FLOATS * sizeof(float);              // 80 KB
 
 __device__ __forceinline__ unsigned long long bn_low_mask(int bit) { return bit ? (~0ull >> (64 - bit)) : 0ull; }
 __device__ __forceinline__ int bn_winner_pos(const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix, int e) {
@@ -232,13 +232,17 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
+// One workgroup (4 waves, one per SIMD: the whole register file is theirs) walks 32-detection tiles.  The stages of
+// a tile are a chain of small products separated by barriers, so nothing inside the chain may wait for memory:
+// the weight slices each wave multiplies by are loaded into registers once, before the first tile, and all seven
+// input tiles of a detection tile (x, d_x, r, [r_n,] d_rc, d_rn, q, segment-max records) are requested together
+// at its top.  The weight-gradient accumulators stay in registers across the tiles of the workgroup.
+template <bool NF>
+__global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rt = wave >> 2, cw = wave & 3, lt = tid & 255;       // row tile, role within the row tile, thread within it
+  const int tid = threadIdx.x, lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
-  float* base = smem + rt * BN_RT_FLOATS;
-  float* sX = base;                          // [32][132] x_prev (= block_feats[b-1])
+  float* sX = smem;                          // [32][132] x_prev (= block_feats[b-1])
   float* sDZ = sX + 32 * LD128;              // [32][132] d_x tile: dz of block b, then dz of block b-1
   float* sRc = sDZ + 32 * LD128;             // [32][68]  d_rc          | post: q
   float* sRn = sRc + 32 * LD64;              // [32][68]  d_rn          | post: p (segment max)
@@ -247,23 +251,70 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
   float* sRrn = sDr + 32 * LD32;             // [32][36]  r_n (neighbor_feats)
   float* sPart = sRrn + 32 * LD32;           // [4][32][32] K-split partials | post: [2][32][64]
   float* sDrn = sRn;                         // [32][36]  drpre of the neighbour reduce FC, over d_rn once that is consumed
-  const bool nf = a.wrn != nullptr;
   float* sQ = sRc; float* sP = sRn; float* sDq = sRr; float* sR = sPart;
   f32x16 aWcn = zero16(), aWr = zero16(), aWrn = zero16(), aW4a = zero16(), aW4b = zero16(), aW3 = zero16();
   float gb1 = 0.f, gbr = 0.f, gbrn = 0.f, gb4 = 0.f, gb3 = 0.f;
-  const int ntiles = (a.n_det + 63) / 64;
+  BtRegs<32> gW1, gWr, gWrn, gW3; BtRegs<64> gW4;
+  if (a.do_pre) {
+    load_bt<32>(gW1, a.w1 + (size_t)(32 + 32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane);   // role = (term, K half)
+    load_bt<D_R>(gWr, a.wr + (size_t)(32 * cw) * D_R, D_R, lane);
+    if (NF) load_bt<D_R>(gWrn, a.wrn + (size_t)(32 * cw) * D_R, D_R, lane);
+  }
+  if (a.do_post) {
+    load_bt<64>(gW4, a.w4 + (size_t)(32 * (cw & 1)) * D_S + 64 * (cw >> 1), D_S, lane);        // role = (column tile, K half)
+    load_bt<32>(gW3, a.w3 + (size_t)(32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane);
+  }
+  const int ntiles = (a.n_det + 31) / 32;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int row0 = t * 64 + 32 * rt;                    // first detection of this row tile
-    __syncthreads();
-    // ---- tiles from HBM: x_prev, d_x, r
-    if (a.x_prev) load_tile<D_S, LD128>(sX, a.x_prev, row0, a.n_det, lt, 256);
-    else for (int i = lt; i < 32 * LD128; i += 256) sX[i] = 0.f;
-    if (a.do_post || a.do_pre) load_tile<D_S, LD128>(sDZ, a.d_x, row0, a.n_det, lt, 256);
+    const int row0 = t * 32;                    // first detection of this tile
+    // ---- every input of the tile, requested together
+    float4 vx[4], vz[4], vr, vrn, vc[2], vn[2], vq[2];
+    unsigned long long vpm[8];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    vr = vrn = z4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+      const bool ok = row0 + row < a.n_det;
+      vx[j] = (a.x_prev && ok) ? ldg4_b(a.x_prev, (unsigned)(row0 + row) * (D_S * 4u) + 16u * c4) : z4;
+      vz[j] = ok ? ldg4_b(a.d_x, (unsigned)(row0 + row) * (D_S * 4u) + 16u * c4) : z4;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
+      const bool ok = row0 + row < a.n_det;
+      vc[j] = (a.do_pre && a.d_rc && ok) ? ldg4_b(a.d_rc, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
+      vn[j] = (a.do_pre && a.d_rc && ok) ? ldg4_b(a.d_rn, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
+      vq[j] = (a.do_post && ok) ? ldg4_b(a.q, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
+    }
     if (a.do_pre) {
-      load_tile<D_R, LD32>(sRr, a.r, row0, a.n_det, lt, 256);
-      if (nf) load_tile<D_R, LD32>(sRrn, a.r_nb, row0, a.n_det, lt, 256);
-      if (a.d_rc) { load_tile<D_P, LD64>(sRc, a.d_rc, row0, a.n_det, lt, 256); load_tile<D_P, LD64>(sRn, a.d_rn, row0, a.n_det, lt, 256); }
-      else { for (int i = lt; i < 2 * 32 * LD64; i += 256) sRc[i] = 0.f; }      // no edges
+      const int row = tid >> 3, c4 = tid & 7;
+      const bool ok = row0 + row < a.n_det;
+      if (ok) vr = ldg4_b(a.r, (unsigned)(row0 + row) * (D_R * 4u) + 16u * c4);
+      if (NF && ok) vrn = ldg4_b(a.r_nb, (unsigned)(row0 + row) * (D_R * 4u) + 16u * c4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
+      vpm[j] = (a.do_post && row0 + row < a.n_det) ? a.pm[(size_t)(row0 + row) * D_P + ff] : 0ull;
+    }
+    __syncthreads();                              // the previous tile's readers are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+      *reinterpret_cast<float4*>(sX + row * LD128 + 4 * c4) = vx[j];
+      *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = vz[j];
+    }
+    if (a.do_pre) {
+      { const int row = tid >> 3, c4 = tid & 7;
+        *reinterpret_cast<float4*>(sRr + row * LD32 + 4 * c4) = vr;
+        if (NF) *reinterpret_cast<float4*>(sRrn + row * LD32 + 4 * c4) = vrn; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
+        *reinterpret_cast<float4*>(sRc + row * LD64 + 4 * c4) = vc[j];
+        *reinterpret_cast<float4*>(sRn + row * LD64 + 4 * c4) = vn[j];
+      }
     }
     __syncthreads();
     if (a.do_pre) {
@@ -271,7 +322,7 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
       {
         const int term = cw & 1, kh = cw >> 1;
         f32x16 acc = zero16();
-        mma_abt<32>(acc, (term ? sRn : sRc) + 32 * kh, LD64, a.w1 + (size_t)(32 + 32 * term) * D_P + 32 * kh, D_P, lane);
+        mma_abt_r<32>(acc, (term ? sRn : sRc) + 32 * kh, LD64, gW1, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sPart[(cw * 32 + crow(r, half)) * 32 + col] = acc[r];
       }
@@ -279,23 +330,23 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
       {
         const int term = cw >> 1, nj = cw & 1;
         const float* Y = term ? sRn : sRc;
-        const float* X = (term && nf) ? sRrn : sRr;
+        const float* X = (term && NF) ? sRrn : sRr;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
           const int row = 2 * kk + half;
           aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(X[row * LD32 + col], Y[row * LD64 + 32 * nj + col], aWcn, 0, 0, 0);
         }
       }
-      if (lt < D_P) gb1 += col_sum32(sRc, LD64, lt);
+      if (tid < D_P) gb1 += col_sum32(sRc, LD64, tid);
       __syncthreads();
-      for (int i = lt; i < 32 * D_R; i += 256) {
+      for (int i = tid; i < 32 * D_R; i += 256) {
         const int row = i >> 5, ff = i & 31;
         // partials: roles 0 / 2 = drc . Wc^T (K halves), roles 1 / 3 = drn . Wn^T
-        if (nf) {
-          const float vc = sPart[(0 * 32 + row) * 32 + ff] + sPart[(2 * 32 + row) * 32 + ff];
-          const float vn = sPart[(1 * 32 + row) * 32 + ff] + sPart[(3 * 32 + row) * 32 + ff];
-          sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? vc : 0.f;      // ReLU of reduce_dim
-          sDrn[row * LD32 + ff] = sRrn[row * LD32 + ff] > 0.f ? vn : 0.f;    // ReLU of reduce_dim_neighbor
+        if (NF) {
+          const float vcs = sPart[(0 * 32 + row) * 32 + ff] + sPart[(2 * 32 + row) * 32 + ff];
+          const float vns = sPart[(1 * 32 + row) * 32 + ff] + sPart[(3 * 32 + row) * 32 + ff];
+          sDr[row * LD32 + ff] = sRr[row * LD32 + ff] > 0.f ? vcs : 0.f;     // ReLU of reduce_dim
+          sDrn[row * LD32 + ff] = sRrn[row * LD32 + ff] > 0.f ? vns : 0.f;   // ReLU of reduce_dim_neighbor
         } else {
           float v = sPart[(0 * 32 + row) * 32 + ff] + sPart[(1 * 32 + row) * 32 + ff];
           v += sPart[(2 * 32 + row) * 32 + ff];
@@ -310,20 +361,20 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
         const int row = 2 * kk + half;
         aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDr[row * LD32 + col], aWr, 0, 0, 0);
       }
-      if (lt < D_R) gbr += col_sum32(sDr, LD32, lt);
-      if (nf) {
+      if (tid < D_R) gbr += col_sum32(sDr, LD32, tid);
+      if (NF) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
           const int row = 2 * kk + half;
           aWrn = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDrn[row * LD32 + col], aWrn, 0, 0, 0);
         }
-        if (lt < D_R) gbrn += col_sum32(sDrn, LD32, lt);
+        if (tid < D_R) gbrn += col_sum32(sDrn, LD32, tid);
       }
       if (a.do_post || a.want_dx0) {
         // d_x += drpre . Wr^T [+ drpre_n . Wrn^T] (columns [32 cw, 32 cw + 32))
         f32x16 acc = zero16();
-        mma_abt<D_R>(acc, sDr, LD32, a.wr + (size_t)(32 * cw) * D_R, D_R, lane);
-        if (nf) mma_abt<D_R>(acc, sDrn, LD32, a.wrn + (size_t)(32 * cw) * D_R, D_R, lane);
+        mma_abt_r<D_R>(acc, sDr, LD32, gWr, lane);
+        if (NF) mma_abt_r<D_R>(acc, sDrn, LD32, gWrn, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
@@ -336,7 +387,7 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
     }
     if (a.do_post) {
       // dz = d_x * (x_out > 0): also the shortcut gradient of block b-1 (network.py:407-408)
-      for (int i = lt; i < 32 * (D_S / 4); i += 256) {
+      for (int i = tid; i < 32 * (D_S / 4); i += 256) {
         const int row = i >> 5, c4 = i & 31;
         const float4 g = *reinterpret_cast<const float4*>(sDZ + row * LD128 + 4 * c4);
         const float4 x = *reinterpret_cast<const float4*>(sX + row * LD128 + 4 * c4);
@@ -344,12 +395,15 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
         *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = v;
         if (row0 + row < a.n_det) *reinterpret_cast<float4*>(a.d_x + (size_t)(row0 + row) * D_S + 4 * c4) = v;
       }
-      load_tile<D_P, LD64>(sQ, a.q, row0, a.n_det, lt, 256);
-      for (int i = lt; i < 32 * D_P; i += 256) {
-        const int row = i >> 6, ff = i & 63;
-        float v = 0.f;
-        if (row0 + row < a.n_det) v = __uint_as_float((unsigned)(a.pm[(size_t)(row0 + row) * D_P + ff] >> 32));
-        sP[row * LD64 + ff] = v;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
+        *reinterpret_cast<float4*>(sQ + row * LD64 + 4 * c4) = vq[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
+        sP[row * LD64 + ff] = __uint_as_float((unsigned)(vpm[j] >> 32));
       }
       __syncthreads();
       // d W4 += q^T . dz : role cw owns output column tile cw
@@ -361,17 +415,17 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
         aW4a = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, aW4a, 0, 0, 0);
         aW4b = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, aW4b, 0, 0, 0);
       }
-      if (lt < D_S) gb4 += col_sum32(sDZ, LD128, lt);
+      if (tid < D_S) gb4 += col_sum32(sDZ, LD128, tid);
       // dq = (dz . W4^T) * (q > 0): role = (column tile, K half)
       {
         const int nt = cw & 1, kh = cw >> 1;
         f32x16 acc = zero16();
-        mma_abt<64>(acc, sDZ + 64 * kh, LD128, a.w4 + (size_t)(32 * nt) * D_S + 64 * kh, D_S, lane);
+        mma_abt_r<64>(acc, sDZ + 64 * kh, LD128, gW4, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
       }
       __syncthreads();
-      for (int i = lt; i < 32 * D_P; i += 256) {
+      for (int i = tid; i < 32 * D_P; i += 256) {
         const int row = i >> 6, ff = i & 63;
         const float v = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
         sDq[row * LD64 + ff] = sQ[row * LD64 + ff] > 0.f ? v : 0.f;
@@ -386,65 +440,45 @@ __global__ void __launch_bounds__(512) blk_bwd_node(const BlkNodeArgs a) {
           aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[row * LD64 + 32 * mi + col], sDq[row * LD64 + 32 * nj + col], aW3, 0, 0, 0);
         }
       }
-      if (lt < D_P) gb3 += col_sum32(sDq, LD64, lt);
-      // dp = dq . W3^T : role = (column tile, K half)
+      if (tid < D_P) gb3 += col_sum32(sDq, LD64, tid);
+      // dp = dq . W3^T : role = (column tile, K half); the partials of the dq step were consumed before the last barrier
       {
         const int nt = cw & 1, kh = cw >> 1;
         f32x16 acc = zero16();
-        mma_abt<32>(acc, sDq + 32 * kh, LD64, a.w3 + (size_t)(32 * nt) * D_P + 32 * kh, D_P, lane);
-        __syncthreads();   // sR of the dq step fully consumed
+        mma_abt_r<32>(acc, sDq + 32 * kh, LD64, gW3, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
       }
       __syncthreads();
-      for (int i = lt; i < 32 * D_P; i += 256) {
-        const int row = i >> 6, ff = i & 63;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
         if (row0 + row < a.n_det) {
-          const size_t o = (size_t)(row0 + row) * D_P + ff;
           const float dp = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
-          const unsigned cnt = (unsigned)(a.pm[o] & 0xffffffffull);
-          a.d_pc[o] = dp / (float)cnt;                     // weighted_grads = grad / num_selected
+          const unsigned cnt = (unsigned)(vpm[j] & 0xffffffffull);
+          a.d_pc[(size_t)(row0 + row) * D_P + ff] = dp / (float)cnt;                     // weighted_grads = grad / num_selected
         }
       }
     }
   }
-  // ---- partial weight gradients of this workgroup: row tile 1 is added to row tile 0 (fixed order), then stored
-  __syncthreads();
-  float* red = smem;                           // [96][256] accumulator registers of row tile 1 + [5][256] bias sums
-  if (rt == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      red[(r) * 256 + lt] = aWcn[r]; red[(16 + r) * 256 + lt] = aWr[r]; red[(32 + r) * 256 + lt] = aW4a[r];
-      red[(48 + r) * 256 + lt] = aW4b[r]; red[(64 + r) * 256 + lt] = aW3[r]; red[(80 + r) * 256 + lt] = aWrn[r];
+  // ---- partial weight gradients of this workgroup
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  if (a.do_pre) {
+    store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aWcn, lane);
+    store_acc(ar + a.o_wr + (size_t)(32 * cw) * D_R, D_R, aWr, lane);
+    if (tid < D_P) ar[a.o_b1 + tid] = gb1;
+    if (tid < D_R) ar[a.o_br + tid] = gbr;
+    if (NF) {
+      store_acc(ar + a.o_wrn + (size_t)(32 * cw) * D_R, D_R, aWrn, lane);
+      if (tid < D_R) ar[a.o_brn + tid] = gbrn;
     }
-    red[96 * 256 + lt] = gb1; red[97 * 256 + lt] = gbr; red[98 * 256 + lt] = gb4; red[99 * 256 + lt] = gb3; red[100 * 256 + lt] = gbrn;
   }
-  __syncthreads();
-  if (rt == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      aWcn[r] += red[(r) * 256 + lt]; aWr[r] += red[(16 + r) * 256 + lt]; aW4a[r] += red[(32 + r) * 256 + lt];
-      aW4b[r] += red[(48 + r) * 256 + lt]; aW3[r] += red[(64 + r) * 256 + lt]; aWrn[r] += red[(80 + r) * 256 + lt];
-    }
-    gb1 += red[96 * 256 + lt]; gbr += red[97 * 256 + lt]; gb4 += red[98 * 256 + lt]; gb3 += red[99 * 256 + lt]; gbrn += red[100 * 256 + lt];
-    float* ar = a.arena + (size_t)blockIdx.x * a.stride;
-    if (a.do_pre) {
-      store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aWcn, lane);
-      store_acc(ar + a.o_wr + (size_t)(32 * cw) * D_R, D_R, aWr, lane);
-      if (lt < D_P) ar[a.o_b1 + lt] = gb1;
-      if (lt < D_R) ar[a.o_br + lt] = gbr;
-      if (nf) {
-        store_acc(ar + a.o_wrn + (size_t)(32 * cw) * D_R, D_R, aWrn, lane);
-        if (lt < D_R) ar[a.o_brn + lt] = gbrn;
-      }
-    }
-    if (a.do_post) {
-      store_acc(ar + a.o_w4 + 32 * cw, D_S, aW4a, lane);
-      store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * cw, D_S, aW4b, lane);
-      store_acc(ar + a.o_w3 + (size_t)(32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aW3, lane);
-      if (lt < D_S) ar[a.o_b4 + lt] = gb4;
-      if (lt < D_P) ar[a.o_b3 + lt] = gb3;
-    }
+  if (a.do_post) {
+    store_acc(ar + a.o_w4 + 32 * cw, D_S, aW4a, lane);
+    store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * cw, D_S, aW4b, lane);
+    store_acc(ar + a.o_w3 + (size_t)(32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aW3, lane);
+    if (tid < D_S) ar[a.o_b4 + tid] = gb4;
+    if (tid < D_P) ar[a.o_b3 + tid] = gb3;
   }
 }
 
@@ -819,7 +853,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into the [E,64] fp32 arrays
   void* prof = buf->profiler;
   const long long stride = L.total;
-  const int g_node = min((N + 63) / 64, 256);                                           // node-kernel workgroups (64 detections each)
+  const int g_node = min((N + 31) / 32, 256);                                           // node-kernel workgroups (32-detection tiles, one workgroup per CU)
   const int g_head = min((N + 31) / 32, 256);
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? 512 : 0;                                                  // edge_bwd_w workgroups (two per CU)
@@ -848,7 +882,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     GNET_LAUNCH(prof, GNET_K_HEAD_BWD, s, head_bwd<<<g_head, 256, 0, s>>>(h));
   }
   // backward chain: node(post B) -> edge(B) -> node(pre B + post B-1) -> edge(B-1) -> ... -> node(pre 1)
-  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
   for (int b = B + 1; b >= 1; --b) {
     // node stage: pre of block b (b <= B), post of block b-1 (b >= 2)
     BlkNodeArgs n;
@@ -875,7 +910,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       n.o_w4 = K.w4; n.o_b4 = K.b4; n.o_w3 = K.w3; n.o_b3 = K.b3;
     } else { n.q = nullptr; n.pm = nullptr; n.w4 = n.w3 = nullptr; n.o_w4 = n.o_b4 = n.o_w3 = n.o_b3 = 0; }
     n.d_x = buf->d_x; n.d_pc = buf->d_pc; n.arena = buf->arena; n.stride = stride;
-    GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<<<g_node, 512, kBlkNodeSmem, s>>>(n));
+    if (cfg->neighbor_feats) { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<true><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
+    else { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<false><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
     // edge stage of block b-1
     if (b >= 2 && E > 0) {
       const int st = edge_stage_block(cfg, shape, L, params, b - 1, buf, g_edge, s);
