@@ -50,6 +50,13 @@ __device__ __forceinline__ float col_sum32(const float* s, int ld, int col) {
   return v;
 }
 
+__device__ __forceinline__ float col_sum8(const float* s, int ld, int col) {
+  float v = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v += s[r * ld + col];
+  return v;
+}
+
 // write one 32x32 accumulator tile (C layout) to a row-major destination
 __device__ __forceinline__ void store_acc(float* dst, int ld, const f32x16& acc, int lane) {
   const int col = lane & 31, half = lane >> 5;
@@ -253,7 +260,9 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
   float* sDrn = sRn;                         // [32][36]  drpre of the neighbour reduce FC, over d_rn once that is consumed
   float* sQ = sRc; float* sP = sRn; float* sDq = sRr; float* sR = sPart;
   f32x16 aWcn = zero16(), aWr = zero16(), aWrn = zero16(), aW4a = zero16(), aW4b = zero16(), aW3 = zero16();
-  float gb1 = 0.f, gbr = 0.f, gbrn = 0.f, gb4 = 0.f, gb3 = 0.f;
+  // bias gradients = column sums of the tiles: wave cw sums rows [8 cw, 8 cw + 8) of every tile, lane = column; the four
+  // waves are folded once, after the last tile
+  float gb1 = 0.f, gbr = 0.f, gbrn = 0.f, gb4 = 0.f, gb4b = 0.f, gb3 = 0.f;
   BtRegs<32> gW1, gWr, gWrn, gW3; BtRegs<64> gW4;
   if (a.do_pre) {
     load_bt<32>(gW1, a.w1 + (size_t)(32 + 32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane);   // role = (term, K half)
@@ -337,7 +346,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
           aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(X[row * LD32 + col], Y[row * LD64 + 32 * nj + col], aWcn, 0, 0, 0);
         }
       }
-      if (tid < D_P) gb1 += col_sum32(sRc, LD64, tid);
+      gb1 += col_sum8(sRc + 8 * cw * LD64, LD64, lane);
       __syncthreads();
       for (int i = tid; i < 32 * D_R; i += 256) {
         const int row = i >> 5, ff = i & 31;
@@ -361,14 +370,14 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         const int row = 2 * kk + half;
         aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDr[row * LD32 + col], aWr, 0, 0, 0);
       }
-      if (tid < D_R) gbr += col_sum32(sDr, LD32, tid);
+      gbr += col_sum8(sDr + 8 * cw * LD32, LD32, col);
       if (NF) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
           const int row = 2 * kk + half;
           aWrn = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDrn[row * LD32 + col], aWrn, 0, 0, 0);
         }
-        if (tid < D_R) gbrn += col_sum32(sDrn, LD32, tid);
+        gbrn += col_sum8(sDrn + 8 * cw * LD32, LD32, col);
       }
       if (a.do_post || a.want_dx0) {
         // d_x += drpre . Wr^T [+ drpre_n . Wrn^T] (columns [32 cw, 32 cw + 32))
@@ -415,7 +424,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         aW4a = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, aW4a, 0, 0, 0);
         aW4b = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, aW4b, 0, 0, 0);
       }
-      if (tid < D_S) gb4 += col_sum32(sDZ, LD128, tid);
+      gb4 += col_sum8(sDZ + 8 * cw * LD128, LD128, lane); gb4b += col_sum8(sDZ + 8 * cw * LD128, LD128, 64 + lane);
       // dq = (dz . W4^T) * (q > 0): role = (column tile, K half)
       {
         const int nt = cw & 1, kh = cw >> 1;
@@ -440,7 +449,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
           aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[row * LD64 + 32 * mi + col], sDq[row * LD64 + 32 * nj + col], aW3, 0, 0, 0);
         }
       }
-      if (tid < D_P) gb3 += col_sum32(sDq, LD64, tid);
+      gb3 += col_sum8(sDq + 8 * cw * LD64, LD64, lane);
       // dp = dq . W3^T : role = (column tile, K half); the partials of the dq step were consumed before the last barrier
       {
         const int nt = cw & 1, kh = cw >> 1;
@@ -463,22 +472,32 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
   }
   // ---- partial weight gradients of this workgroup
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+  __syncthreads();
+  float* sB = smem;                            // [4 waves][352]: b1 64 | br 32 | brn 32 | b4 128 | b3 64 | pad
+  sB[cw * 352 + lane] = gb1;
+  if (lane < 32) { sB[cw * 352 + 64 + lane] = gbr; sB[cw * 352 + 96 + lane] = gbrn; }
+  sB[cw * 352 + 128 + lane] = gb4; sB[cw * 352 + 192 + lane] = gb4b;
+  sB[cw * 352 + 256 + lane] = gb3;
+  __syncthreads();
+  for (int i = tid; i < 320; i += 256) {
+    const float v = (sB[i] + sB[352 + i]) + (sB[2 * 352 + i] + sB[3 * 352 + i]);
+    if (i < 64) { if (a.do_pre) ar[a.o_b1 + i] = v; }
+    else if (i < 96) { if (a.do_pre) ar[a.o_br + i - 64] = v; }
+    else if (i < 128) { if (a.do_pre && NF) ar[a.o_brn + i - 96] = v; }
+    else if (i < 256) { if (a.do_post) ar[a.o_b4 + i - 128] = v; }
+    else { if (a.do_post) ar[a.o_b3 + i - 256] = v; }
+  }
   if (a.do_pre) {
     store_acc(ar + a.o_w1 + (size_t)(32 + 32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aWcn, lane);
     store_acc(ar + a.o_wr + (size_t)(32 * cw) * D_R, D_R, aWr, lane);
-    if (tid < D_P) ar[a.o_b1 + tid] = gb1;
-    if (tid < D_R) ar[a.o_br + tid] = gbr;
     if (NF) {
       store_acc(ar + a.o_wrn + (size_t)(32 * cw) * D_R, D_R, aWrn, lane);
-      if (tid < D_R) ar[a.o_brn + tid] = gbrn;
     }
   }
   if (a.do_post) {
     store_acc(ar + a.o_w4 + 32 * cw, D_S, aW4a, lane);
     store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * cw, D_S, aW4b, lane);
     store_acc(ar + a.o_w3 + (size_t)(32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aW3, lane);
-    if (tid < D_S) ar[a.o_b4 + tid] = gb4;
-    if (tid < D_P) ar[a.o_b3 + tid] = gb3;
   }
 }
 
