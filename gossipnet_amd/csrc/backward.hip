@@ -239,6 +239,48 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   }
 }
 
+// Inputs of one 32-detection tile of blk_bwd_node, in registers (256 threads): x, d_x [32][128]; d_rc, d_rn, q [32][64];
+// r, r_n [32][32]; segment-max records [32][64].
+struct NodeTileIn { float4 vx[4], vz[4], vr, vrn, vc[2], vn[2]; };            // needed at the top of a tile: requested one tile ahead
+struct NodeTileMid { float4 vq[2]; unsigned long long vpm[8]; };              // needed from the post stage on: requested at the tile's top
+template <bool NF>
+__device__ __forceinline__ void load_node_tile(NodeTileIn& in, const BlkNodeArgs& a, int row0, int tid) {
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  in.vr = in.vrn = z4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+    const bool ok = row0 + row < a.n_det;
+    in.vx[j] = (a.x_prev && ok) ? ldg4_b(a.x_prev, (unsigned)(row0 + row) * (D_S * 4u) + 16u * c4) : z4;
+    in.vz[j] = ok ? ldg4_b(a.d_x, (unsigned)(row0 + row) * (D_S * 4u) + 16u * c4) : z4;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
+    const bool ok = row0 + row < a.n_det;
+    in.vc[j] = (a.do_pre && a.d_rc && ok) ? ldg4_b(a.d_rc, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
+    in.vn[j] = (a.do_pre && a.d_rc && ok) ? ldg4_b(a.d_rn, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
+  }
+  if (a.do_pre) {
+    const int row = tid >> 3, c4 = tid & 7;
+    const bool ok = row0 + row < a.n_det;
+    if (ok) in.vr = ldg4_b(a.r, (unsigned)(row0 + row) * (D_R * 4u) + 16u * c4);
+    if (NF && ok) in.vrn = ldg4_b(a.r_nb, (unsigned)(row0 + row) * (D_R * 4u) + 16u * c4);
+  }
+}
+__device__ __forceinline__ void load_node_mid(NodeTileMid& m, const BlkNodeArgs& a, int row0, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
+    m.vq[j] = (a.do_post && row0 + row < a.n_det) ? ldg4_b(a.q, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
+    m.vpm[j] = (a.do_post && row0 + row < a.n_det) ? a.pm[(size_t)(row0 + row) * D_P + ff] : 0ull;
+  }
+}
+
 // One workgroup (4 waves, one per SIMD: the whole register file is theirs) walks 32-detection tiles.  The stages of
 // a tile are a chain of small products separated by barriers, so nothing inside the chain may wait for memory:
 // the weight slices each wave multiplies by are loaded into registers once, before the first tile, and all seven
@@ -274,57 +316,32 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
     load_bt<32>(gW3, a.w3 + (size_t)(32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane);
   }
   const int ntiles = (a.n_det + 31) / 32;
+  NodeTileIn in;
+  if ((int)blockIdx.x < ntiles) load_node_tile<NF>(in, a, blockIdx.x * 32, tid);
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int row0 = t * 32;                    // first detection of this tile
-    // ---- every input of the tile, requested together
-    float4 vx[4], vz[4], vr, vrn, vc[2], vn[2], vq[2];
-    unsigned long long vpm[8];
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    vr = vrn = z4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
-      const bool ok = row0 + row < a.n_det;
-      vx[j] = (a.x_prev && ok) ? ldg4_b(a.x_prev, (unsigned)(row0 + row) * (D_S * 4u) + 16u * c4) : z4;
-      vz[j] = ok ? ldg4_b(a.d_x, (unsigned)(row0 + row) * (D_S * 4u) + 16u * c4) : z4;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
-      const bool ok = row0 + row < a.n_det;
-      vc[j] = (a.do_pre && a.d_rc && ok) ? ldg4_b(a.d_rc, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
-      vn[j] = (a.do_pre && a.d_rc && ok) ? ldg4_b(a.d_rn, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
-      vq[j] = (a.do_post && ok) ? ldg4_b(a.q, (unsigned)(row0 + row) * (D_P * 4u) + 16u * c4) : z4;
-    }
-    if (a.do_pre) {
-      const int row = tid >> 3, c4 = tid & 7;
-      const bool ok = row0 + row < a.n_det;
-      if (ok) vr = ldg4_b(a.r, (unsigned)(row0 + row) * (D_R * 4u) + 16u * c4);
-      if (NF && ok) vrn = ldg4_b(a.r_nb, (unsigned)(row0 + row) * (D_R * 4u) + 16u * c4);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
-      vpm[j] = (a.do_post && row0 + row < a.n_det) ? a.pm[(size_t)(row0 + row) * D_P + ff] : 0ull;
-    }
+    NodeTileMid mid;
+    load_node_mid(mid, a, row0, tid);
     __syncthreads();                              // the previous tile's readers are done
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
-      *reinterpret_cast<float4*>(sX + row * LD128 + 4 * c4) = vx[j];
-      *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = vz[j];
+      *reinterpret_cast<float4*>(sX + row * LD128 + 4 * c4) = in.vx[j];
+      *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = in.vz[j];
     }
     if (a.do_pre) {
       { const int row = tid >> 3, c4 = tid & 7;
-        *reinterpret_cast<float4*>(sRr + row * LD32 + 4 * c4) = vr;
-        if (NF) *reinterpret_cast<float4*>(sRrn + row * LD32 + 4 * c4) = vrn; }
+        *reinterpret_cast<float4*>(sRr + row * LD32 + 4 * c4) = in.vr;
+        if (NF) *reinterpret_cast<float4*>(sRrn + row * LD32 + 4 * c4) = in.vrn; }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
-        *reinterpret_cast<float4*>(sRc + row * LD64 + 4 * c4) = vc[j];
-        *reinterpret_cast<float4*>(sRn + row * LD64 + 4 * c4) = vn[j];
+        *reinterpret_cast<float4*>(sRc + row * LD64 + 4 * c4) = in.vc[j];
+        *reinterpret_cast<float4*>(sRn + row * LD64 + 4 * c4) = in.vn[j];
       }
     }
+    // the next tile of this workgroup is requested now and lands while this one is computed
+    if (t + (int)gridDim.x < ntiles) load_node_tile<NF>(in, a, (t + gridDim.x) * 32, tid);
     __syncthreads();
     if (a.do_pre) {
       // dr = drc . Wc^T + drn . Wn^T : role = (term, K half)
@@ -407,12 +424,12 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
-        *reinterpret_cast<float4*>(sQ + row * LD64 + 4 * c4) = vq[j];
+        *reinterpret_cast<float4*>(sQ + row * LD64 + 4 * c4) = mid.vq[j];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
-        sP[row * LD64 + ff] = __uint_as_float((unsigned)(vpm[j] >> 32));
+        sP[row * LD64 + ff] = __uint_as_float((unsigned)(mid.vpm[j] >> 32));
       }
       __syncthreads();
       // d W4 += q^T . dz : role cw owns output column tile cw
@@ -464,7 +481,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
         if (row0 + row < a.n_det) {
           const float dp = sR[row * D_P + ff] + sR[(32 + row) * D_P + ff];
-          const unsigned cnt = (unsigned)(vpm[j] & 0xffffffffull);
+          const unsigned cnt = (unsigned)(mid.vpm[j] & 0xffffffffull);
           a.d_pc[(size_t)(row0 + row) * D_P + ff] = dp / (float)cnt;                     // weighted_grads = grad / num_selected
         }
       }
