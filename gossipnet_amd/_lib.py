@@ -56,7 +56,7 @@ class gnet_buffers(C.Structure):
 
 
 EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_graph_transpose", "gnet_workspace_bytes", "gnet_plan",
-           "gnet_forward", "gnet_loss", "gnet_match_prepare", "gnet_backward", "det_matching_workspace_bytes", "det_matching_f32",
+           "gnet_forward", "gnet_loss", "gnet_match_prepare", "gnet_backward", "gnet_backward_prepare", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
            "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
            "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou"]
@@ -113,7 +113,9 @@ def load():
     lib.gnet_match_prepare.restype = C.c_int
     lib.gnet_match_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), P(gnet_buffers), vp]
     lib.gnet_backward.restype = C.c_int
-    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, vp]
+    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, C.c_int32, vp]
+    lib.gnet_backward_prepare.restype = C.c_int
+    lib.gnet_backward_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp]
     lib.det_matching_workspace_bytes.restype = sz
     lib.det_matching_workspace_bytes.argtypes = [i32, i32]
     lib.det_matching_f32.restype = C.c_int

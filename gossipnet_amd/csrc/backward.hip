@@ -870,8 +870,25 @@ __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+extern "C" int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                                     const float* params, gnet_buffers* buf, gnet_stream_t stream) {
+  clear_hip_error();
+  if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
+  if (!shape || !in || !params || !buf) return GNET_ERR_INVALID;
+  if (!buf->d_pw || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows) return GNET_ERR_INVALID;   // plan(training >= 1)
+  const int E = (int)shape->n_edge;
+  if (shape->n_det == 0 || E == 0) return GNET_OK;
+  if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  // the edge stages accumulate into d_pw (winner rows only)
+  HIP_CHECK_RET(hipMemsetAsync(buf->d_pw, 0, (size_t)E * D_E * sizeof(float), s));
+  // winner maps / lists of ALL blocks (they depend on the forward pass only: off the backward chain)
+  return edge_stage_prepare(cfg, shape, make_layout(cfg), params, buf, s);
+}
+
 extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-                             const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream) {
+                             const float* params, gnet_buffers* buf, float* grads, int32_t prepared,
+                             gnet_stream_t stream) {
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
@@ -902,11 +919,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
   { const int st = edge_stage_set_attributes(); if (st != GNET_OK) return st; }
 
-  if (E > 0) {
-    // the edge stages accumulate into d_pw (winner rows only)
-    HIP_CHECK_RET(hipMemsetAsync(buf->d_pw, 0, (size_t)E * D_E * sizeof(float), s));
-    // winner maps / lists of ALL blocks (they depend on the forward pass only: off the backward chain)
-    const int st = edge_stage_prepare(cfg, shape, L, params, buf, s);
+  if (E > 0 && !prepared) {
+    const int st = gnet_backward_prepare(cfg, shape, in, params, buf, stream);
     if (st != GNET_OK) return st;
   }
   {

@@ -353,8 +353,6 @@ class Gnet(object):
         self._rp_free[k].record(torch.cuda.current_stream(self.device))
         _lib.check(lib.gnet_graph_fill(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr, buf.edge_c,
                                        buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
-        if training and E > 0:
-            _lib.check(lib.gnet_graph_transpose(buf.row_ptr, buf.edge_c, buf.edge_n, E, buf.edge_t, s), "gnet_graph_transpose")
         self.num_edges = E
         return shape, buf
 
@@ -368,9 +366,28 @@ class Gnet(object):
         self._plan_done.record(main)
         self._side.wait_event(self._plan_done)
         with torch.cuda.stream(self._side):
-            _lib.check(self._lib.gnet_match_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), C.byref(buf),
-                                                    C.c_void_p(self._side.cuda_stream)), "gnet_match_prepare")
+            ss = C.c_void_p(self._side.cuda_stream)
+            _lib.check(self._lib.gnet_match_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), C.byref(buf), ss),
+                       "gnet_match_prepare")
             self._prep_done.record(self._side)
+            if shape.n_edge > 0:
+                # the reverse-edge permutation is read by the backward pass only (which waits for `_bprep_done`,
+                # recorded later on this stream)
+                _lib.check(self._lib.gnet_graph_transpose(buf.row_ptr, buf.edge_c, buf.edge_n, shape.n_edge, buf.edge_t, ss),
+                           "gnet_graph_transpose")
+
+    def _prepare_backward(self, shape, inp, buf):
+        """The SegmentMax winner maps / row lists of all blocks depend on the forward pass only: they are built on the
+        side stream while the main stream runs the matching, the loss and the head's backward."""
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_bprep_done", None) is None:
+            self._fwd_done, self._bprep_done = torch.cuda.Event(), torch.cuda.Event()
+        self._fwd_done.record(main)
+        self._side.wait_event(self._fwd_done)
+        with torch.cuda.stream(self._side):
+            _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
+                                                       C.byref(buf), C.c_void_p(self._side.cuda_stream)), "gnet_backward_prepare")
+            self._bprep_done.record(self._side)
 
     def _mode(self, training):
         """`training` argument of the C ABI: 0 inference, 1 training, 2 training + per-block pw_fc1 activations kept."""
@@ -412,13 +429,16 @@ class Gnet(object):
             self._prepare_matching(shape, inp, buf)
         _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                     C.byref(buf), self._mode(training), s), "gnet_forward")
+        if training and backward:
+            self._prepare_backward(shape, inp, buf)
         if training:
             torch.cuda.current_stream(self.device).wait_event(self._prep_done)
             _lib.check(lib.gnet_loss(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.class_weights),
                                      float(self.grad_scale), C.byref(buf), 1, s), "gnet_loss")
             if backward:
+                torch.cuda.current_stream(self.device).wait_event(self._bprep_done)
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
-                                             C.byref(buf), _vp(self.grads), s), "gnet_backward")
+                                             C.byref(buf), _vp(self.grads), 1, s), "gnet_backward")
                 if self._imfeats:
                     self._imfeat_backward(db)
                 if self.weight_reg:

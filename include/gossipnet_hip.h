@@ -208,7 +208,14 @@ int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shape, const gn
  * dense algorithm minus exact zeros.
  * Limits: n_edge <= 2^24 - 128 (32-bit byte offsets into [E,64] fp32 arrays; GNET_ERR_UNSUPPORTED beyond). */
 int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-                  const float* params, gnet_buffers* buf, float* grads, gnet_stream_t stream);
+                  const float* params, gnet_buffers* buf, float* grads, int32_t prepared, gnet_stream_t stream);
+
+/* The part of gnet_backward that depends on the forward pass only, not on the loss: the SegmentMax winner maps and
+ * row lists of every block, and the zeroed d_pw accumulator.  A caller may run it on another stream once
+ * gnet_forward has finished, beside gnet_loss, and pass prepared = 1 to gnet_backward (after ordering the two
+ * streams).  With prepared = 0 gnet_backward does this work itself. */
+int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
+                          const float* params, gnet_buffers* buf, gnet_stream_t stream);
 
 /* ---- training step around the path (train.py:64-77: slim create_train_op with Adam / Momentum) --------
  * All buffers are flat fp32 of n = gnet_param_count elements (device).  grad_scale multiplies the
