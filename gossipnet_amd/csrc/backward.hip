@@ -840,13 +840,15 @@ struct ReduceArgs {
   float* grads;
 };
 
-// 64 parameters x 4 partial groups per workgroup: group g adds the copies g, g + 4, ... (four independent load
-// streams per parameter instead of one dependent chain), the groups are folded in a fixed order.
+// 256 parameters x 4 partial groups per workgroup: a lane owns four consecutive parameters (one 16-byte load per
+// copy; the class boundaries and the arena stride are multiples of 4, so the four share their copy count), group g
+// adds the copies g, g + 4, ... (four independent load streams per parameter instead of one dependent chain), the
+// groups are folded in a fixed order.  The tail of the parameter vector (its length is odd) is handled per element.
 __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
-  __shared__ float part[4][64];
+  __shared__ float4 part[4][64];
   const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long long p = (long long)blockIdx.x * 64 + px;
-  float v = 0.f;
+  const long long p = ((long long)blockIdx.x * 64 + px) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p < a.total) {
     int n;
     if (p < a.w1c_end) n = a.n_w1c;
@@ -859,12 +861,33 @@ __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
       const bool edge = (q >= w1 && q < w1 + D_E * D_P) || (q >= w2 && q < w2 + D_P * D_P + D_P);
       n = edge ? a.n_edge : a.n_node;
     } else n = a.n_head;
+    // the arena rows are padded to the stride: the 16-byte load of the last, partial group stays inside its row
     const float* src = a.arena + p;
-    for (int k = g; k < n; k += 4) v += src[(size_t)k * a.stride];
+    int k = g;
+    for (; k + 12 < n; k += 16) {
+      const float4 x0 = *reinterpret_cast<const float4*>(src + (size_t)k * a.stride);
+      const float4 x1 = *reinterpret_cast<const float4*>(src + (size_t)(k + 4) * a.stride);
+      const float4 x2 = *reinterpret_cast<const float4*>(src + (size_t)(k + 8) * a.stride);
+      const float4 x3 = *reinterpret_cast<const float4*>(src + (size_t)(k + 12) * a.stride);
+      v.x += x0.x; v.y += x0.y; v.z += x0.z; v.w += x0.w;
+      v.x += x1.x; v.y += x1.y; v.z += x1.z; v.w += x1.w;
+      v.x += x2.x; v.y += x2.y; v.z += x2.z; v.w += x2.w;
+      v.x += x3.x; v.y += x3.y; v.z += x3.z; v.w += x3.w;
+    }
+    for (; k < n; k += 4) {
+      const float4 x0 = *reinterpret_cast<const float4*>(src + (size_t)k * a.stride);
+      v.x += x0.x; v.y += x0.y; v.z += x0.z; v.w += x0.w;
+    }
   }
   part[g][px] = v;
   __syncthreads();
-  if (g == 0 && p < a.total) a.grads[p] = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
+  if (g == 0 && p < a.total) {
+    const float4 p0 = part[0][px], p1 = part[1][px], p2 = part[2][px], p3 = part[3][px];
+    const float4 r = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                                 (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+    if (p + 3 < a.total) *reinterpret_cast<float4*>(a.grads + p) = r;
+    else { a.grads[p] = r.x; if (p + 1 < a.total) a.grads[p + 1] = r.y; if (p + 2 < a.total) a.grads[p + 2] = r.z; }
+  }
 }
 
 }  // namespace
@@ -902,15 +925,15 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     HIP_CHECK_RET(hipMemsetAsync(grads, 0, (size_t)L.total * sizeof(float), s));
     return GNET_OK;
   }
-  if ((size_t)GNET_ARENA_PARTIALS * (size_t)L.total > buf->arena_floats) return GNET_ERR_WORKSPACE;
+  if ((size_t)GNET_ARENA_PARTIALS * (size_t)arena_stride(L.total) > buf->arena_floats) return GNET_ERR_WORKSPACE;
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into the [E,64] fp32 arrays
   void* prof = buf->profiler;
-  const long long stride = L.total;
+  const long long stride = arena_stride(L.total);
   const int g_node = min((N + 31) / 32, 256);                                           // node-kernel workgroups (32-detection tiles, one workgroup per CU)
   const int g_head = min((N + 31) / 32, 256);
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? 512 : 0;                                                  // edge_bwd_w workgroups (two per CU)
-  const int g_pw = E > 0 ? min(etiles, GNET_ARENA_PARTIALS) : 0;
+  const int g_pw = E > 0 ? min(etiles, 256) : 0;                                       // pw_bwd_main: one workgroup per CU, looping over its tiles
   const int g_w1 = E > 0 ? max(1, min(GNET_ARENA_PARTIALS, (N + 3) / 4)) : 0;          // node-sum workgroups
   const int g_w1c = E > 0 ? max(1, min(128, 256 / (2 * L.cprime))) : 0;               // node chunks per class row
   const EdgeGeom G = edge_geom(E, N);
@@ -995,7 +1018,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     r.nblocks = B;
     r.n_w1c = g_w1c; r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_head;
     r.grads = grads;
-    GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 63) / 64), 256, 0, s>>>(r));
+    GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 255) / 256), 256, 0, s>>>(r));
   }
   return launch_status();
 }

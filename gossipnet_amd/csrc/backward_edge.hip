@@ -781,7 +781,7 @@ int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const Para
   e.pw = buf->pw_feats; e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b]; e.d_pc = buf->d_pc;
   e.w1t = pt + K.w1; e.w2 = params + K.w2;
   e.d_pw = buf->d_pw; e.g1c = buf->d_g1;
-  e.arena = buf->arena; e.stride = L.total; e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
+  e.arena = buf->arena; e.stride = arena_stride(L.total); e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
   GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_w<<<n_partials, 64 * EBW_WAVES, kEdgeBwdWSmem, s>>>(e));
   return GNET_OK;
 }

@@ -13,6 +13,8 @@ constexpr int D_E = 32;    // pwfeat_narrow_dim
 constexpr int D_HEAD = 128;
 // partial weight-gradient copies per parameter (upper bound on writer workgroups per kernel)
 constexpr int GNET_ARENA_PARTIALS = 512;
+// row stride of the partial-gradient arena: the parameter count rounded up to 64 floats (16-byte loads in reduce_partials)
+__host__ __device__ inline long long arena_stride(long long total) { return (total + 63) & ~63ll; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -22,7 +22,7 @@ size_t arena_floats(const gnet_config* cfg, const gnet_shape* sh) {
   const ParamLayout L = make_layout(cfg);
   (void)sh;
   // every backward kernel writes at most kMaxPartials partial copies of the parameters it owns
-  return (size_t)GNET_ARENA_PARTIALS * (size_t)L.total;
+  return (size_t)GNET_ARENA_PARTIALS * (size_t)arena_stride(L.total);
 }
 
 size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* ws, gnet_buffers* out) {
