@@ -50,6 +50,40 @@ def test_matching_random_vs_oracle(n, m, seed):
         assert np.array_equal(r, g)
 
 
+@pytest.mark.parametrize("pattern", ["chain", "two_gts", "ladder3", "crowd_mix", "dup_iou"])
+def test_matching_dependency_patterns_vs_oracle(pattern):
+    """Inputs built to stress the batch-parallel resolution of match_greedy: long chains of detections whose
+    second choice is the next one's first, everybody after the same GTs, >2 candidates whose best two are taken."""
+    rng = np.random.default_rng(11)
+    n, m = 700, 160
+    iou = np.zeros((n, m), np.float32)
+    ign = np.zeros(m, bool)
+    if pattern == "chain":
+        for i in range(n):                      # first choice g, second choice g + 1: each decision feeds the next
+            g = (i // 3) % (m - 1)
+            iou[i, g] = 0.9 - 0.0001 * (i % 3); iou[i, g + 1] = 0.6
+    elif pattern == "two_gts":
+        iou[:, 0] = rng.uniform(0.5, 1, n); iou[:, 1] = rng.uniform(0.5, 1, n)
+    elif pattern == "ladder3":
+        for i in range(n):                      # three or four candidates in a sliding window
+            g = (i // 5) % (m - 4)
+            iou[i, g:g + 4] = np.sort(rng.uniform(0.5, 1, 4))[::-1]
+            if i % 2: iou[i, g + 3] = 0.0
+    elif pattern == "crowd_mix":
+        ign[::3] = True
+        iou[:] = rng.uniform(0, 1, (n, m)); iou[rng.uniform(size=(n, m)) < 0.9] = 0
+        iou[:, :6] = rng.uniform(0.45, 1, (n, 6))
+    else:                                       # equal IoUs: the later GT index wins (det_matching.cc:142-148)
+        for i in range(n):
+            g = (i // 4) % (m - 3)
+            iou[i, g:g + 3] = 0.75
+    score = rng.permutation(n).astype(np.float32)
+    ref = native.det_matching(iou, score, ign)
+    got = _match(iou, score, ign)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g)
+
+
 def test_matching_score_ties_follow_documented_rule():
     # equal scores: higher index first (stable ascending sort reversed, det_matching.cc:95-96)
     iou = np.array([[.9], [.9], [.9]], np.float32)
