@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
     if (tid < D_HEAD) gb2 += col_sum32(sD2, LD128, tid);
     {
       f32x16 acc = zero16();                                                // d head1 = d head2 . W2^T
-      mma_abt<D_HEAD>(acc, sD2, LD128, a.hw2 + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
+      mma_abt_gB<D_HEAD, 8>(acc, sD2, LD128, a.hw2 + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);   // weight loads 8 k-steps ahead
 #pragma unroll
       for (int r = 0; r < 16; ++r) sD1[crow(r, half) * LD128 + 32 * wave + col] = acc[r];
     }
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
     if (tid < D_HEAD) gb1 += col_sum32(sD1, LD128, tid);
     {
       f32x16 acc = zero16();                                                // d x = d head1 . W1^T
-      mma_abt<D_HEAD>(acc, sD1, LD128, a.hw1 + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
+      mma_abt_gB<D_HEAD, 8>(acc, sD1, LD128, a.hw1 + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int node = row0 + crow(r, half);
@@ -812,12 +812,29 @@ __global__ void __launch_bounds__(256) pw_w1_classrows(const PwW1Args a) {
     const bool member = valid && (!a.multiclass || a.classes[i] - 1 == k);
     unsigned long long mask = __ballot(member);
     while (mask) {
-      const int j = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const float s = __shfl(sc, j);
-      const float* row = src + (size_t)(base + j) * D_H + lane;
+      // four member rows in flight (ascending index order; a missing slot re-reads the last row and is skipped)
+      int j[4]; float s[4]; bool hv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = fmaf(s, row[64 * q], acc[q]);
+      for (int u = 0; u < 4; ++u) {
+        hv[u] = mask != 0ull;                               // wave-uniform
+        j[u] = hv[u] ? __builtin_ctzll(mask) : (u ? j[u - 1] : 0);
+        if (hv[u]) mask &= mask - 1;
+        s[u] = __shfl(sc, j[u]);
+      }
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* row = src + (size_t)(base + j[u]) * D_H + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = row[64 * q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (hv[u]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = fmaf(s[u], v[u][q], acc[q]);
+        }
+      }
     }
   }
 #pragma unroll

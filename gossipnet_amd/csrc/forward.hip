@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   if (a.do_head) {
     __syncthreads();
     f32x16 acc = zero16();
-    mma_abt<D_S>(acc, sX, N_LD, a.hw1t + (size_t)(32 * wave) * D_S, D_S, lane);
+    mma_abt_gB<D_S, 8>(acc, sX, N_LD, a.hw1t + (size_t)(32 * wave) * D_S, D_S, lane);            // weight loads 8 k-steps ahead
     {
       const float bb = a.hb1[32 * wave + col];
 #pragma unroll
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     }
     __syncthreads();
     acc = zero16();
-    mma_abt<D_HEAD>(acc, sY, N_LD, a.hw2t + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
+    mma_abt_gB<D_HEAD, 8>(acc, sY, N_LD, a.hw2t + (size_t)(32 * wave) * D_HEAD, D_HEAD, lane);
     __syncthreads();
     {
       const float bb = a.hb2[32 * wave + col];

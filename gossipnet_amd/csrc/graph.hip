@@ -35,6 +35,10 @@ __global__ void __launch_bounds__(256) graph_sweep(const float4* __restrict__ de
                                                    int* __restrict__ edge_c, int* __restrict__ edge_n,
                                                    float* __restrict__ edge_iou) {
   __shared__ float sx1[kColTile], sy1[kColTile], sx2[kColTile], sy2[kColTile], sar[kColTile];
+  // FILL: the hits of a row (a few per 64-column group) collect in a 128-entry LDS ring and leave as whole
+  // 64-entry groups -- one full-wave store per array instead of one store instruction per group with hits
+  __shared__ int rng_n[FILL ? kRowsPerBlock * 128 : 1];
+  __shared__ float rng_v[FILL ? kRowsPerBlock * 128 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int brow0 = blockIdx.x * kRowsPerBlock;
   const int brow1 = min(n, brow0 + kRowsPerBlock) - 1;
@@ -43,7 +47,7 @@ __global__ void __launch_bounds__(256) graph_sweep(const float4* __restrict__ de
   const int cmax = det_off[image_of(det_off, n_img, brow1) + 1];
 
   float ax1[kRowsPerWave], ay1[kRowsPerWave], ax2[kRowsPerWave], ay2[kRowsPerWave], aar[kRowsPerWave];
-  int lo[kRowsPerWave], hi[kRowsPerWave], pos[kRowsPerWave];
+  int lo[kRowsPerWave], hi[kRowsPerWave], pos[kRowsPerWave], base[kRowsPerWave], flushed[kRowsPerWave];
 #pragma unroll
   for (int q = 0; q < kRowsPerWave; ++q) {
     const int row = brow0 + wave * kRowsPerWave + q;
@@ -53,10 +57,10 @@ __global__ void __launch_bounds__(256) graph_sweep(const float4* __restrict__ de
       aar[q] = (b.z - b.x) * (b.w - b.y);           // network.py:468-471
       const int img = image_of(det_off, n_img, row);
       lo[q] = det_off[img]; hi[q] = det_off[img + 1];
-      pos[q] = FILL ? row_ptr[row] : 0;
+      base[q] = FILL ? row_ptr[row] : 0; pos[q] = 0; flushed[q] = 0;
     } else {
       ax1[q] = ay1[q] = ax2[q] = ay2[q] = aar[q] = 0.f;
-      lo[q] = hi[q] = 0; pos[q] = 0;
+      lo[q] = hi[q] = 0; pos[q] = 0; base[q] = 0; flushed[q] = 0;
     }
   }
 
@@ -90,14 +94,38 @@ __global__ void __launch_bounds__(256) graph_sweep(const float4* __restrict__ de
         const bool pred = inrange && (iou >= thr);   // network.py:192-193
         const unsigned long long mask = __ballot(pred);
         if (FILL) {
+          const int slot = (wave * kRowsPerWave + q) * 128;
           if (pred) {
             const int p = pos[q] + __popcll(mask & ((1ull << lane) - 1ull));
-            edge_c[p] = brow0 + wave * kRowsPerWave + q;
-            edge_n[p] = j;
-            edge_iou[p] = iou;
+            rng_n[slot + (p & 127)] = j;
+            rng_v[slot + (p & 127)] = iou;
           }
+          pos[q] += __popcll(mask);
+          if (pos[q] - flushed[q] >= 64) {                 // wave-uniform
+            wave_lds_sync();
+            const int k = flushed[q] + lane;
+            edge_c[base[q] + k] = brow0 + wave * kRowsPerWave + q;
+            edge_n[base[q] + k] = rng_n[slot + (k & 127)];
+            edge_iou[base[q] + k] = rng_v[slot + (k & 127)];
+            flushed[q] += 64;
+            wave_lds_sync();                               // the ring entries are rewritten by later groups
+          }
+        } else {
+          pos[q] += __popcll(mask);
         }
-        pos[q] += __popcll(mask);
+      }
+    }
+  }
+  if (FILL) {
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const int slot = (wave * kRowsPerWave + q) * 128;
+      const int k = flushed[q] + lane;
+      if (k < pos[q]) {
+        edge_c[base[q] + k] = brow0 + wave * kRowsPerWave + q;
+        edge_n[base[q] + k] = rng_n[slot + (k & 127)];
+        edge_iou[base[q] + k] = rng_v[slot + (k & 127)];
       }
     }
   }
