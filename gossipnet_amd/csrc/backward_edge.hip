@@ -366,12 +366,6 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   int* sE = reinterpret_cast<int*>(sH + 32 * LD64);        // [32] edge of every tile row
   int* sRJ = sE + 32;                          // [slots][64] tile row of column j's winner (-1: not in this tile)
   float* sDV = reinterpret_cast<float*>(sRJ + EBW_SLOTS * 64);   // [slots][64] d_pc[c][j]
-  for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) {
-    const float v = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];          // W1[pf = i & 31][f = i >> 5]
-    sWpT[(i >> 5) * LD32 + (i & 31)] = v;
-  }
-  for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
-  __syncthreads();
   const int col = lane & 31, half = lane >> 5;
   float w2acc[D_P];                            // lane j: d W2[f][j], f = register index
 #pragma unroll
@@ -416,12 +410,20 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     apB = a.apos[ob_]; dvB = a.d_pc[ob_]; tfB = a.tflag[max(cB_, 0)];                                   \
     apC = a.apos[oc_]; dvC = a.d_pc[oc_]; tfC = a.tflag[max(cC_, 0)];                                   \
   } while (0)
+  // the first tile's chain of dependent requests (list -> rows -> column records) runs beside the staging of the
+  // weights, not after it
   if (t0 < t1) {
     EBW_LOAD_LIST(t0);
     EBW_LOAD_ROWS(t0);
     if (t0 + 1 < t1) EBW_LOAD_LIST(t0 + 1);
-    EBW_LOAD_BIAS();
   }
+  for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) {
+    const float v = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];          // W1[pf = i & 31][f = i >> 5]
+    sWpT[(i >> 5) * LD32 + (i & 31)] = v;
+  }
+  for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
+  if (t0 < t1) EBW_LOAD_BIAS();
+  __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int p0 = t * 32;
     const int nrows = min(32, W - p0);

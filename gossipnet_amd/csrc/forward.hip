@@ -318,9 +318,6 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T[j][f]
   float* sHw = sW2 + D_P * E_LD2;              // per wave: rc rows of the tile's first two centres [2][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < D_P * D_E; i += 64 * EFW_WAVES) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
-  for (int i = tid; i < D_P * D_P; i += 64 * EFW_WAVES) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
-  __syncthreads();
   const int col = lane & 31, half = lane >> 5;
   const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
   const int ntiles = (a.n_edge + 31) / 32;
@@ -333,6 +330,20 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   const int gw = lb * EFW_WAVES + wave;
   const int t0 = gw * per, t1 = min(ntiles, t0 + per);
   float* sRC = sHw + wave * (2 * D_P);
+  // the first tile's records (edge -> centre / neighbour row -> rn / rc rows: three dependent round trips) are
+  // requested BEFORE the weights are staged, so that the chain runs beside the staging instead of after it
+  int nx_c = -1, nx_nz = 0;
+  f32x4 pa[4];
+  if (t0 < t1) {
+    { const int e = t0 * 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
+    const float* ap = a.pw + (size_t)min(t0 * 32 + col, a.n_edge - 1) * D_E + 4 * half;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+    nx_nz = a.edge_nz[t0 * 32 + col];                                  // (the tail of edge_nz is padded)
+  }
+  for (int i = tid; i < D_P * D_E; i += 64 * EFW_WAVES) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
+  for (int i = tid; i < D_P * D_P; i += 64 * EFW_WAVES) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
+  __syncthreads();
   if (t0 >= t1) return;
   const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
   // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
@@ -348,15 +359,6 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   //     edge_nz (index of a zero row of rn): no clamps, no (c != n) selects;
   //   * the segment maximum is taken on h2 + b2 and rectified once per segment, not per element.
   // ---- prefetch state for the first tile (lane = edge e0 + col, both half-waves alike)
-  int nx_c = -1;
-  { const int e = t0 * 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
-  f32x4 pa[4];
-  {
-    const float* ap = a.pw + (size_t)min(t0 * 32 + col, a.n_edge - 1) * D_E + 4 * half;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
-  }
-  int nx_nz = a.edge_nz[t0 * 32 + col];                                // (the tail of edge_nz is padded)
   float4 rnv[8];                                                       // rn[n][8 g + 4 half .. + 3]
 #pragma unroll
   for (int g = 0; g < 8; ++g) rnv[g] = ldg4_b(a.rn, (unsigned)nx_nz * (D_P * 4u) + 32u * g + 16u * half);
