@@ -310,6 +310,32 @@ def test_gradients_bitwise_reproducible():
         assert torch.equal(g, runs[0][0]) and torch.equal(p, runs[0][1]) and torch.equal(l, runs[0][2])
 
 
+def test_alternating_batches_without_host_syncs_match_isolated_runs():
+    """A step uses two streams (neighbour count, matching candidates, reverse-edge permutation and winner lists on
+    the side stream) and recycles one workspace: steps of different shapes issued back to back, with no host
+    synchronisation between them, must give bit for bit what each batch gives on a fresh network."""
+    from gossipnet_amd.network import Gnet
+    net, _ = make_pair(80, 4)
+    batches = [[make_image(700, 80, seed=31), make_image(90, 80, seed=32)],
+               [make_image(260, 80, seed=33)],
+               [make_image(40, 80, seed=34), make_image(900, 80, seed=35), make_image(300, 80, seed=36)]]
+    want = []
+    for b in batches:
+        ref = Gnet(80)
+        ref.params.copy_(net.params)
+        ref.run(b)
+        torch.cuda.synchronize()
+        want.append((ref.grads.clone(), ref.prediction.clone(), ref.det_gt_matching.clone()))
+        del ref
+    got = []
+    for i in [0, 1, 2, 1, 0, 2, 2, 0]:
+        net.run(batches[i])                       # no synchronize: the next step's launches queue behind this one
+        got.append((i, net.grads.clone(), net.prediction.clone(), net.det_gt_matching.clone()))
+    torch.cuda.synchronize()
+    for i, g, p, m in got:
+        assert torch.equal(g, want[i][0]) and torch.equal(p, want[i][1]) and torch.equal(m, want[i][2]), i
+
+
 @pytest.mark.parametrize("imfeat_dim", [-1, 64])
 def test_imfeats_start_features(imfeat_dim):
     """Image-feature variant (network.py:223-240): block_feats[0] = reduce_imfeats(flatten(crop_windows(imfeats, dets)))
