@@ -297,6 +297,12 @@ struct EdgeFwdArgs {
 // the centre's edges lie inside this wave's edge range (no other wave touches it), by the exact atomic
 // combine only for the (at most two) centres that straddle the range.  No loads or returning atomics sit
 // in divergent code, so the in-order vmcnt never drains the prefetches early.
+// b = 2 b + (h == s): one compare and one add-with-carry.  (Written as C the compiler assembles the 16 hit bits
+// with a select, a shift and an or per element; the carry form is pinned here.)
+__device__ __forceinline__ void hit_bit(unsigned& b, float h, float s) {
+  asm volatile("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(b) : "v"(h), "v"(s) : "vcc");
+}
+
 // branch-free (selects only): divergent control flow costs far more than the few extra VALU ops
 __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, unsigned k2) {
   const bool gt = m2 > m, eq = m2 == m;
@@ -502,8 +508,11 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       hleft &= hleft - 1;
       const int hi = hleft ? __builtin_ctz(hleft) : nrows;
       const int cseg = __builtin_amdgcn_readlane(my_c, lo);
-      float s0, s1; unsigned q0 = 0, q1 = 0;
-      int a0 = 16, a1 = 16;                             // accumulator slot of the first row attaining the maximum
+      float s0, s1;
+      // hits of this lane's rows, one bit per accumulator slot (bit r = slot r attains the segment maximum): built
+      // by b = 2 b + hit from slot 15 down (one compare + one add-with-carry per element); the tie count is its
+      // population count, the arg-max slot its lowest set bit
+      unsigned b0 = 0, b1 = 0;
       if (whole) {
         s0 = h2a[0]; s1 = h2b[0];
 #pragma unroll
@@ -511,33 +520,56 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         s0 = half_fmax(s0);
         s1 = half_fmax(s1);
 #pragma unroll
-        for (int r = 15; r >= 0; --r) {                // one compare feeds the tie count and the arg-max slot
-          const bool h0 = h2a[r] == s0, h1_ = h2b[r] == s1;
-          q0 += h0 ? 1u : 0u; q1 += h1_ ? 1u : 0u;
-          if (TRAIN) { a0 = h0 ? r : a0; a1 = h1_ ? r : a1; }   // rows ascend with r: the last hit is the first row
+        for (int r = 15; r >= 0; --r) {
+          hit_bit(b0, h2a[r], s0);
+          hit_bit(b1, h2b[r], s1);
         }
       } else {
-        // rows [lo, hi) of the tile; this lane's row crow(r, half) is bit crow(r, 0) of `mine`
+        // rows [lo, hi) of the tile.  Accumulator slots come in groups of four consecutive rows (8 g + 4 half + q):
+        // a group of 8 rows lies outside the segment (skipped), inside it (no row masks) or across one of its
+        // ends (masked) -- wave-uniform cases, so only the one or two boundary groups pay for selects.
         const unsigned rowmask = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
         const unsigned mine = rowmask >> (4 * half);
         const float ninf = -__builtin_inff();
         s0 = ninf; s1 = ninf;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool in = (mine >> crow(r, 0)) & 1u;
-          s0 = fmaxf(s0, in ? h2a[r] : ninf);
-          s1 = fmaxf(s1, in ? h2b[r] : ninf);
+        for (int g = 0; g < 4; ++g) {
+          if (8 * g + 8 <= lo || 8 * g >= hi) continue;
+          if (lo <= 8 * g && hi >= 8 * g + 8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s0 = fmaxf(s0, h2a[4 * g + q]); s1 = fmaxf(s1, h2b[4 * g + q]); }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const bool in = (mine >> (8 * g + q)) & 1u;
+              s0 = fmaxf(s0, in ? h2a[4 * g + q] : ninf);
+              s1 = fmaxf(s1, in ? h2b[4 * g + q] : ninf);
+            }
+          }
         }
         s0 = half_fmax(s0);
         s1 = half_fmax(s1);
 #pragma unroll
-        for (int r = 15; r >= 0; --r) {
-          const bool in = (mine >> crow(r, 0)) & 1u;
-          const bool h0 = in && h2a[r] == s0, h1_ = in && h2b[r] == s1;
-          q0 += h0 ? 1u : 0u; q1 += h1_ ? 1u : 0u;
-          if (TRAIN) { a0 = h0 ? r : a0; a1 = h1_ ? r : a1; }
+        for (int g = 3; g >= 0; --g) {
+          if (8 * g + 8 <= lo || 8 * g >= hi) { b0 <<= 4; b1 <<= 4; continue; }
+          if (lo <= 8 * g && hi >= 8 * g + 8) {
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+              hit_bit(b0, h2a[4 * g + q], s0);
+              hit_bit(b1, h2b[4 * g + q], s1);
+            }
+          } else {
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+              const bool in = (mine >> (8 * g + q)) & 1u;      // a masked row compares as -inf: never the (finite) maximum
+              hit_bit(b0, in ? h2a[4 * g + q] : ninf, s0);
+              hit_bit(b1, in ? h2b[4 * g + q] : ninf, s1);
+            }
+          }
         }
       }
+      unsigned q0 = __popc(b0), q1 = __popc(b1);
+      int a0 = b0 ? __builtin_ctz(b0) : 16, a1 = b1 ? __builtin_ctz(b1) : 16;   // first row attaining the maximum
       if (TRAIN) {
         // accumulator slot r -> edge: row crow(r, half) of the tile; no hit in this half-wave: INT_MAX
         a0 = a0 < 16 ? e0 + 8 * (a0 >> 2) + 4 * half + (a0 & 3) : 0x7fffffff;
