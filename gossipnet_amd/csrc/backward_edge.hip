@@ -503,6 +503,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       int lo[EBW_SLOTS], hi[EBW_SLOTS], tfk[EBW_SLOTS], growk[EBW_SLOTS];
       float dvk[EBW_SLOTS], dvm[EBW_SLOTS];
       int tf_any = 0;
+      const int nk = min(EBW_SLOTS, __popc(hleft));      // detections in this chunk (wave-uniform)
 #pragma unroll
       for (int k = 0; k < EBW_SLOTS; ++k) {
         const bool have = hleft != 0u;                   // wave-uniform
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       // over the slots: the register allocator cannot keep three copies' loads apart); inactive lanes add 0 * h1[0]
       static_assert(EBW_SLOTS == 3, "slot selects below");
 #pragma unroll 1
-      for (int k = 0; k < EBW_SLOTS; ++k) {
+      for (int k = 0; k < nk; ++k) {
         const int gr = k == 0 ? growk[0] : k == 1 ? growk[1] : growk[2];
         const float dm = k == 0 ? dvm[0] : k == 1 ? dvm[1] : dvm[2];
         const float* hr = sH + gr * LD64;
