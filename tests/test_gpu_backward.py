@@ -64,6 +64,22 @@ def test_backward_parity_small(n, c, b, bias):
     assert n_tight >= 1      # kink crossings are the exception, not the rule
 
 
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 65, 95, 129, 257])
+def test_tile_tails_forward_and_pinned_backward(n):
+    """Detection counts around the 32-row tile size of the node kernels (and below one tile, one detection): every
+    output and every gradient tensor against the oracle."""
+    for c in (1, 80):
+        net, orc = make_pair(c, 2)
+        net.keep_edge_activations = True
+        batch = make_image(n, c, seed=100 + n)
+        ref, gref = orc.forward_backward(batch)
+        net.run(batch)
+        torch.cuda.synchronize()
+        check_outputs(net, ref)
+        pinned = pinned_errors(net, orc, batch, c, 2)
+        assert max(pinned.values()) <= PINNED, (n, c, max(pinned.items(), key=lambda kv: kv[1]))
+
+
 @pytest.mark.parametrize("n,c,b,seed", [(300, 80, 16, 0), (300, 80, 16, 1), (1000, 1, 16, 0)])
 def test_backward_parity_pinned_16_blocks(n, c, b, seed):
     net, orc = make_pair(c, b)

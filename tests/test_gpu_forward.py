@@ -32,6 +32,29 @@ def test_forward_parity(n, c, b, seed):
     assert rel_err(net.prediction.cpu().numpy(), ref["prediction"].detach().numpy()) < TOL
 
 
+@pytest.mark.parametrize("c", [1, 80])
+def test_geometry_and_score_columns_vs_oracle(c):
+    """SURVEY 8a F1 (`_geometry_feats`, network.py:411-454) on its own: the 7 geometry columns the pw-MLP reads
+    (within a few ulp: logf / sqrtf / IEEE division on the device vs numpy) and the one-hot x score columns in the
+    factored form the kernels use -- (row, score) of the centre and of the neighbour -- bit-exact."""
+    net, orc = make_pair(c, 1)
+    batch = make_image(300, c, seed=9)
+    ref = orc.forward(batch)
+    net.run(batch, training=True, backward=False)
+    torch.cuda.synchronize()
+    raw = ref["raw_pw_feats"]
+    E, cp = raw.shape[0], max(c, 1)
+    geo = net.debug_view("geo", E * 8).cpu().numpy().reshape(E, 8)
+    assert rel_err(geo[:, :7], raw[:, 2 * cp:]) < 2e-6
+    assert np.array_equal(geo[:, 0], raw[:, 2 * cp])                       # the IoU column is the graph's: bit-exact
+    info = net.debug_view("einfo", E * 4, dtype=torch.int32).cpu().numpy().reshape(E, 4)
+    dense = np.zeros((E, 2 * cp), np.float32)
+    dense[np.arange(E), info[:, 0]] = info[:, 2].view(np.float32)
+    dense[np.arange(E), info[:, 1]] += info[:, 3].view(np.float32)
+    assert (info[:, 0] < cp).all() and (info[:, 1] >= cp).all()
+    assert np.array_equal(dense, raw[:, :2 * cp])
+
+
 def test_forward_inference_mode_matches_training_mode():
     net, orc = make_pair(80, 4)
     batch = make_image(200, 80, seed=3)
