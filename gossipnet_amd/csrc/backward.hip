@@ -10,16 +10,18 @@
 //   head_bwd       predict/logits, fc2, fc1                       -> d_x (grad wrt block_feats[B])
 //   winners_mark + winner lists of every block (backward_edge.hip; depend on the forward pass only)
 //   per block b = B..1, three launches:
-//     blk_bwd_node  [centre / reversed-edge sums of block b+1's g1 rows -> per-node halves of pw_fc1, reduce_dim of
-//                   block b+1 -> d_x += drpre . Wr^T] + [shortcut ReLU, fc2, fc1 of block b -> d_x := dz, d_pc]
+//     gather_winners  centre / reversed-edge sums of block b+1's compact g1 rows -> d_rc, d_rn
+//     blk_bwd_node  [per-node halves of pw_fc1, reduce_dim of block b+1 -> d_x += drpre . Wr^T] +
+//                   [shortcut ReLU, fc2, fc1 of block b -> d_x := dz, d_pc]
 //     edge_bwd_w    (backward_edge.hip) pw_fc2, pw_fc1 on 32-row tiles of the winner edges -> d_pw (+=), g1 rows
-//   blk_bwd_node  once more for the first block's pre stage
+//   gather_winners + blk_bwd_node once more for the first block's pre stage
 //   pw_bwd_main    pw_feats fc3, fc2 (+ d_h1 = grad wrt fc1 pre-activation), on the listed rows
 //   pw_w1_nodesums + pw_w1_classrows   pw_feats fc1 (score columns via per-detection sums, 7 geometry rows)
 //   reduce_partials  sums the per-workgroup partial weight gradients in a fixed order
 // Weight gradients are accumulated in MFMA accumulators across a workgroup's tiles and written once
-// per workgroup to an arena; reduce_partials adds them in index order.  There are no float atomics:
-// every sum has a fixed order, so gradients are reproducible run to run.
+// per workgroup to an arena; reduce_partials adds them in index order.  Every sum has a fixed order (the one
+// float atomic, d_pw += in edge_bwd_w, receives exactly one addition per element and launch: ordered by the
+// launch order), so gradients are reproducible run to run.
 #include <type_traits>
 #include "common.hpp"
 #include "backward_edge.hpp"
@@ -190,6 +192,16 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
   const int eb = row_ptr[node], ee = row_ptr[node + 1];
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
+  // the reversed pairs' list positions of the first 64 edges (a chain of dependent loads: edge_t -> bitmap word -> prefix)
+  // are requested before the own rows are summed, so that the two chains overlap
+  int tp_first = -1;
+  {
+    const int el = eb + lane;
+    if (el < ee && edge_n[el] != node) {
+      const int t = edge_t[el];
+      if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp_first = bn_winner_pos(ewin, wprefix, t);
+    }
+  }
   const int p0 = bn_winner_pos(ewin, wprefix, eb), p1 = bn_winner_pos(ewin, wprefix, ee);
   // the sums are latency-bound: several rows per quarter-wave in flight (a missing row re-reads row p0 / position 0 with
   // weight 0); ascending order per quarter-wave, the quarter-waves are folded at the end (fixed order)
@@ -207,7 +219,8 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   for (int base = eb; base < ee; base += 64) {
     const int el = base + lane;
     int tp = -1;                                            // list position of the reversed pair, if it is a winner
-    if (el < ee && edge_n[el] != node) {
+    if (base == eb) tp = tp_first;
+    else if (el < ee && edge_n[el] != node) {
       const int t = edge_t[el];
       if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp = bn_winner_pos(ewin, wprefix, t);
     }

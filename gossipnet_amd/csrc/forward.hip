@@ -310,7 +310,7 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
   m = gt ? m2 : m;
 }
 
-constexpr int EFW_WAVES = 4;      // waves per workgroup; 2 workgroups per CU.  (6 waves = 3 per SIMD measured 28% SLOWER)
+constexpr int EFW_WAVES = 4;      // waves per workgroup; 3 workgroups per CU (launch bounds below)
 constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 2 * D_P) * sizeof(float);
 
 // TRAIN: record the arg-max edge of every (centre, column) for the sparse SegmentMax backward.  The pw_fc1
