@@ -569,11 +569,13 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         }
       }
       unsigned q0 = __popc(b0), q1 = __popc(b1);
-      int a0 = b0 ? __builtin_ctz(b0) : 16, a1 = b1 ? __builtin_ctz(b1) : 16;   // first row attaining the maximum
+      int a0 = 0x7fffffff, a1 = 0x7fffffff;          // first edge attaining the maximum (no hit in this half-wave: INT_MAX)
       if (TRAIN) {
-        // accumulator slot r -> edge: row crow(r, half) of the tile; no hit in this half-wave: INT_MAX
-        a0 = a0 < 16 ? e0 + 8 * (a0 >> 2) + 4 * half + (a0 & 3) : 0x7fffffff;
-        a1 = a1 < 16 ? e0 + 8 * (a1 >> 2) + 4 * half + (a1 & 3) : 0x7fffffff;
+        // lowest hit slot r -> row crow(r, half) = r + (r & 12) + 4 half of the tile (v_ffbl of 0 is -1: masked by the select)
+        const int r0 = (int)__builtin_ctz(b0 | 0x10000u), r1 = (int)__builtin_ctz(b1 | 0x10000u);
+        const int ebase = e0 + 4 * half;
+        a0 = b0 ? ebase + r0 + (r0 & 12) : a0;
+        a1 = b1 ? ebase + r1 + (r1 & 12) : a1;
         a0 = half_min(a0);
         a1 = half_min(a1);
       }
