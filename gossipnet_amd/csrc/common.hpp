@@ -288,31 +288,44 @@ __device__ __forceinline__ void mma_abt_gB(f32x16& acc, const float* A, int lda,
   }
 }
 
-template <int K, int PF>
+// Two row tiles against a B operand streamed from global memory, as a ROLLED software pipeline over pairs of k-steps
+// (8 k each) pinned with scheduling barriers: the weight fragments of the NEXT pair are requested before the 16 MFMAs
+// of this pair.  (Written as an unrolled register ring, the scheduler sinks every load to just in front of its first
+// use -- `global_load; s_waitcnt vmcnt(0); v_mfma` -- and each k-step pays an L2 latency.)
+template <int K>
 __device__ __forceinline__ void mma_abt2_gB(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1, int lda,
                                             const float* __restrict__ Bt, int ldb, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const float* a0p = A0 + r * lda + 4 * h;
   const float* a1p = A1 + r * lda + 4 * h;
   const float* bp = Bt + (size_t)r * ldb + 4 * h;
-  constexpr int NS = K / 8;
-  f32x4 ring[PF];
-#pragma unroll
-  for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(bp + 8 * (i < NS ? i : NS - 1));
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const f32x4 b = ring[s % PF];
-    if (s + PF < NS) ring[s % PF] = *reinterpret_cast<const f32x4*>(bp + 8 * (s + PF));
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * s);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * s);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+  static_assert(K % 16 == 0, "pairs of k-steps");
+  f32x4 bA = *reinterpret_cast<const f32x4*>(bp), bB = *reinterpret_cast<const f32x4*>(bp + 8);
+#pragma unroll 1
+  for (int k = 0; k < K; k += 16) {
+    const int kn = min(k + 16, K - 16);                  // (the last pair re-reads itself)
+    const f32x4 nA = *reinterpret_cast<const f32x4*>(bp + kn), nB = *reinterpret_cast<const f32x4*>(bp + kn + 8);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + k), a1 = *reinterpret_cast<const f32x4*>(a1p + k);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(a0p + k + 8), c1 = *reinterpret_cast<const f32x4*>(a1p + k + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bA.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bA.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bA.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bA.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bA.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bA.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bA.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bA.w, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.x, bB.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.x, bB.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.y, bB.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.y, bB.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.z, bB.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.z, bB.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.w, bB.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.w, bB.w, acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    bA = nA; bB = nB;
   }
 }
 

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     __syncthreads();
     // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
     f32x16 acc0 = zero16(), acc1 = zero16();
-    mma_abt2_gB<D_H, 4>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
+    mma_abt2_gB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
     // requested before this tile's stores: the next tile's geometry
     {
       const int next = tile + (int)gridDim.x;
