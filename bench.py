@@ -148,7 +148,7 @@ def cpu_baseline(make, num_classes, num_blocks, budget_s):
             "runs": runs, "cpu": lscpu_model()}
 
 
-def time_config(dev, classes, blocks, dets, images, preset, steps, warmup):
+def time_config(dev, classes, blocks, dets, images, preset, steps, warmup, inference=False):
     """detections/s of one configuration on one GPU (no kernel timing)."""
     from gossipnet_amd.config import cfg, reset_cfg
     from gossipnet_amd.network import Gnet, DeviceBatch
@@ -156,7 +156,10 @@ def time_config(dev, classes, blocks, dets, images, preset, steps, warmup):
     reset_cfg()
     cfg.gnet.num_blocks = blocks
     net = Gnet(classes, device=dev)
-    batch = DeviceBatch([make_image(dets, classes, seed=1000 + i, preset=preset) for i in range(images)], dev)
+    imgs = [make_image(dets, classes, seed=1000 + i, preset=preset) for i in range(images)]
+    if inference:                                          # test.py:44-45 feeds dets / det_scores / det_classes only
+        imgs = [{k: im[k] for k in ("dets", "det_scores", "det_classes")} for im in imgs]
+    batch = DeviceBatch(imgs, dev)
     for _ in range(warmup):
         net.run(batch)
     torch.cuda.synchronize()
@@ -169,7 +172,8 @@ def time_config(dev, classes, blocks, dets, images, preset, steps, warmup):
     del net
     return {"detections_per_sec": round(dets * images * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "edges_per_det": round(e / (dets * images), 2), "dets_per_image": dets, "images_per_step": images,
-            "num_classes": classes, "num_blocks": blocks, "preset": preset, "steps": steps}
+            "num_classes": classes, "num_blocks": blocks, "preset": preset, "steps": steps,
+            "mode": "inference (forward only)" if inference else "training step (fwd + loss + bwd)"}
 
 
 def main():
@@ -378,6 +382,7 @@ def main():
             oc["configs[2] N=2000 C=80, 1 image/step (the reference's step shape, train.py:115)"] = time_config(dev, 80, 16, 2000, 1, "dense", 20, 5)
             oc["configs[2] N=2000 C=80, 8 images/step, coco_like preset"] = time_config(dev, 80, 16, 2000, 8, "coco_like", 10, 3)
             oc["configs[3] dense N=10000 C=80, 1 image/step"] = time_config(dev, 80, 16, 10000, 1, "dense", 5, 2)
+            oc["configs[2] N=2000 C=80, 8 images/step, INFERENCE (forward only, test.py:70)"] = time_config(dev, 80, 16, 2000, 8, "dense", 10, 3, inference=True)
             out["other_configs"] = oc
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(gen, args.classes, args.blocks, args.cpu_seconds)
