@@ -669,7 +669,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       // rows past the list (last tile) go to the slack row E of d_pw: unconditional, no divergent branches
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const unsigned er = crow(r, half) < nrows ? (unsigned)sE[crow(r, 0) + 4 * half] : (unsigned)a.n_edge;
+        // (edge of accumulator row r through two v_readlane of the lane = row records: an LDS read per atomic would
+        // put an LDS latency in front of each of the 16)
+        const unsigned er = crow(r, half) < nrows ? (unsigned)row_bcast(my_e, r, half) : (unsigned)a.n_edge;
         __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<char*>(a.d_pw) + (er * (D_E * 4u) + 4u * col)), acc[r],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
