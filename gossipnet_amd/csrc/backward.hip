@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     }
     if (tid < D_H) gb2 += col_sum32(sH2, LD256, tid);
     // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
-    mma_xty<1, 8>(aW2, sH1 + 32 * wave, LD256, sH2, LD256, lane);
+    mma_xty_pipelined<8>(aW2, sH1 + 32 * wave, LD256, sH2, LD256, lane);
     // d(fc1 pre) tile w = (d2 . W2^T) * (h1 > 0)
     {
       f32x16 acc = zero16();

@@ -331,6 +331,30 @@ __device__ __forceinline__ void mma_abt2_gB(f32x16& acc0, f32x16& acc1, const fl
 
 // acc[m][n] += X[32 rows x (32*MI)]^T * Y[32 rows x (32*NJ)] (weight-gradient shape: the
 // contraction runs over the 32 tile rows).  X, Y row-major; rows that do not exist must be 0 in Y.
+// The same product for one row tile of X with the operands of step kk + 1 requested before the NJ MFMAs of step kk
+// (pinned: otherwise every pair of MFMAs sits behind its own LDS read and wait).
+template <int NJ>
+__device__ __forceinline__ void mma_xty_pipelined(f32x16 (&acc)[1][NJ], const float* X, int ldx, const float* Y, int ldy, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  float a = X[h * ldx + r], b[NJ];
+#pragma unroll
+  for (int n = 0; n < NJ; ++n) b[n] = Y[h * ldy + 32 * n + r];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int row = 2 * (kk + 1 < 16 ? kk + 1 : kk) + h;
+    float an = X[row * ldx + r], bn[NJ];
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) bn[n] = Y[row * ldy + 32 * n + r];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[0][n], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a = an;
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) b[n] = bn[n];
+  }
+}
+
 template <int MI, int NJ>
 __device__ __forceinline__ void mma_xty(f32x16 (&acc)[MI][NJ], const float* X, int ldx, const float* Y,
                                         int ldy, int lane) {
