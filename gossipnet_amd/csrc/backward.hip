@@ -252,6 +252,17 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   }
 }
 
+// acc += X^T . Y over the 32 rows of a tile (weight-gradient shape), X / Y already offset to the lane's column: all 32
+// LDS operands are requested before the 16 MFMAs (one wave per SIMD: nobody else hides a read placed in front of each MFMA)
+__device__ __forceinline__ void dw_tile(f32x16& acc, const float* X, int ldx, const float* Y, int ldy, int half) {
+  float xa[16], ya[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { xa[kk] = X[(2 * kk + half) * ldx]; ya[kk] = Y[(2 * kk + half) * ldy]; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk], ya[kk], acc, 0, 0, 0);
+}
+
 // Inputs of one 32-detection tile of blk_bwd_node, in registers (256 threads): x, d_x [32][128]; d_rc, d_rn, q [32][64];
 // r, r_n [32][32]; segment-max records [32][64].
 struct NodeTileIn { float4 vx[4], vz[4], vr, vrn, vc[2], vn[2]; };            // needed at the top of a tile: requested one tile ahead
@@ -370,11 +381,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         const int term = cw >> 1, nj = cw & 1;
         const float* Y = term ? sRn : sRc;
         const float* X = (term && NF) ? sRrn : sRr;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const int row = 2 * kk + half;
-          aWcn = __builtin_amdgcn_mfma_f32_32x32x2f32(X[row * LD32 + col], Y[row * LD64 + 32 * nj + col], aWcn, 0, 0, 0);
-        }
+        dw_tile(aWcn, X + col, LD32, Y + 32 * nj + col, LD64, half);
       }
       gb1 += col_sum8(sRc + 8 * cw * LD64, LD64, lane);
       __syncthreads();
@@ -395,18 +402,10 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
       }
       __syncthreads();
       // d Wr += x_prev^T . drpre : role cw owns rows [32 cw, 32 cw + 32) of Wr
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + half;
-        aWr = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDr[row * LD32 + col], aWr, 0, 0, 0);
-      }
+      dw_tile(aWr, sX + 32 * cw + col, LD128, sDr + col, LD32, half);
       gbr += col_sum8(sDr + 8 * cw * LD32, LD32, col);
       if (NF) {
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const int row = 2 * kk + half;
-          aWrn = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[row * LD128 + 32 * cw + col], sDrn[row * LD32 + col], aWrn, 0, 0, 0);
-        }
+        dw_tile(aWrn, sX + 32 * cw + col, LD128, sDrn + col, LD32, half);
         gbrn += col_sum8(sDrn + 8 * cw * LD32, LD32, col);
       }
       if (a.do_post || a.want_dx0) {
@@ -426,13 +425,22 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
     }
     if (a.do_post) {
       // dz = d_x * (x_out > 0): also the shortcut gradient of block b-1 (network.py:407-408)
-      for (int i = tid; i < 32 * (D_S / 4); i += 256) {
-        const int row = i >> 5, c4 = i & 31;
-        const float4 g = *reinterpret_cast<const float4*>(sDZ + row * LD128 + 4 * c4);
-        const float4 x = *reinterpret_cast<const float4*>(sX + row * LD128 + 4 * c4);
-        const float4 v = make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f);
-        *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = v;
-        if (row0 + row < a.n_det) *reinterpret_cast<float4*>(a.d_x + (size_t)(row0 + row) * D_S + 4 * c4) = v;
+      {
+        float4 g[4], x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+          g[j] = *reinterpret_cast<const float4*>(sDZ + row * LD128 + 4 * c4);
+          x[j] = *reinterpret_cast<const float4*>(sX + row * LD128 + 4 * c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+          const float4 v = make_float4(x[j].x > 0.f ? g[j].x : 0.f, x[j].y > 0.f ? g[j].y : 0.f, x[j].z > 0.f ? g[j].z : 0.f, x[j].w > 0.f ? g[j].w : 0.f);
+          *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = v;
+          if (row0 + row < a.n_det) *reinterpret_cast<float4*>(a.d_x + (size_t)(row0 + row) * D_S + 4 * c4) = v;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -446,14 +454,8 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
       }
       __syncthreads();
       // d W4 += q^T . dz : role cw owns output column tile cw
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + half;
-        const float x0 = sQ[row * LD64 + col], x1 = sQ[row * LD64 + 32 + col];
-        const float y = sDZ[row * LD128 + 32 * cw + col];
-        aW4a = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y, aW4a, 0, 0, 0);
-        aW4b = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y, aW4b, 0, 0, 0);
-      }
+      dw_tile(aW4a, sQ + col, LD64, sDZ + 32 * cw + col, LD128, half);
+      dw_tile(aW4b, sQ + 32 + col, LD64, sDZ + 32 * cw + col, LD128, half);
       gb4 += col_sum8(sDZ + 8 * cw * LD128, LD128, lane); gb4b += col_sum8(sDZ + 8 * cw * LD128, LD128, 64 + lane);
       // dq = (dz . W4^T) * (q > 0): role = (column tile, K half)
       {
@@ -473,11 +475,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
       // d W3 += p^T . dq : role = (mi, nj)
       {
         const int mi = cw >> 1, nj = cw & 1;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const int row = 2 * kk + half;
-          aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[row * LD64 + 32 * mi + col], sDq[row * LD64 + 32 * nj + col], aW3, 0, 0, 0);
-        }
+        dw_tile(aW3, sP + 32 * mi + col, LD64, sDq + 32 * nj + col, LD64, half);
       }
       gb3 += col_sum8(sDq + 8 * cw * LD64, LD64, lane);
       // dp = dq . W3^T : role = (column tile, K half); the partials of the dq step were consumed before the last barrier
