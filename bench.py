@@ -322,6 +322,19 @@ def main():
                                                       "note": "FLOPs of the reference's dense per-edge formulation (SURVEY 8d)"}}
                 if note:
                     roofline["traffic_note"] = note
+        # the four MFMA-bound classes side by side (edge_fwd and pw_bwd_main are within a few percent of each other:
+        # which of them is "dominant" can change from run to run); from the untimed, fully instrumented pass
+        mfma_kernels = {}
+        for k_ in ("edge_fwd", "pw_bwd_main", "pw_fwd", "edge_bwd"):
+            if counts.get(k_):
+                e_ = executed_mfma_flops(k_, E, N_local, wpb, pw_rows)
+                n_ = 1 if k_ == "pw_fwd" else counts[k_]      # (the pw_fwd class also times the small edge_geometry launch)
+                tf_ = e_ * n_ / (table[k_] * 1e-3) / 1e12
+                mfma_kernels[k_] = {"ms_per_step": round(table[k_], 4), "launches_per_step": n_,
+                                    "mfma_flops_per_step": e_ * n_, "tflops": round(tf_, 2),
+                                    "frac": round(tf_ / FP32_MFMA_PEAK_TFLOPS, 4)}
+        if roofline is not None:
+            roofline["mfma_kernels"] = mfma_kernels
         # whole-step executed MFMA FLOPs
         ex_total = 0.0
         for k_, c_ in counts.items():
