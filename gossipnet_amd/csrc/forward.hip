@@ -683,10 +683,18 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   }
   if (a.do_post) {
     // p tile (segment max) -> sY[32][68]
-    for (int i = tid; i < 32 * D_P; i += 256) {
-      const int row = i >> 6, ff = i & 63;
-      const int node = min(row0 + row, a.n_det - 1);
-      sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(a.pm[(size_t)node * D_P + ff] >> 32));
+    {
+      unsigned long long pv[8];                          // all eight records requested before the first LDS store
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
+        pv[j] = a.pm[(size_t)min(row0 + row, a.n_det - 1) * D_P + ff];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
+        sY[row * E_LD2 + ff] = __uint_as_float((unsigned)(pv[j] >> 32));
+      }
     }
     __syncthreads();
     f32x16 acc = zero16();
@@ -734,14 +742,18 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   }
   if (a.do_pre) {
     if (a.pm_next) {
-      for (int i = tid; i < 32 * D_P; i += 256) {
-        const int node = row0 + (i >> 6);
-        if (node < a.n_det) {
-          const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
-          if (ee == eb || eb / a.edge_span != (ee - 1) / a.edge_span) {
-            a.pm_next[(size_t)node * D_P + (i & 63)] = 0ull;
-            if (a.parg_next) a.parg_next[(size_t)node * D_P + (i & 63)] = 0ull;
-          }
+      int eb[8], ee[8];                                  // (all sixteen row_ptr reads before the first use)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int node = min(row0 + (tid >> 6) + 4 * j, a.n_det - 1);
+        eb[j] = a.row_ptr[node]; ee[j] = a.row_ptr[node + 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int node = row0 + (tid >> 6) + 4 * j;
+        if (node < a.n_det && (ee[j] == eb[j] || eb[j] / a.edge_span != (ee[j] - 1) / a.edge_span)) {
+          a.pm_next[(size_t)node * D_P + (tid & 63)] = 0ull;
+          if (a.parg_next) a.parg_next[(size_t)node * D_P + (tid & 63)] = 0ull;
         }
       }
     }
