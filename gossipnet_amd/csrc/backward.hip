@@ -93,10 +93,30 @@ __global__ void __launch_bounds__(256) head_bwd(const HeadBwdArgs a) {
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int row0 = t * 32;
     __syncthreads();
-    load_tile<D_HEAD, LD128>(sH2, a.head2, row0, a.n_det, tid, 256);
-    load_tile<D_HEAD, LD128>(sH1, a.head1, row0, a.n_det, tid, 256);
-    load_tile<D_S, LD128>(sX, a.xb, row0, a.n_det, tid, 256);
-    if (tid < 32) sDl[tid] = (row0 + tid < a.n_det) ? a.d_logits[row0 + tid] : 0.f;
+    {
+      // the three [32][128] tiles: all twelve 16-byte requests of a thread before the first LDS store
+      static_assert(D_S == D_HEAD, "one offset for the three tiles");
+      float4 v2[4], v1[4], vx[4];
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+        const bool ok = row0 + row < a.n_det;
+        const size_t o = (size_t)(row0 + row) * D_HEAD + 4 * c4;
+        v2[j] = ok ? *reinterpret_cast<const float4*>(a.head2 + o) : z4;
+        v1[j] = ok ? *reinterpret_cast<const float4*>(a.head1 + o) : z4;
+        vx[j] = ok ? *reinterpret_cast<const float4*>(a.xb + o) : z4;
+      }
+      const float dl = (tid < 32 && row0 + tid < a.n_det) ? a.d_logits[row0 + tid] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j, row = i >> 5, c4 = i & 31;
+        *reinterpret_cast<float4*>(sH2 + row * LD128 + 4 * c4) = v2[j];
+        *reinterpret_cast<float4*>(sH1 + row * LD128 + 4 * c4) = v1[j];
+        *reinterpret_cast<float4*>(sX + row * LD128 + 4 * c4) = vx[j];
+      }
+      if (tid < 32) sDl[tid] = dl;
+    }
     __syncthreads();
     // d head2 = dl (outer) wl
     for (int i = tid; i < 32 * D_HEAD; i += 256) {
