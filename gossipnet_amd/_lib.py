@@ -51,7 +51,7 @@ class gnet_buffers(C.Structure):
                 [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_rnb", "blk_h1", "blk_parg")] +
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
                                            "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
-                                           "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +
+                                           "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "tpos", "wrow", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +
                 [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t), ("profiler", C.c_void_p), ("start_feat", C.c_void_p)])
 
 
@@ -113,9 +113,9 @@ def load():
     lib.gnet_match_prepare.restype = C.c_int
     lib.gnet_match_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), P(gnet_buffers), vp]
     lib.gnet_backward.restype = C.c_int
-    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, C.c_int32, vp]
+    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, C.c_int32, vp, vp]
     lib.gnet_backward_prepare.restype = C.c_int
-    lib.gnet_backward_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp]
+    lib.gnet_backward_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), C.c_int32, vp]
     lib.det_matching_workspace_bytes.restype = sz
     lib.det_matching_workspace_bytes.argtypes = [i32, i32]
     lib.det_matching_f32.restype = C.c_int

@@ -204,25 +204,17 @@ __device__ __forceinline__ int bn_winner_pos(const unsigned long long* __restric
 }
 
 __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ g1c, const int* __restrict__ row_ptr,
-                                                      const int* __restrict__ edge_n, const int* __restrict__ edge_t,
-                                                      const unsigned long long* __restrict__ ewin, const int* __restrict__ wprefix,
+                                                      const int* __restrict__ wrow, const int* __restrict__ tpos,
                                                       int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
   const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= n_det) return;
   const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
   const int eb = row_ptr[node], ee = row_ptr[node + 1];
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sn = sc;
-  // the reversed pairs' list positions of the first 64 edges (a chain of dependent loads: edge_t -> bitmap word -> prefix)
-  // are requested before the own rows are summed, so that the two chains overlap
-  int tp_first = -1;
-  {
-    const int el = eb + lane;
-    if (el < ee && edge_n[el] != node) {
-      const int t = edge_t[el];
-      if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp_first = bn_winner_pos(ewin, wprefix, t);
-    }
-  }
-  const int p0 = bn_winner_pos(ewin, wprefix, eb), p1 = bn_winner_pos(ewin, wprefix, ee);
+  // list positions come precomputed (winner_tpos): the own rows are [wrow[node], wrow[node + 1]), the reversed pairs'
+  // positions tpos[e]; the first 64 of those are requested before the own rows are summed
+  const int tp_first = eb + lane < ee ? tpos[eb + lane] : -1;
+  const int p0 = wrow[node], p1 = wrow[node + 1];
   // the sums are latency-bound: several rows per quarter-wave in flight (a missing row re-reads row p0 / position 0 with
   // weight 0); ascending order per quarter-wave, the quarter-waves are folded at the end (fixed order)
   for (int p = p0 + sub; p < p1; p += 16) {
@@ -240,10 +232,7 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
     const int el = base + lane;
     int tp = -1;                                            // list position of the reversed pair, if it is a winner
     if (base == eb) tp = tp_first;
-    else if (el < ee && edge_n[el] != node) {
-      const int t = edge_t[el];
-      if ((ewin[t >> 6] >> (t & 63)) & 1ull) tp = bn_winner_pos(ewin, wprefix, t);
-    }
+    else if (el < ee) tp = tpos[el];
     unsigned long long mr = __ballot(tp >= 0);
     while (mr) {
       // next 16 reversed rows: four per quarter-wave
@@ -942,7 +931,7 @@ __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
 
 // ------------------------------------------------------------------------------------------
 extern "C" int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-                                     const float* params, gnet_buffers* buf, gnet_stream_t stream) {
+                                     const float* params, gnet_buffers* buf, int32_t phase, gnet_stream_t stream) {
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf) return GNET_ERR_INVALID;
@@ -951,19 +940,24 @@ extern "C" int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* s
   if (shape->n_det == 0 || E == 0) return GNET_OK;
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  // the edge stages accumulate into d_pw (winner rows only)
-  HIP_CHECK_RET(hipMemsetAsync(buf->d_pw, 0, (size_t)E * D_E * sizeof(float), s));
+  if (phase == 0 || phase == 1) {
+    // zeroing: the edge stages accumulate into d_pw (winner rows only); the winner maps start empty
+    HIP_CHECK_RET(hipMemsetAsync(buf->d_pw, 0, (size_t)E * D_E * sizeof(float), s));
+    const int st = edge_stage_clear(cfg, shape, buf, s);
+    if (st != GNET_OK) return st;
+  }
+  if (phase == 1) return GNET_OK;
   // winner maps / lists of ALL blocks (they depend on the forward pass only: off the backward chain)
   return edge_stage_prepare(cfg, shape, make_layout(cfg), params, buf, s);
 }
 
 extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                              const float* params, gnet_buffers* buf, float* grads, int32_t prepared,
-                             gnet_stream_t stream) {
+                             void* prepared_event, gnet_stream_t stream) {
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
-  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows) return GNET_ERR_INVALID;   // plan(training >= 1)
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows || !buf->tpos || !buf->wrow) return GNET_ERR_INVALID;   // plan(training >= 1)
   hipStream_t s = (hipStream_t)stream;
   const ParamLayout L = make_layout(cfg);
   const int B = cfg->num_blocks;
@@ -991,7 +985,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   { const int st = edge_stage_set_attributes(); if (st != GNET_OK) return st; }
 
   if (E > 0 && !prepared) {
-    const int st = gnet_backward_prepare(cfg, shape, in, params, buf, stream);
+    const int st = gnet_backward_prepare(cfg, shape, in, params, buf, 0, stream);
     if (st != GNET_OK) return st;
   }
   {
@@ -1012,8 +1006,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     n.d_rc = E > 0 ? buf->d_rc : nullptr; n.d_rn = E > 0 ? buf->d_rn : nullptr;
     if (b <= B && E > 0) {
       GNET_LAUNCH(prof, GNET_K_GATHER, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
-          buf->d_g1, buf->row_ptr, buf->edge_n, buf->edge_t, (const unsigned long long*)buf->ewin + (size_t)(b - 1) * G.bm_stride,
-          buf->wprefix + (size_t)(b - 1) * G.bm_stride, N, buf->d_rc, buf->d_rn));
+          buf->d_g1, buf->row_ptr, buf->wrow + (size_t)(b - 1) * G.tf_stride, buf->tpos + (size_t)(b - 1) * G.wl_stride, N,
+          buf->d_rc, buf->d_rn));
     }
     n.x_prev = b >= 2 ? buf->block_feats[b - 1] : buf->start_feat;
     if (b <= B) {
@@ -1035,6 +1029,10 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     else { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<false><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
     // edge stage of block b-1
     if (b >= 2 && E > 0) {
+      if (b == B + 1 && prepared && prepared_event) {
+        // first use of the prepared winner lists: head_bwd and the node kernel above needed none of them
+        HIP_CHECK_RET(hipStreamWaitEvent(s, (hipEvent_t)prepared_event, 0));
+      }
       const int st = edge_stage_block(cfg, shape, L, params, b - 1, buf, g_edge, s);
       if (st != GNET_OK) return st;
     }

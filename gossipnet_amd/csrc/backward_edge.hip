@@ -321,6 +321,33 @@ __global__ void __launch_bounds__(256) winner_positions(const PosArgs a) {
   }
 }
 
+// tpos[e] = list position of the reversed pair of edge e if that pair is a winner of the block (not for self pairs:
+// their rn row is the zero row), wrow[i] = list position of the first winner at or after detection i's first edge.
+// gather_winners reads these instead of chasing edge_t -> bitmap word -> prefix count per edge.  All blocks in one launch.
+struct TposArgs {
+  int n_det, n_edge;
+  long long bm_stride, wl_stride, tf_stride;
+  const unsigned long long* ewin; const int* wprefix;
+  const int* row_ptr; const int* edge_c; const int* edge_n; const int* edge_t;
+  int* tpos; int* wrow;
+};
+
+__global__ void __launch_bounds__(256) winner_tpos(const TposArgs a) {
+  const int blk = blockIdx.y;
+  const unsigned long long* ewin = a.ewin + (size_t)blk * a.bm_stride;
+  const int* wprefix = a.wprefix + (size_t)blk * a.bm_stride;
+  int* tpos = a.tpos + (size_t)blk * a.wl_stride;
+  int* wrow = a.wrow + (size_t)blk * a.tf_stride;
+  const int stride = gridDim.x * 256;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < a.n_edge; e += stride) {
+    const int t = a.edge_t[e];
+    int tp = -1;
+    if (a.edge_c[e] != a.edge_n[e] && ((ewin[t >> 6] >> (t & 63)) & 1ull)) tp = winner_pos(ewin, wprefix, t);
+    tpos[e] = tp;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i <= a.n_det; i += stride) wrow[i] = winner_pos(ewin, wprefix, a.row_ptr[i]);
+}
+
 // ------------------------------------------------------------------------------------------
 struct EdgeBwdWArgs {
   int n_edge, n_det;
@@ -721,21 +748,28 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// the zeroing the winner maps need: independent of the forward pass (may run long before edge_stage_prepare)
+int edge_stage_clear(const gnet_config* cfg, const gnet_shape* shape, gnet_buffers* buf, hipStream_t s) {
+  const int B = cfg->num_blocks, N = shape->n_det, E = (int)shape->n_edge;
+  const EdgeGeom G = edge_geom(E, N);
+  HIP_CHECK_RET(hipMemsetAsync(buf->ewin, 0, (size_t)(B + 1) * G.bm_stride * sizeof(unsigned long long), s));
+  HIP_CHECK_RET(hipMemsetAsync(buf->rl_scratch + (size_t)(B + 1) * (2 * G.n_wg + 1), 0, (size_t)GNET_MAX_BLOCKS * sizeof(int), s));
+  return GNET_OK;
+}
+
 int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const ParamLayout& L, const float* params,
                        gnet_buffers* buf, hipStream_t s) {
   const int B = cfg->num_blocks, N = shape->n_det, E = (int)shape->n_edge;
   const EdgeGeom G = edge_geom(E, N);
   void* prof = buf->profiler;
   const float* pt = buf->packed_t;
-  HIP_CHECK_RET(hipMemsetAsync(buf->ewin, 0, (size_t)(B + 1) * G.bm_stride * sizeof(unsigned long long), s));
   WinArgs w;
   w.n_det = N; w.bm_stride = (long long)G.bm_stride; w.xm_stride = (long long)G.xm_stride; w.tf_stride = (long long)G.tf_stride;
   w.ewin = (unsigned long long*)buf->ewin; w.xmask = (unsigned long long*)buf->xmask; w.tflag = (unsigned char*)buf->tflag;
   // list of the detections with tied maxima: the arg-max position array apos is written after winners_ties, its
   // first N ints per block serve as the list until then; the counters live in the slack of the scan scratch
   w.tlist = buf->apos; w.tl_stride = (long long)G.ap_stride;
-  w.tcount = buf->rl_scratch + (size_t)(B + 1) * (2 * G.n_wg + 1);
-  HIP_CHECK_RET(hipMemsetAsync(w.tcount, 0, (size_t)GNET_MAX_BLOCKS * sizeof(int), s));
+  w.tcount = buf->rl_scratch + (size_t)(B + 1) * (2 * G.n_wg + 1);     // (zeroed by edge_stage_clear)
   w.row_ptr = buf->row_ptr; w.edge_nz = buf->edge_nz; w.pw = buf->pw_feats;
   for (int b = 1; b <= B; ++b) {
     w.pm[b - 1] = (const unsigned long long*)buf->blk_pm[b]; w.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
@@ -759,6 +793,12 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   p.ewin = (const unsigned long long*)buf->ewin; p.wprefix = buf->wprefix; p.apos = buf->apos;
   for (int b = 1; b <= B; ++b) p.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_positions<<<dim3(min((N * D_P + 255) / 256, 1024), B), 256, 0, s>>>(p));
+  TposArgs t;
+  t.n_det = N; t.n_edge = E; t.bm_stride = (long long)G.bm_stride; t.wl_stride = (long long)G.wl_stride; t.tf_stride = (long long)G.tf_stride;
+  t.ewin = (const unsigned long long*)buf->ewin; t.wprefix = buf->wprefix;
+  t.row_ptr = buf->row_ptr; t.edge_c = buf->edge_c; t.edge_n = buf->edge_n; t.edge_t = buf->edge_t;   // (edge_t: gnet_graph_transpose, earlier on this stream)
+  t.tpos = buf->tpos; t.wrow = buf->wrow;
+  GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_tpos<<<dim3(min((E + 255) / 256, 1024), B), 256, 0, s>>>(t));
   return GNET_OK;
 }
 

@@ -3,6 +3,7 @@
 #include "common.hpp"
 
 // winner maps + lists of every block (depends on the forward pass only); also the row list of the pw-MLP backward
+int edge_stage_clear(const gnet_config* cfg, const gnet_shape* shape, gnet_buffers* buf, hipStream_t s);
 int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const ParamLayout& L, const float* params,
                        gnet_buffers* buf, hipStream_t s);
 // edge_bwd_w of block b: d_pw (+=), compact g1 rows, partial d W(pw_fc1 rows 0-31), d W(pw_fc2), d b(pw_fc2)

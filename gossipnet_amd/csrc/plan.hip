@@ -84,6 +84,8 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.xmask = c.take<uint64_t>(B * G.xm_stride);
       b.tflag = c.take<uint8_t>(B * G.tf_stride);
       b.apos = c.take<int32_t>(B * G.ap_stride);
+      b.tpos = c.take<int32_t>(B * G.wl_stride);
+      b.wrow = c.take<int32_t>(B * G.tf_stride);
       b.rl_scratch = c.take<int32_t>((B + 1) * (2 * G.n_wg + 1) + GNET_MAX_BLOCKS + 64);   // + per-block tie-list counters
     }
     b.pw_rows = c.take<int32_t>(Ep);

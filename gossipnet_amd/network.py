@@ -356,7 +356,7 @@ class Gnet(object):
         self.num_edges = E
         return shape, buf
 
-    def _prepare_matching(self, shape, inp, buf):
+    def _prepare_matching(self, shape, inp, buf, backward=True):
         """det_anno_iou and the matching's candidate keys depend on the inputs only: they run on the side stream
         while the forward pass runs on the main one (ordered after everything the main stream has queued so far --
         the previous step's readers of these buffers -- and before gnet_loss through `_prep_done`)."""
@@ -375,6 +375,9 @@ class Gnet(object):
                 # recorded later on this stream)
                 _lib.check(self._lib.gnet_graph_transpose(buf.row_ptr, buf.edge_c, buf.edge_n, shape.n_edge, buf.edge_t, ss),
                            "gnet_graph_transpose")
+                if backward:     # the zeroing half of the backward preparation does not need the forward pass
+                    _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
+                                                               C.byref(buf), 1, ss), "gnet_backward_prepare")
 
     def _prepare_backward(self, shape, inp, buf):
         """The SegmentMax winner maps / row lists of all blocks depend on the forward pass only: they are built on the
@@ -386,7 +389,7 @@ class Gnet(object):
         self._side.wait_event(self._fwd_done)
         with torch.cuda.stream(self._side):
             _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
-                                                       C.byref(buf), C.c_void_p(self._side.cuda_stream)), "gnet_backward_prepare")
+                                                       C.byref(buf), 2, C.c_void_p(self._side.cuda_stream)), "gnet_backward_prepare")
             self._bprep_done.record(self._side)
 
     def _mode(self, training):
@@ -426,7 +429,7 @@ class Gnet(object):
         if self._imfeats:
             buf.start_feat = _vp(self._imfeat_forward(db))
         if training:
-            self._prepare_matching(shape, inp, buf)
+            self._prepare_matching(shape, inp, buf, backward)
         _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                     C.byref(buf), self._mode(training), s), "gnet_forward")
         if training and backward:
@@ -436,9 +439,10 @@ class Gnet(object):
             _lib.check(lib.gnet_loss(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.class_weights),
                                      float(self.grad_scale), C.byref(buf), 1, s), "gnet_loss")
             if backward:
-                torch.cuda.current_stream(self.device).wait_event(self._bprep_done)
+                # (the main stream waits for the winner lists inside gnet_backward, where they are first needed)
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
-                                             C.byref(buf), _vp(self.grads), 1, s), "gnet_backward")
+                                             C.byref(buf), _vp(self.grads), 1, C.c_void_p(self._bprep_done.cuda_event), s),
+                           "gnet_backward")
                 if self._imfeats:
                     self._imfeat_backward(db)
                 if self.weight_reg:

@@ -130,6 +130,8 @@ typedef struct gnet_buffers {
   uint64_t* xmask;    /* [num_blocks][xm_stride] per edge: columns whose (tied) maximum it attains besides the recorded arg-max edge; valid on rows of flagged detections only */
   uint8_t* tflag;     /* [num_blocks][tf_stride] the detection has a tied positive maximum in this block */
   int32_t* apos;      /* [num_blocks][n_det+32,64] list position of the arg-max edge of every (detection, column); -1 = no gradient */
+  int32_t* tpos;      /* [num_blocks][n_edge+64] list position of every edge's REVERSED pair in the block's winner list; -1 = not a winner (or a self pair) */
+  int32_t* wrow;      /* [num_blocks][n_det+32] list position of the first winner of every detection's edge range (CSR row pointers of the winner lists) */
   int32_t* rl_scratch;/* scan scratch of the list construction; also holds the list lengths */
   int32_t* pw_rows;   /* [n_edge+64] ascending indices of the edges with a non-zero d_pw row (rows of the pw-MLP backward) */
   float* w1_s;        /* [n_det,256] sum of d_h1 over the detection's own pairs (centre role)      */
@@ -208,14 +210,20 @@ int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shape, const gn
  * dense algorithm minus exact zeros.
  * Limits: n_edge <= 2^24 - 128 (32-bit byte offsets into [E,64] fp32 arrays; GNET_ERR_UNSUPPORTED beyond). */
 int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-                  const float* params, gnet_buffers* buf, float* grads, int32_t prepared, gnet_stream_t stream);
+                  const float* params, gnet_buffers* buf, float* grads, int32_t prepared, void* prepared_event,
+                  gnet_stream_t stream);
+/* prepared_event (hipEvent_t or NULL, only with prepared = 1): recorded by the caller behind gnet_backward_prepare on
+ * its stream.  gnet_backward makes `stream` wait for it where the prepared data is first needed -- after the head's
+ * and the last block's node kernels, which need none of it -- instead of the caller waiting before the call. */
 
 /* The part of gnet_backward that depends on the forward pass only, not on the loss: the SegmentMax winner maps and
  * row lists of every block, and the zeroed d_pw accumulator.  A caller may run it on another stream once
  * gnet_forward has finished, beside gnet_loss, and pass prepared = 1 to gnet_backward (after ordering the two
  * streams).  With prepared = 0 gnet_backward does this work itself. */
 int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
-                          const float* params, gnet_buffers* buf, gnet_stream_t stream);
+                          const float* params, gnet_buffers* buf, int32_t phase, gnet_stream_t stream);
+/* phase 0 = everything (after gnet_forward); 1 = only the zeroing (d_pw, the winner maps: independent of the forward
+ * pass, may run beside it); 2 = only the forward-dependent part (after gnet_forward and after phase 1). */
 
 /* ---- training step around the path (train.py:64-77: slim create_train_op with Adam / Momentum) --------
  * All buffers are flat fp32 of n = gnet_param_count elements (device).  grad_scale multiplies the
