@@ -115,7 +115,10 @@ __global__ void __launch_bounds__(256) winners_ties(const WinArgs a) {
   float* sh = sh_all[wave];
   const int* tl = a.tlist + (size_t)blk * a.tl_stride;
   const int n_tied = a.tcount[blk];
-  for (int li = blockIdx.x * 4 + wave; li < n_tied; li += nwaves) {
+  // eight waves share a flagged detection, each taking every eighth 32-edge tile of it: the kernel is a handful of
+  // waves' worth of dependent work per block, so its duration is one wave's chain
+  const int gw = blockIdx.x * 4 + wave, sub = gw & 7;
+  for (int li = gw >> 3; li < n_tied; li += nwaves >> 3) {
     const int node = __builtin_amdgcn_readfirstlane(tl[li]);
     const unsigned long long pv = a.parg[blk][(size_t)node * D_P + lane];
     const unsigned long long pc = a.pm[blk][(size_t)node * D_P + lane];
@@ -123,16 +126,16 @@ __global__ void __launch_bounds__(256) winners_ties(const WinArgs a) {
     const int arg = (int)(unsigned)pv;
     const unsigned long long ties = __ballot(valid && (unsigned)pc > 1u);
     const int eb = a.row_ptr[node], ee = a.row_ptr[node + 1];
-    for (int e = eb + lane; e < ee; e += 64) xmask[e] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const float* rcp = a.rc[blk] + (size_t)node * D_P;
     const float* rnp = a.rn[blk];
     const float* w1tp = a.w1t[blk]; const float* w2tp = a.w2t[blk];
     const float bias0 = a.b2[blk][col], bias1 = a.b2[blk][32 + col];
     const float rc0 = rcp[col], rc1 = rcp[32 + col];
     const float mx = __uint_as_float((unsigned)(pv >> 32));
-    for (int e0 = eb; e0 < ee; e0 += 32) {
+    for (int e0 = eb + 32 * sub; e0 < ee; e0 += 32 * 8) {
       const int nrows = min(32, ee - e0);
+      if (lane < nrows) xmask[e0 + lane] = 0ull;            // this tile's masks (every edge belongs to one tile of one wave)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       f32x16 h1a, h1b;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
