@@ -73,21 +73,24 @@ def load():
     if _lib is not None:
         return _lib
     from . import build as _build
-    stale = False
-    if os.path.exists(LIB_PATH):
+    # A library whose recorded source hash DIFFERS from the tree is rebuilt (never silently used); one without a record
+    # (built by other tooling, deployed without the sources' toolchain) is loaded as it is, with a warning.
+    stale = missing = not os.path.exists(LIB_PATH)
+    if not missing:
         try:
             stale = open(LIB_PATH + ".srchash").read().strip() != _build.source_hash()
         except OSError:
-            stale = True
-    if stale or not os.path.exists(LIB_PATH):
-        # not a fallback: the same HIP sources, compiled on the spot when hipcc is available (a library built from
-        # other sources than the ones in the tree is rebuilt rather than silently used)
+            import warnings
+            warnings.warn("libgossipnet_hip.so carries no source hash (%s.srchash): loading it as it is" % LIB_PATH)
+    if stale:
+        # not a fallback: the same HIP sources, compiled on the spot when hipcc is available.  build() serialises
+        # concurrent callers (one rank per GPU under torchrun) with a file lock and re-checks the hash inside it.
         try:
             _build.build()
         except Exception as exc:      # noqa: BLE001
             raise GnetError("libgossipnet_hip.so is %s (%s) and could not be built (%s): run "
                             "`python -m gossipnet_amd.build` -- there is no CPU fallback"
-                            % ("stale" if stale else "missing", LIB_PATH, exc))
+                            % ("missing" if missing else "stale", LIB_PATH, exc))
     # torch bundles its own HIP runtime: it must be mapped first so that this library binds to the
     # same libamdhip64 as the streams/allocations it is handed (loading /opt/rocm's copy first breaks launches)
     import torch  # noqa: F401

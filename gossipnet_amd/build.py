@@ -30,12 +30,33 @@ def source_hash():
     return h.hexdigest()
 
 
+def _up_to_date():
+    try:
+        return os.path.exists(LIB) and open(LIB + ".srchash").read().strip() == source_hash()
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=False):
+    """Compiles what changed and links the library.  Concurrent callers (one process per GPU) are serialised by an
+    exclusive lock on csrc/build/.lock; a caller that waited finds the library current and returns."""
+    import fcntl
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date():
+                return LIB
+            return _build_locked(force, verbose, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, objdir):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "backward_edge.hpp"),
                    os.path.join(HERE, "..", "include", "gossipnet_hip.h")]
-    objdir = os.path.join(CSRC, "build")
-    os.makedirs(objdir, exist_ok=True)
     hdr_mtime = max(os.path.getmtime(d) for d in deps[len(srcs):])
     objs, procs = [], []
     for s in srcs:
@@ -55,8 +76,9 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed")
     if procs or force or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        subprocess.check_call(cmd)
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, LIB)                 # a process that has the old library mapped keeps its inode
     with open(LIB + ".srchash", "w") as f:
         f.write(source_hash())
     return LIB

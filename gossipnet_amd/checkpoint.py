@@ -29,17 +29,14 @@ def save(net, path, global_step=0, optimizer=None, fmt="npz"):
     out = {k: v for k, v in net.state_dict().items()}
     out["global_step"] = np.int64(global_step)
     if optimizer is not None:
-        off = 0
-        m = optimizer.m.cpu().numpy()
-        v = optimizer.v.cpu().numpy() if optimizer.v is not None else None
-        for name, shape in net._spec:
-            k = int(np.prod(shape))
+        m = {k: t.cpu().numpy() for k, t in net.flat_to_named(optimizer.m).items()}
+        v = {k: t.cpu().numpy() for k, t in net.flat_to_named(optimizer.v).items()} if optimizer.v is not None else None
+        for name, _ in net._spec:
             if optimizer.kind == "adam":
-                out[name + "/Adam"] = m[off:off + k].reshape(shape)
-                out[name + "/Adam_1"] = v[off:off + k].reshape(shape)
+                out[name + "/Adam"] = m[name]
+                out[name + "/Adam_1"] = v[name]
             else:
-                out[name + "/Momentum"] = m[off:off + k].reshape(shape)
-            off += k
+                out[name + "/Momentum"] = m[name]
     if fmt == "tf":
         from . import tf_bundle
         tf_bundle.write_bundle(path, {k: np.asarray(v) for k, v in out.items()})
@@ -72,11 +69,12 @@ def load(net, path, optimizer=None):
     if optimizer is not None:
         slot_m = "/Adam" if optimizer.kind == "adam" else "/Momentum"
         if all((n + slot_m) in z.files for n, _ in net._spec):
-            flat = np.concatenate([z[n + slot_m].reshape(-1) for n, _ in net._spec]).astype(np.float32)
-            optimizer.m.copy_(torch.from_numpy(flat).to(optimizer.m.device))
+            def restore(flat, suffix):
+                for n, t in net.flat_to_named(flat).items():
+                    t.copy_(torch.from_numpy(np.asarray(z[n + suffix], np.float32)).to(flat.device))
+            restore(optimizer.m, slot_m)
             if optimizer.kind == "adam":
-                flat = np.concatenate([z[n + "/Adam_1"].reshape(-1) for n, _ in net._spec]).astype(np.float32)
-                optimizer.v.copy_(torch.from_numpy(flat).to(optimizer.v.device))
+                restore(optimizer.v, "/Adam_1")
         optimizer.global_step = int(z["global_step"]) if "global_step" in z.files else 0
     return int(z["global_step"]) if "global_step" in z.files else 0
 

@@ -121,7 +121,9 @@ __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ scor
 //     taken, its IoU row is scanned by the whole wave.
 // The first unresolved detection always resolves, so the rounds terminate; every commit is the decision the
 // sequential loop takes at that detection's turn (its wish is free then, and nobody before it asked for it).
-constexpr int kMaxGt = 2048;
+// taken[] / owner[] of the image's ground-truth boxes live in (dynamic) LDS sized for the TOTAL number of boxes of the
+// call -- the one count the host knows (the per-image counts are device data), and an upper bound of every image's.
+constexpr int kMaxGt = 24576;      // 5 bytes per box: 120 KB of the 160 KB LDS
 __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou, const long long* __restrict__ anno_off,
                                                    const int* __restrict__ det_off, const int* __restrict__ gt_off,
                                                    const unsigned char* __restrict__ ignore,
@@ -129,9 +131,10 @@ __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou
                                                    const unsigned long long* __restrict__ k2,
                                                    const int* __restrict__ ncand, const int* __restrict__ cfirst,
                                                    float* __restrict__ labels, float* __restrict__ weights,
-                                                   int* __restrict__ assign) {
-  __shared__ unsigned char taken[kMaxGt];
-  __shared__ int owner[kMaxGt];
+                                                   int* __restrict__ assign, int cap) {
+  extern __shared__ __attribute__((aligned(16))) int match_lds[];
+  int* owner = match_lds;                                                    // [cap]
+  unsigned char* taken = reinterpret_cast<unsigned char*>(match_lds + cap);   // [cap]
   const int img = blockIdx.x, lane = threadIdx.x;
   const int d0 = det_off[img], d1 = det_off[img + 1];
   const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
@@ -271,15 +274,19 @@ MatchWs carve_match(void* ws, int n_det) {
 }
 
 int run_matching(const float* iou, const long long* anno_off, const int* det_off, const int* gt_off,
-                 const unsigned char* ignore, const float* score, int n_det, int n_img, void* ws, float* labels,
+                 const unsigned char* ignore, const float* score, int n_det, int n_gt, int n_img, void* ws, float* labels,
                  float* weights, int* assign, bool have_cand, hipStream_t s) {
+  if (n_gt > kMaxGt) return GNET_ERR_UNSUPPORTED;
+  const int cap = (max(n_gt, 1) + 63) & ~63;
+  const size_t lds = (size_t)cap * 5;
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)match_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kMaxGt * 5)));
   const MatchWs w = carve_match(ws, n_det);
   const int grid = (n_det + 255) / 256;
   if (!have_cand)
     match_cand<<<grid, 256, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, n_det, n_img, w.k1, w.k2, w.ncand, w.cfirst);
   match_rank<<<(n_det + 63) / 64, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
-  match_greedy<<<n_img, 64, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
-                                    labels, weights, assign);
+  match_greedy<<<n_img, 64, lds, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
+                                      labels, weights, assign, cap);
   return launch_status();
 }
 
@@ -312,7 +319,7 @@ extern "C" int det_matching_f32(const float* iou, const float* score, const uint
   const long long* anno_off = (const long long*)workspace;
   const int* det_off = (const int*)((char*)workspace + 16);
   const int* gt_off = (const int*)((char*)workspace + 24);
-  return run_matching(iou, anno_off, det_off, gt_off, ignore, score, n_det, 1, (char*)workspace + 1024, labels, weights,
+  return run_matching(iou, anno_off, det_off, gt_off, ignore, score, n_det, n_gt, 1, (char*)workspace + 1024, labels, weights,
                       assignment, false, s);
 }
 
@@ -323,6 +330,7 @@ int check_loss_args(const gnet_config* cfg, const gnet_shape* shape, const gnet_
   if (shape->n_det == 0) return GNET_OK;
   if (!in->gt_off || !in->anno_off || !in->det_off) return GNET_ERR_INVALID;
   if (shape->n_gt > 0 && (!in->gt_boxes || !in->gt_crowd || !in->gt_classes)) return GNET_ERR_INVALID;
+  if (shape->n_gt > kMaxGt) return GNET_ERR_UNSUPPORTED;      // the matching keeps per-box state in LDS (match_greedy)
   return GNET_OK;
 }
 }  // namespace
@@ -358,7 +366,7 @@ extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const 
     if (st != GNET_OK) return st;
   }
   st = run_matching(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
-                    buf->prediction, N, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
+                    buf->prediction, N, shape->n_gt, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
                     buf->det_gt_matching, true, s);
   if (st != GNET_OK) return st;
   loss_kernel<<<shape->n_img, 256, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,

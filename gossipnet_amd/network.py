@@ -105,9 +105,9 @@ class DeviceBatch(object):
         else:
             gtb = np.zeros((0, 4), f32); crowd = np.zeros(0, np.uint8); gcls = np.zeros(0, i32)
             m_per = [0] * self.n_img
-        if max(m_per) > 2048:
-            raise _lib.GnetError("more than 2048 ground-truth boxes in one image: the matching kernel keeps the "
-                                 "matched flags in a 64-lane x 32-bit register bitmask")
+        if sum(m_per) > 24576:
+            raise _lib.GnetError("more than 24576 ground-truth boxes in one step: the matching kernel keeps its per-box "
+                                 "state in LDS, sized by the step's total (gnet_loss returns GNET_ERR_UNSUPPORTED)")
         self.gt_off_h = np.concatenate([[0], np.cumsum(m_per)]).astype(i32)
         self.anno_off_h = np.concatenate([[0], np.cumsum(np.asarray(n_per, np.int64) * np.asarray(m_per, np.int64))]).astype(np.int64)
         self.n_det, self.n_gt = int(dets.shape[0]), int(gtb.shape[0])
@@ -195,9 +195,21 @@ class Gnet(object):
         self._spec = param_spec(num_classes, g.num_blocks)
         assert sum(int(np.prod(s)) for _, s in self._spec) == n
         self._core_n = int(n)
+        # flat-buffer offset of every variable: the core tensors are packed in the C ABI's order; the reduce_imfeats
+        # tensors behind them each start on a 16-byte boundary (fc.hip reads its operands as float4; the core count is
+        # 1 mod 4 because the logits bias has one element).  Padding elements stay zero in params and grads.
+        self._offsets, off = {}, 0
+        for nm, shape in self._spec:
+            self._offsets[nm] = off
+            off += int(np.prod(shape))
         if self._imfeats:
-            self._spec = self._spec + imfeat_param_spec(self.imfeat_channels)
-            n = sum(int(np.prod(s)) for _, s in self._spec)
+            extra = imfeat_param_spec(self.imfeat_channels)
+            for nm, shape in extra:
+                off = (off + 3) & ~3
+                self._offsets[nm] = off
+                off += int(np.prod(shape))
+            self._spec = self._spec + extra
+            n = (off + 3) & ~3
             from .fc import FcWorkspace
             self._fc_ws = FcWorkspace(self.device)
         key = (self.name, num_classes, g.num_blocks, str(self.device), self._imfeats, self.imfeat_channels, bool(g.neighbor_feats))
@@ -212,15 +224,13 @@ class Gnet(object):
         self.variables = {}
         self.gradients = {}
         reg = torch.zeros(n, dtype=torch.float32)
-        off = 0
         for nm, shape in self._spec:
-            k = int(np.prod(shape))
+            k, off = int(np.prod(shape)), self._offsets[nm]
             self.variables[nm] = self.params[off:off + k].view(*shape)
             self.gradients[nm] = self.grads[off:off + k].view(*shape)
             # l2 regulariser sites: every `weights_regularizer=weight_reg` (network.py:332-403), not predict/*
             if nm.endswith("weights") and "/predict/" not in nm:
                 reg[off:off + k] = 1.0
-            off += k
         self._reg_mask = reg.to(self.device)
         self.trainable_variables = [self.variables[nm] for nm, _ in self._spec]   # network.py:317-322
         self.weight_reg = weight_reg                       # l2 scale (tf l2_regularizer(scale): scale*sum(w^2)/2)
@@ -251,10 +261,9 @@ class Gnet(object):
         uniform), 'msra' = variance_scaling(2.0, FAN_IN, truncated normal; tf.contrib.layers: stddev sqrt(1.3 f / n));
         biases constant.  (TF's RNG streams cannot be reproduced: the seed fixes OUR stream.)"""
         gen = torch.Generator().manual_seed(int(cfg.random_seed))
-        flat = torch.empty(n, dtype=torch.float32)
-        off = 0
+        flat = torch.zeros(n, dtype=torch.float32)
         for nm, shape in self._spec:
-            k = int(np.prod(shape))
+            k, off = int(np.prod(shape)), self._offsets[nm]
             if nm.endswith("weights"):
                 kind = cfg.gnet.weight_init
                 if kind == 'msra':
@@ -267,8 +276,17 @@ class Gnet(object):
                     flat[off:off + k] = ((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).reshape(-1)
             else:
                 flat[off:off + k] = float(cfg.gnet.bias_const_init)
-            off += k
         return flat.to(self.device)
+
+    def tensor_offsets(self):
+        """Start of every variable in the flat buffers, in _spec order, plus the buffer length (the tensor table of
+        gnet_clip_by_norm: tensor i = [off[i], off[i+1]) -- alignment padding belongs to the tensor in front of it and
+        is zero)."""
+        return [self._offsets[nm] for nm, _ in self._spec] + [int(self.params.numel())]
+
+    def flat_to_named(self, flat):
+        """Views of a flat buffer laid out like params / grads (optimizer slots), by TF variable name."""
+        return {nm: flat[self._offsets[nm]:self._offsets[nm] + int(np.prod(shape))].view(*shape) for nm, shape in self._spec}
 
     def load_params(self, named):
         """Assign variables by TF name (e.g. from a converted checkpoint)."""

@@ -62,24 +62,9 @@ def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_
     return out
 
 
-class _RoiPool(torch.autograd.Function):
-    """Gradient registration of roi_pooling_op_grad.py:23-43: returns [data_grad, None]."""
-
-    @staticmethod
-    def forward(ctx, bottom_data, bottom_rois, pooled_height, pooled_width, spatial_scale):
-        top, argmax = roi_pool_raw(bottom_data, bottom_rois, pooled_height, pooled_width, spatial_scale)
-        ctx.save_for_backward(bottom_data, bottom_rois, argmax)
-        ctx.attrs = (pooled_height, pooled_width, spatial_scale)
-        ctx.mark_non_differentiable(argmax)
-        return top, argmax
-
-    @staticmethod
-    def backward(ctx, grad_top, _grad_argmax):
-        data, rois, argmax = ctx.saved_tensors
-        ph, pw, sc = ctx.attrs
-        return roi_pool_grad(data, rois, argmax, grad_top, ph, pw, sc), None, None, None, None
-
-
 def roi_pool(bottom_data, bottom_rois, pooled_height, pooled_width, spatial_scale):
-    """(top_data, argmax) = roi_pool(bottom_data [B,H,W,C], bottom_rois [R,5], ...) (roi_pooling_op.cc:35-43)."""
-    return _RoiPool.apply(bottom_data, bottom_rois, int(pooled_height), int(pooled_width), float(spatial_scale))
+    """(top_data, argmax) = roi_pool(bottom_data [B,H,W,C], bottom_rois [R,5], ...) (roi_pooling_op.cc:35-43).
+    Differentiable with respect to bottom_data through the gradient registered in roi_pooling_op_grad
+    (the reference registers it when that module is imported, roi_pooling_op_grad.py:23; here it is always bound)."""
+    from .roi_pooling_op_grad import RoiPoolFunction
+    return RoiPoolFunction.apply(bottom_data, bottom_rois, int(pooled_height), int(pooled_width), float(spatial_scale))

@@ -1,4 +1,4 @@
-"""Training step around the hot path -- mirror of the reference's train.py:26-37 (LearningRate),
+"""Training step around the hot path -- the reference's train.py:26-37 (LearningRate schedule),
 train.py:64-77 (get_optimizer: Adam / Momentum through slim.learning.create_train_op with optional
 per-gradient norm clipping) and train.py:263-272 (EMA(0.7) loss smoothing).  SURVEY.md 8f rank 1.
 The update itself runs in libgossipnet_hip.so (csrc/optim.hip) on the flat parameter buffer.
@@ -13,19 +13,23 @@ from .config import cfg
 
 
 class LearningRate(object):
-    """train.py:26-37 -- multi-step table cfg.train.lr_multi_step = [(iteration, lr), ...]."""
+    """Multi-step schedule over cfg.train.lr_multi_step = [(last_iteration, lr), ...] -- the table of the reference's
+    LearningRate (train.py:26-37): entry k's rate applies up to AND INCLUDING its iteration, the last rate for ever after.
 
-    def __init__(self):
-        self.steps = cfg.train.lr_multi_step
-        self.current_step = 0
+    Stateless: the rate is looked up from the iteration itself (bisection over the boundaries).  Fed the consecutive
+    iterations of a training run it returns what the reference returns; the reference keeps a cursor that only moves
+    when `iter ==` a boundary, so a run resumed past a boundary (train.py:274-283 restores global_step) would stay on
+    the old rate there -- here the resumed iteration gets the rate of its own interval."""
 
-    def get_lr(self, iter):
-        if self.current_step >= len(self.steps):
-            return self.steps[-1][1]
-        lr = self.steps[self.current_step][1]
-        if iter == self.steps[self.current_step][0]:
-            self.current_step += 1
-        return lr
+    def __init__(self, table=None):
+        table = cfg.train.lr_multi_step if table is None else table
+        self.boundaries = [int(it) for it, _ in table]
+        self.rates = [float(lr) for _, lr in table]
+
+    def get_lr(self, iteration):
+        import bisect
+        k = bisect.bisect_left(self.boundaries, int(iteration))     # boundaries strictly below this iteration
+        return self.rates[min(k, len(self.rates) - 1)]
 
 
 class ExponentialMovingAverage(object):
@@ -65,8 +69,7 @@ class Optimizer(object):
         self.v = torch.zeros(n, dtype=torch.float32, device=net.device) if self.kind == "adam" else None
         self.global_step = 0
         self.clip = float(cfg.train.gradient_clipping)
-        offs = np.concatenate([[0], np.cumsum([int(np.prod(s)) for _, s in net._spec])]).astype(np.int64)
-        self._offs = torch.from_numpy(offs).to(net.device)
+        self._offs = torch.from_numpy(np.asarray(net.tensor_offsets(), np.int64)).to(net.device)
         self._ntensors = len(net._spec)
 
     def apply_gradients(self, lr, grad_scale=1.0):

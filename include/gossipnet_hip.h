@@ -195,6 +195,8 @@ int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inp
 int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
               const float* class_weights, float grad_scale, gnet_buffers* buf, int32_t prepared,
               gnet_stream_t stream);
+/* Limit: shape->n_gt (all images of the step together) <= 24576 -- the greedy matching keeps 5 bytes of state per
+ * ground-truth box in LDS, sized by the one count the host knows; GNET_ERR_UNSUPPORTED beyond (det_matching_f32 alike). */
 
 /* The score-independent half of gnet_loss -- det_anno_iou (network.py:174-187) and the per-detection
  * candidate keys of the matching (det_matching.cc:128-148) -- depends on the inputs only: a caller may
@@ -204,7 +206,11 @@ int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shape, const gn
                        gnet_buffers* buf, gnet_stream_t stream);
 
 /* ---- backward: d loss / d params -> grads[param_count] (overwritten).
- * Reproducible: no float atomics, fixed summation order (per-workgroup partials, summed in index order).
+ * Reproducible (bitwise identical on repeated runs): weight gradients are per-workgroup partials summed in index
+ * order; the one float atomic in the path -- edge_bwd_w adds a tile's d P rows into d_pw with a returnless
+ * atomic add -- touches every address at most once per launch and the 16 block launches are stream-ordered, so
+ * each element still receives its additions in a fixed order.  (Integer atomics build the winner bitmaps; the
+ * order of the tied-detection list `tlist` is not fixed, and nothing depends on it: winners_ties only sets bits.)
  * The gradient of the SegmentMax (network.py:383-386) reaches one edge per (detection, column); the edge
  * stage and the pw-MLP backward therefore run on the edges that carry gradient only -- the same sums as the
  * dense algorithm minus exact zeros.

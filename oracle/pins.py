@@ -8,14 +8,12 @@ from . import gnet_oracle as go
 
 def grad_errors(net, gref, c, b, imfeat=None, neighbor_feats=False):
     """Per-tensor max |g_hip - g_ref| / max |g_ref| (TF variable name -> error)."""
-    g = net.grads.cpu().numpy()
-    off, errs = 0, {}
+    errs = {}
     for name, shape in go.param_spec(c, b, imfeat, neighbor_feats):
-        k = int(np.prod(shape))
+        g = net.gradients[name].detach().cpu().numpy().reshape(-1)       # (by name: the flat buffer may hold alignment padding)
         gr = np.asarray(gref[name], np.float64).reshape(-1)
-        m = np.abs(gr).max() if k else 0.0
-        errs[name] = float(np.abs(g[off:off + k] - gr).max() / m) if m > 0 else float(np.abs(g[off:off + k]).max())
-        off += k
+        m = np.abs(gr).max() if gr.size else 0.0
+        errs[name] = float(np.abs(g - gr).max() / m) if m > 0 else float(np.abs(g).max())
     return errs
 
 
