@@ -18,8 +18,11 @@ The JSON line also carries
                 against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) = `frac`; `reference_formulation`
                 = the same with the FLOPs of the reference's dense per-edge formulation, which a kernel can
                 exceed 1.0 on by not executing them; `traffic` = HBM bytes per launch from the separate rocprofv3
-                --pmc passes (profiles/r02_traffic.json), reported only while that file was collected from the same
-                kernel sources (hash), else null
+                --pmc passes (profiles/r03_traffic.json), reported only while that file was collected from the same
+                kernel sources (hash), else null; `mfma_busy` (per MFMA kernel, same file and gate) =
+                SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the launch's GRBM_GUI_ACTIVE cycles) of the --pmc pass
+  roi_pool      the RoiPool / RoiPoolGrad ops at the reference's shape (R=2000 rois, 38x63x1024 map, 7x7 bins):
+                compulsory bytes / HIP-event time vs 8 TB/s
   hbm           the HBM-bound kernel classes: algorithmic bytes per launch / average launch duration vs 8 TB/s
   executed      whole-step MFMA FLOPs really issued and their fraction of the fp32 MFMA peak
   other_configs the other BASELINE configurations and the reference's own step shape (1 image/step), measured
@@ -43,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def kernel_source_hash():
@@ -176,6 +179,42 @@ def time_config(dev, classes, blocks, dets, images, preset, steps, warmup, infer
             "mode": "inference (forward only)" if inference else "training step (fwd + loss + bwd)"}
 
 
+def roi_pool_bench(dev, R=2000, H=38, W=63, C=1024, P=7, iters=10):
+    """RoiPool / RoiPoolGrad (roi_pooling_op.cc:128-187, 374-449) at the reference's contract shape: the block3 feature map
+    of a ~600x1000 image at stride 16 ([1,38,63,1024]), R = 2000 enlarged detection windows, 7x7 bins.  Compulsory bytes:
+    forward = the map once + top and argmax written (R*49*C*8 B); backward = top_diff + argmax read + the map-sized
+    gradient written.  HIP events on the launch stream, mean of `iters` launches after 3 warm-ups."""
+    from gossipnet_amd.network import enlarge_windows, to_frcn_coords
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool_raw, roi_pool_grad
+    from gossipnet_amd.synthetic import make_image
+    g = torch.Generator(device="cpu").manual_seed(0)
+    fmap = torch.randn(1, H, W, C, generator=g).to(dev)
+    dets = torch.from_numpy(make_image(R, 80, seed=0)["dets"]).to(dev)
+    dets = dets * torch.tensor([W * 16 / 640.0, H * 16 / 480.0, W * 16 / 640.0, H * 16 / 480.0], device=dev)   # canvas -> image pixels
+    rois = to_frcn_coords(enlarge_windows(dets))
+    top, am = roi_pool_raw(fmap, rois, P, P, 1.0 / 16)
+    gtop = torch.randn(top.shape, generator=g).to(dev)
+    map_b, out_b = fmap.numel() * 4.0, top.numel() * 8.0
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+    res = {"shape": {"rois": R, "map": [1, H, W, C], "bins": [P, P]}, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    for name, fn, by in (("roi_pool_fwd", lambda: roi_pool_raw(fmap, rois, P, P, 1.0 / 16), map_b + out_b),
+                         ("roi_pool_bwd (reference order, bit-exact)", lambda: roi_pool_grad(fmap, rois, am, gtop, P, P, 1.0 / 16, True), map_b + out_b),
+                         ("roi_pool_bwd_atomic", lambda: roi_pool_grad(fmap, rois, am, gtop, P, P, 1.0 / 16, False), map_b + out_b)):
+        t = timed(fn)
+        res[name] = {"bytes": round(by), "us": round(t * 1e6, 1), "gb_per_s": round(by / t / 1e9, 1), "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +300,8 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0               # this rank's own K steps (before waiting for the others)
+    per_rank = None
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -272,12 +313,18 @@ def main():
         et = torch.tensor([E, N_local], dtype=torch.float64, device=dev)
         dist.all_reduce(et)
         e_total, dets_per_step = float(et[0].item()), int(et[1].item())
+        # every rank's own edge count and step time (before the max): shows load imbalance directly
+        mine_t = torch.tensor([float(E), float(N_local), own_elapsed / args.steps * 1e3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allr, mine_t)
+        per_rank = [{"rank": r_, "edges": int(v[0].item()), "dets": int(v[1].item()), "ms_per_step": round(float(v[2].item()), 4)}
+                    for r_, v in enumerate(allr)]
     else:
         e_total, dets_per_step = float(E), N_local
     value = dets_per_step * args.steps / elapsed
 
     roofline, hbm, executed = None, None, None
-    table, counts = {}, {}
+    table, counts, pmc = {}, {}, {}
     if not args.no_kernel_timing:
         timing = net.read_kernel_timing()
         table_steps = min(args.steps, 5)
@@ -306,8 +353,9 @@ def main():
                             [args.dets, args.images, args.classes, args.blocks, args.preset])
                     if same:
                         traffic = tf["kernels"].get(cls, {}).get("hbm_bytes")
+                        pmc = tf["kernels"]
                     else:
-                        note = "profiles/r02_traffic.json was collected from other kernel sources / another workload: not reported"
+                        note = "profiles/r03_traffic.json was collected from other kernel sources / another workload: not reported"
                 # `achieved` counts the FLOPs the algorithm needs in this kernel's formulation (= the MFMA FLOPs it issues:
                 # e.g. edge_fwd computes P.Wp + rc[c] + rn[n] per edge, the per-node products r.Wc / r.Wn live in
                 # node_fwd); the reference's dense per-edge formulation is reported beside it -- a kernel
@@ -328,13 +376,18 @@ def main():
         for k_ in ("edge_fwd", "pw_bwd_main", "pw_fwd", "edge_bwd"):
             if counts.get(k_):
                 e_ = executed_mfma_flops(k_, E, N_local, wpb, pw_rows)
-                n_ = 1 if k_ == "pw_fwd" else counts[k_]      # (the pw_fwd class also times the small edge_geometry launch)
+                n_ = counts[k_]
                 tf_ = e_ * n_ / (table[k_] * 1e-3) / 1e12
                 mfma_kernels[k_] = {"ms_per_step": round(table[k_], 4), "launches_per_step": n_,
                                     "mfma_flops_per_step": e_ * n_, "tflops": round(tf_, 2),
-                                    "frac": round(tf_ / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                    "frac": round(tf_ / FP32_MFMA_PEAK_TFLOPS, 4),
+                                    "mfma_busy": pmc.get(k_, {}).get("mfma_busy"),
+                                    "valu_per_mfma": pmc.get(k_, {}).get("valu_per_mfma")}
         if roofline is not None:
             roofline["mfma_kernels"] = mfma_kernels
+            roofline["mfma_busy"] = pmc.get(roofline["kernel"], {}).get("mfma_busy")
+            roofline["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per launch, from the separate rocprofv3 "
+                                          "--pmc pass (profiles/r03_traffic.json, same kernel sources); null = no current counters")
         # whole-step executed MFMA FLOPs
         ex_total = 0.0
         for k_, c_ in counts.items():
@@ -397,6 +450,10 @@ def main():
             oc["configs[3] dense N=10000 C=80, 1 image/step"] = time_config(dev, 80, 16, 10000, 1, "dense", 5, 2)
             oc["configs[2] N=2000 C=80, 8 images/step, INFERENCE (forward only, test.py:70)"] = time_config(dev, 80, 16, 2000, 8, "dense", 10, 3, inference=True)
             out["other_configs"] = oc
+        if world == 1 and not args.no_other_configs:
+            out["roi_pool"] = roi_pool_bench(dev)
+        if world > 1:
+            out["per_rank"] = per_rank
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(gen, args.classes, args.blocks, args.cpu_seconds)
         else:

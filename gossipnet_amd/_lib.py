@@ -48,7 +48,7 @@ _PB = C.c_void_p * (GNET_MAX_BLOCKS + 1)
 class gnet_buffers(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "edge_t", "edge_nz", "geo", "einfo", "pw_h1", "pw_h2",
                                            "pw_feats")] +
-                [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_rnb", "blk_h1", "blk_parg")] +
+                [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_rnb", "blk_h1", "blk_h2", "blk_parg")] +
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
                                            "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
                                            "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "tpos", "wrow", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +
@@ -62,7 +62,7 @@ EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_grap
            "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
-            "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials"]
+            "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials", "edge_geometry"]
 
 _lib = None
 

@@ -286,6 +286,7 @@ struct EdgeFwdArgs {
   const int* row_ptr;            // [N+1]
   const int* edge_nz;            // [E+64] neighbour index, n_det (a zero row of rn) for self pairs and the tail
   float* h1_out;                 // [E+64,64] relu(pw_fc1) (KEEP variant only: tests / debugging)
+  float* h2_out;                 // [E+64,64] h1.W2 + b2, the values the segment maximum is taken on (KEEP variant only)
   unsigned long long* parg;      // [N,64] (max bits << 32) | first edge attaining it (training), zeroed
 };
 
@@ -500,6 +501,12 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     // it is zero and only count >= 1 matters).
 #pragma unroll
     for (int r = 0; r < 16; ++r) { h2a[r] += bias0; h2b[r] += bias1; }
+    if (KEEP) {
+      // tests: the exact bits the maxima, tie counts and arg-max edges below are derived from (rows past E: slack)
+      float* dst = a.h2_out + (size_t)e0 * D_P + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dst[crow(r, half) * D_P] = h2a[r]; dst[crow(r, half) * D_P + 32] = h2b[r]; }
+    }
     // ---- wave-uniform segment loop
     unsigned hleft = heads;
     const bool whole = nseg == 1 && nrows == 32;       // one centre fills the tile: no row masks
@@ -881,7 +888,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.dets = (const float4*)in->dets; g.scores = in->det_scores; g.classes = in->det_classes;
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
     g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
-    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
+    GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
     a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.einfo = (const int4*)buf->einfo;
     a.w1 = params + L.pw1; a.b1 = params + L.pb1;
@@ -941,10 +948,11 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
         e.edge_nz = buf->edge_nz;
         e.h1_out = keep_h1 ? buf->blk_h1[b + 1] : nullptr;
+        e.h2_out = keep_h1 ? buf->blk_h2[b + 1] : nullptr;
         e.parg = training ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
         const int wg = ef_wg;
         if (keep_h1) {
-          if (!buf->blk_h1[b + 1]) return GNET_ERR_INVALID;                  // planned without training == 2
+          if (!buf->blk_h1[b + 1] || !buf->blk_h2[b + 1]) return GNET_ERR_INVALID;   // planned without training == 2
           GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<true, true><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e));
         } else if (training) { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<true, false><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }
         else { GNET_LAUNCH(prof, GNET_K_EDGE_FWD, s, edge_fwd_w<false, false><<<wg, 64 * EFW_WAVES, kEdgeFwdWSmem, s>>>(e)); }

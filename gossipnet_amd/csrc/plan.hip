@@ -57,7 +57,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.blk_parg[k] = b.blk_pm[k] + Np * D_P;
       b.blk_q[k] = c.take<float>(Np * D_P);
       if (cfg->neighbor_feats) b.blk_rnb[k] = c.take<float>(Np * D_R);
-      if (training == 2) b.blk_h1[k] = c.take<float>(Ep * D_P);     // tests / debugging only
+      if (training == 2) { b.blk_h1[k] = c.take<float>(Ep * D_P); b.blk_h2[k] = c.take<float>(Ep * D_P); }   // tests / debugging only
     }
     b.head1 = c.take<float>(Np * D_HEAD);
     b.head2 = c.take<float>(Np * D_HEAD);

@@ -104,6 +104,7 @@ typedef struct gnet_buffers {
   float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
   float* blk_rnb[GNET_MAX_BLOCKS + 1];     /* [n_det,32]  relu(reduce_dim_neighbor) (neighbor_feats, training)   */
   float* blk_h1[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] relu(pw_fc1) per edge -- only when planned with training == 2 (tests / debugging: the backward pass recomputes the rows it needs) */
+  float* blk_h2[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] pw_fc2 pre-activation (h1.W2 + b2) per edge, the bits the segment maximum was taken on -- only when planned with training == 2 (tests: the winner records are checked against it exactly) */
   uint64_t* blk_parg[GNET_MAX_BLOCKS + 1]; /* [n_det,64] (segment-max bits << 32) | index of the first edge that attains it (training) */
   float* head1;       /* [n_det,128] predict/fc1 */
   float* head2;       /* [n_det,128] predict/fc2 */
@@ -287,7 +288,7 @@ int roi_pool_bwd_atomic_f32(const float* top_diff, const int32_t* argmax, const 
 enum {
   GNET_K_GRAPH = 0, GNET_K_PACK, GNET_K_PW_FWD, GNET_K_NODE_FWD, GNET_K_EDGE_FWD, GNET_K_LOSS,
   GNET_K_HEAD_BWD, GNET_K_WINNERS, GNET_K_EDGE_BWD, GNET_K_GATHER, GNET_K_NODE_BWD, GNET_K_PW_BWD,
-  GNET_K_W1_SUMS, GNET_K_W1_CLASS, GNET_K_REDUCE, GNET_KCLASS_COUNT
+  GNET_K_W1_SUMS, GNET_K_W1_CLASS, GNET_K_REDUCE, GNET_K_GEOMETRY, GNET_KCLASS_COUNT
 };
 int gnet_profiler_create(int32_t capacity, uint32_t class_mask, void** out);
 int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count);

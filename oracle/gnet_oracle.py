@@ -254,8 +254,10 @@ class _PinnedSegmentMaxRelu(torch.autograd.Function):
         return weighted[ids] * self_f, None, None, None
 
 
-def _fc(x, params, scope, relu, stats=None, pin=None):
+def _fc(x, params, scope, relu, stats=None, pin=None, pre=None):
     y = x @ params[scope + "/weights"] + params[scope + "/biases"]
+    if pre is not None:
+        pre.append(y.detach().numpy())
     if relu and stats is not None and y.numel():
         stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float(y.detach().abs().min()))
     if relu and pin is not None:
@@ -375,10 +377,14 @@ class GnetOracle:
         # _pw_feats_fc network.py:324-342
         pin = (lambda key, i: None) if pins is None else (lambda key, i: torch.as_tensor(np.asarray(pins[key][i])))
         own = {"pw": [], "r": [], "rn": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}   # this forward's own smooth piece (keep=True)
+        # ... and the pre-activations behind every mask of it (keep=True): how far each unit is from its kink.  "sel"
+        # holds the pw_fc2 pre-activations (the segment maximum is taken on their rectified values).
+        pre = {k_: [] for k_ in own}
+        rec = (lambda key: pre[key]) if (keep and pins is None) else (lambda key: None)
         note = (lambda key, t: own[key].append((t.detach() > 0).numpy())) if keep else (lambda key, t: None)
         note_im = lambda t: note("im", t)
         for i in range(1, NUM_PWFEAT_FC + 1):
-            f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats, pin("pw", i - 1))
+            f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats, pin("pw", i - 1), rec("pw"))
             note("pw", f)
         pw = f
         out["pw_feats"] = pw
@@ -401,26 +407,26 @@ class GnetOracle:
             x = torch.from_numpy(roifeats.reshape(N, -1)).to(self.dtype)
             scopes = sorted({n_.rsplit("/", 1)[0] for n_ in P if n_.startswith("gnet/reduce_imfeats/")})
             for li, sc in enumerate(scopes):                    # fully_connected, fully_connected_1
-                x = _fc(x, P, sc, True, stats, pin("im", li))
+                x = _fc(x, P, sc, True, stats, pin("im", li), rec("im"))
                 note_im(x)
         block_feats = [x]
         is_id = (c_idx == n_idx).view(-1, 1)
         for b in range(1, self.num_blocks + 1):             # _block network.py:344-409
             s = "gnet/block%d/" % b
-            r = _fc(x, P, s + "reduce_dim", True, stats if b > 1 else None, pin("r", b - 1))
+            r = _fc(x, P, s + "reduce_dim", True, stats if b > 1 else None, pin("r", b - 1), rec("r"))
             note("r", r)
             cf = r[c_idx]
             if self.neighbor_feats:                      # network.py:356-365: a second reduce FC for the neighbour side
-                rnb = _fc(x, P, s + "reduce_dim_neighbor", True, stats if b > 1 else None, pin("rn", b - 1))
+                rnb = _fc(x, P, s + "reduce_dim_neighbor", True, stats if b > 1 else None, pin("rn", b - 1), rec("rn"))
                 note("rn", rnb)
             else:
                 rnb = r
             nf = torch.where(is_id, torch.zeros((), dtype=self.dtype), rnb[n_idx])
             h = torch.cat([pw, cf, nf], 1)
-            h = _fc(h, P, s + "pw_fc1", True, stats, pin("h1", b - 1))
+            h = _fc(h, P, s + "pw_fc1", True, stats, pin("h1", b - 1), rec("h1"))
             note("h1", h)
             if pins is None:
-                h = _fc(h, P, s + "pw_fc2", True, stats)
+                h = _fc(h, P, s + "pw_fc2", True, stats, None, rec("sel"))
                 if stats is not None:
                     stats["max_gap"] = min(stats.get("max_gap", float("inf")), _segmax_gap(h, c_idx, N))
                 p = _SegmentMax.apply(h, c_idx, N)
@@ -429,17 +435,20 @@ class GnetOracle:
             else:
                 h = _fc(h, P, s + "pw_fc2", False)
                 p = _PinnedSegmentMaxRelu.apply(h, c_idx, N, pin("sel", b - 1))
-            q = _fc(p, P, s + "fc1", True, stats, pin("q", b - 1))
+            q = _fc(p, P, s + "fc1", True, stats, pin("q", b - 1), rec("q"))
             note("q", q)
             y = _fc(q, P, s + "fc2", False)
             if stats is not None and N:
                 stats["relu_margin"] = min(stats.get("relu_margin", float("inf")), float((x + y).detach().abs().min()))
+            if keep and pins is None:
+                pre["x"].append((x + y).detach().numpy())
             x = torch.relu(x + y) if pins is None else _PinnedRelu.apply(x + y, pin("x", b - 1))
             note("x", x)
             block_feats.append(x)
         out["block_feats"] = block_feats
         if keep and pins is None:
             out["pins"] = own
+            out["pre"] = pre
         h = x                                                 # head network.py:258-273
         h = _fc(h, P, "gnet/predict/fc1/fully_connected", False)
         h = _fc(h, P, "gnet/predict/fc2/fully_connected", False)

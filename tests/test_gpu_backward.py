@@ -14,6 +14,7 @@ import torch
 
 from oracle import gnet_oracle as go
 from tests.util import make_pair, rel_err, make_image, grad_errors, gpu_pins
+from oracle.pins import mask_disagreements, winner_records_exact
 
 pytestmark = pytest.mark.gpu
 
@@ -37,31 +38,133 @@ def check_outputs(net, ref):
     assert abs(float(net.loss_normed) - float(ref["loss_normed"])) <= 1e-5 * max(1.0, abs(float(ref["loss_normed"])))
 
 
+KINK = 2e-6       # a mask may differ from the oracle's own only where the oracle is this close (x layer scale) to the kink.
+                  # Measured on MI355X (profiles/r03_kinks.txt): <= 2.7e-7 over every test of this file, the headline image
+                  # (33 differing entries of 3.7e8) included; a wrong winner rule is off by the size of the activations.
+
+
+# kink-free seeds (of 6) measured on MI355X per case, minus one (a change of a kernel's summation order may move a unit
+# across its kink); the count is deterministic for fixed kernels.  Filled from the run recorded in profiles/r03_kinks.txt.
+KINK_FREE_MIN = {(6, 1, 1, 0.01): 5, (6, 1, 1, 0.5): 5, (20, 1, 1, 0.01): 5, (20, 1, 1, 0.5): 5, (33, 1, 2, 0.01): 4, (33, 1, 2, 0.5): 5,
+                 (64, 1, 2, 0.01): 5, (64, 1, 2, 0.5): 4, (64, 80, 1, 0.01): 3, (64, 80, 1, 0.5): 4, (64, 80, 2, 0.01): 1,
+                 (64, 80, 2, 0.5): 3, (200, 1, 1, 0.01): 4, (200, 1, 1, 0.5): 4, (150, 80, 3, 0.01): 4, (150, 80, 3, 0.5): 5}
+
+
+def kink_report(net, ref, image=None):
+    """(n_diff, worst, where) of oracle.pins.mask_disagreements for the HIP forward pass against the oracle's own."""
+    return mask_disagreements(gpu_pins(net, image), ref)
+
+
 @pytest.mark.parametrize("bias", [0.01, 0.5])
 @pytest.mark.parametrize("n,c,b", [(6, 1, 1), (20, 1, 1), (33, 1, 2), (64, 1, 2), (64, 80, 1), (64, 80, 2), (200, 1, 1),
                                    (150, 80, 3)])
 def test_backward_parity_small(n, c, b, bias):
-    """bias 0.01 = the experiments' init (ReLU pre-activations near 0 do occur); bias 0.5 keeps most units
-    active.  Every seed, every parameter tensor: <= 1e-5 against the oracle on the same smooth piece; the
-    unpinned comparison may only differ where a kink was crossed (its outliers vanish under pinning)."""
+    """bias 0.01 = the experiments' init (ReLU pre-activations near 0 do occur); bias 0.5 keeps most units active.
+    Three assertions per seed, none of which takes the device's word for the smooth piece:
+      1. the device's ReLU masks and SegmentMax winner sets equal the oracle's OWN, except at entries where the oracle's
+         own pre-activation (or its distance from the segment maximum) is within KINK of the kink -- a winner rule that
+         picked a non-maximal edge or dropped a tied one fails here;
+      2. when no entry differs at all, the UNPINNED gradient comparison must be tight for every tensor;
+      3. on the device's piece (the oracle differentiating the masks of 1.) every tensor agrees to 1e-5.
+    Most seeds are kink-free (measured on MI355X: see the assertion at the end)."""
     cw = np.linspace(0.5, 1.5, c + 1).astype(np.float32)
     net, orc = make_pair(c, b, class_weights=cw, bias=bias)
     net.keep_edge_activations = True
-    n_tight = 0
+    n_free, worst_all = 0, 0.0
     for seed in range(6):
         batch = make_image(n, c, seed=seed)
-        ref, gref = orc.forward_backward(batch)
+        ref, gref = orc.forward_backward(batch, keep=True)
         net.run(batch)
         torch.cuda.synchronize()
         check_outputs(net, ref)
         assert not np.isnan(net.grads.cpu().numpy()).any()
+        n_diff, worst, where = kink_report(net, ref)
+        assert worst <= KINK, (seed, n_diff, worst, where)
+        worst_all = max(worst_all, worst)
         unpinned = grad_errors(net, gref, c, b)
+        if n_diff == 0:
+            assert max(unpinned.values()) <= TIGHT, (seed, max(unpinned.items(), key=lambda kv: kv[1]))
+            n_free += 1
         pinned = pinned_errors(net, orc, batch, c, b)
         assert max(pinned.values()) <= PINNED, (seed, max(pinned.items(), key=lambda kv: kv[1]))
-        outliers = [k for k, v in unpinned.items() if v > TIGHT]
-        assert all(pinned[k] <= PINNED for k in outliers)
-        n_tight += not outliers
-    assert n_tight >= 1      # kink crossings are the exception, not the rule
+    print("kink-free seeds: %d / 6, worst distance from a kink at a differing mask entry %.2e  (n=%d c=%d b=%d bias=%g)"
+          % (n_free, worst_all, n, c, b, bias))
+    assert n_free >= KINK_FREE_MIN.get((n, c, b, bias), 0)
+
+
+def first_winner_only(sel, c_idx):
+    """The winner sets a WRONG implementation would use: of every (detection, column)'s tied edges only the first."""
+    sel = np.asarray(sel)
+    out = np.zeros_like(sel)
+    e, j = np.nonzero(sel)
+    key = c_idx[e].astype(np.int64) * sel.shape[1] + j
+    _, first = np.unique(key, return_index=True)             # (e ascending within equal keys: nonzero() is row-major)
+    out[e[first], j[first]] = True
+    return out
+
+
+@pytest.mark.parametrize("c,bias", [(80, 0.5), (1, 0.5), (80, 0.01)])
+def test_tied_columns_split_evenly_across_distinct_edges(c, bias):
+    """SegmentMax ties between edges with DIFFERENT inputs (TF _SegmentMinOrMaxGrad: every tied edge receives
+    grad / count; network.py:387-388).  Two columns of pw_fc2 get zero weights and a positive bias in both blocks, so
+    that EVERY edge of a detection ties on them (h2[:, j] = b2[j] exactly) while the pw_fc1 rows behind the edges all
+    differ: d W2[:, j] = sum_e h1[e] * dp[c_e, j] / degree(c_e) under the even split, but h1[first edge] * dp[c, j] under
+    a first-winner rule -- the parameter gradients now tell the two apart (with duplicated detections they cannot).
+    The oracle differentiates ITS OWN winner sets (nothing read back from the device's tie records)."""
+    b, n = 2, 48
+    tied = (5, 40)                                              # one column in each 32-column half of the MFMA tile
+    net, orc = make_pair(c, b, bias=bias)
+    net.keep_edge_activations = True
+    with torch.no_grad():
+        for blk in (1, 2):
+            for j in tied:
+                net.variables["gnet/block%d/pw_fc2/weights" % blk][:, j] = 0.0
+                net.variables["gnet/block%d/pw_fc2/biases" % blk][j] = 0.25 + 0.5 * blk
+                orc.params["gnet/block%d/pw_fc2/weights" % blk].data[:, j] = 0.0
+                orc.params["gnet/block%d/pw_fc2/biases" % blk].data[j] = 0.25 + 0.5 * blk
+    names = ["gnet/block%d/pw_fc2/weights" % k for k in (1, 2)] + ["gnet/block%d/pw_fc2/biases" % k for k in (1, 2)]
+    for seed in range(4):
+        batch = make_image(n, c, seed=seed)
+        ref, gref = orc.forward_backward(batch, keep=True)
+        c_idx = ref["neighbor_pair_idxs"][:, 0]
+        deg = np.bincount(c_idx, minlength=n)
+        assert (deg > 1).sum() >= n // 2, "the image must have neighbours"
+        for blk in (0, 1):                                      # the oracle sees the ties: every edge, both columns
+            assert ref["pins"]["sel"][blk][:, list(tied)].all()
+        net.run(batch)
+        torch.cuda.synchronize()
+        check_outputs(net, ref)
+        # the device's tie records against numpy reductions of the values its own kernel saw: exact
+        for blk in (1, 2):
+            H = winner_records_exact(net, blk)
+            assert rel_err(H, ref["pre"]["sel"][blk - 1]) < 1e-5
+            pm = net.debug_view("blk_pm", n * 64, dtype=torch.int64, index=blk).view(n, 64).cpu().numpy()
+            assert np.array_equal((pm & 0xffffffff)[:, list(tied)], np.stack([deg, deg], 1)), "tie count = degree"
+        n_diff, worst, where = kink_report(net, ref)
+        assert worst <= KINK, (seed, n_diff, worst, where)
+        # (1) ReLU masks from the device, winner sets the ORACLE'S OWN: every tensor, in particular the tied columns
+        pins = gpu_pins(net)
+        pins["sel"] = ref["pins"]["sel"]
+        _, g_own_sel = orc.forward_backward(batch, pins=pins)
+        errs = grad_errors(net, g_own_sel, c, b)
+        assert max(errs.values()) <= PINNED, (seed, max(errs.items(), key=lambda kv: kv[1]))
+        dev = {k: net.gradients[k].cpu().numpy() for k in names}
+        for k in names[:2]:
+            for j in tied:
+                col, want = dev[k][:, j], g_own_sel[k][:, j]
+                assert np.abs(col - want).max() <= PINNED * np.abs(g_own_sel[k]).max(), (seed, k, j)
+        # (2) fully unpinned whenever no mask differs
+        if n_diff == 0:
+            unp = grad_errors(net, gref, c, b)
+            assert max(unp.values()) <= TIGHT, (seed, max(unp.items(), key=lambda kv: kv[1]))
+        # (3) the test discriminates: a first-winner rule gives a DIFFERENT d W2 in the tied columns (and would fail (1))
+        wrong = dict(pins)
+        wrong["sel"] = [first_winner_only(sel_, c_idx) for sel_ in ref["pins"]["sel"]]
+        _, g_first = orc.forward_backward(batch, pins=wrong)
+        gap = max(np.abs(g_first[k][:, j] - g_own_sel[k][:, j]).max() / np.abs(g_own_sel[k]).max() for k in names[:2] for j in tied)
+        assert gap > 100 * PINNED, "first-winner and even split must differ here (else the test proves nothing): %g" % gap
+        bad = max(np.abs(dev[k][:, j] - g_first[k][:, j]).max() / np.abs(g_own_sel[k]).max() for k in names[:2] for j in tied)
+        assert bad > 100 * PINNED
 
 
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 65, 95, 129, 257])
@@ -111,6 +214,12 @@ def test_headline_config_single_image():
     bf = net.block_feats
     for k in range(1, b + 1):
         assert rel_err(bf[k].cpu().numpy(), ref["block_feats"][k].detach().numpy()) < 1e-5, "block %d" % k
+    n_diff, worst, where = kink_report(net, ref)
+    print("headline image: %d mask entries differ from the oracle's own, worst distance %.2e at %s" % (n_diff, worst, where))
+    assert worst <= KINK, (n_diff, worst, where)
+    for blk in (1, 8, 16):
+        H = winner_records_exact(net, blk)
+        assert rel_err(H, ref["pre"]["sel"][blk - 1]) < 1e-5
     pinned = pinned_errors(net, orc, batch, c, b)
     assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
 
@@ -273,12 +382,16 @@ def test_exact_ties_from_duplicate_detections():
         batch = dict(base)
         for k in ("dets", "det_scores", "det_classes"):
             batch[k] = base[k][rep]
-        ref, gref = orc.forward_backward(batch)
+        ref, gref = orc.forward_backward(batch, keep=True)
         net.run(batch)
         torch.cuda.synchronize()
         pm = net.debug_view("blk_pm", 180 * 64, dtype=torch.int64, index=1).cpu().numpy()
         assert (((pm & 0xffffffff) > 1) & ((pm >> 32) > 0)).any(), "test must contain positive ties"
         assert rel_err(net.prediction.cpu().numpy(), ref["prediction"].detach().numpy()) < 1e-5
+        for blk in (1, 2):                                  # tie records vs the values the kernel saw: exact
+            winner_records_exact(net, blk)
+        n_diff, worst, where = kink_report(net, ref)        # ... and vs the oracle's own winner sets
+        assert worst <= KINK, (seed, n_diff, worst, where)
         pinned = pinned_errors(net, orc, batch, 80, 2)
         assert max(pinned.values()) <= PINNED, (seed, max(pinned.items(), key=lambda kv: kv[1]))
 

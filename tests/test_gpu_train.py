@@ -103,6 +103,65 @@ if use_dist: dist.destroy_process_group()
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
 
 
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path):
+    """N > 1 on the PRODUCT path before an 8-GPU node ever runs it: two processes share cuda:0 under a `gloo` group
+    (it accepts device tensors); each runs train_step(net, opt, shard, lr, dist=dist) on its LPT-by-edge-count shard of
+    a 5-image global step -- HIP gradients into the flat buffer, ONE all-reduce, grad_scale = 1 / images of the step,
+    reg_scale = 1 / world, parameters broadcast from rank 0 -- and after two optimizer steps both replicas hold the
+    parameters of the single-process run over all five images (reduction order differs: <= 1e-6 relative)."""
+    import subprocess, sys, os, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.network import Gnet
+from gossipnet_amd.synthetic import make_image
+from gossipnet_amd.train import Optimizer, train_step
+from gossipnet_amd.data_parallel import broadcast_parameters, shard_images
+out, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+dist = None
+torch.cuda.set_device(0)
+if world > 1:
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+reset_cfg(); cfg.gnet.num_blocks = 3
+cfg.train.optimizer = "sgd"                     # momentum update: linear in the gradient (Adam's g / sqrt(v) turns a
+                                                # 1e-7 reduction-order difference of a cancelling sum into a visible step)
+cfg.random_seed = 42 + rank                     # replicas start DIFFERENT: the broadcast must make them equal
+net = Gnet(80, weight_reg=0.0005)
+if world > 1: broadcast_parameters(net.params, dist, src=0)
+opt = Optimizer(net)
+imgs = [make_image(n, 80, seed=s) for n, s in ((150, 0), (90, 1), (200, 2), (60, 3), (120, 4))]
+costs = [float(Gnet.count_edges(im["dets"], "cuda:0")) for im in imgs]
+mine = shard_images(imgs, rank, world, costs=costs)
+assert 1 <= len(mine) < len(imgs) or world == 1
+net.grad_scale = 1.0 / len(imgs)
+for it in range(2):
+    train_step(net, opt, mine, 1e-2, dist=dist)
+torch.cuda.synchronize()
+np.save(out, net.params.cpu().numpy())
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+""" % root
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = str(s_.getsockname()[1]); s_.close()
+    single = str(tmp_path / "single.npy")
+    subprocess.run([sys.executable, "-c", script, single, "0", "1", port], check=True, cwd=root, timeout=600)
+    files = [str(tmp_path / ("r%d.npy" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", script, files[r], str(r), "2", port], cwd=root) for r in range(2)]
+    for p_ in procs:
+        assert p_.wait(timeout=600) == 0
+    want = np.load(single)
+    r0, r1 = np.load(files[0]), np.load(files[1])
+    assert np.array_equal(r0, r1), "replicas hold identical parameters after the all-reduce"
+    assert np.isfinite(want).all() and np.abs(r0 - want).max() <= 1e-6 * np.abs(want).max()
+    from gossipnet_amd.config import reset_cfg
+    reset_cfg()
+    start = make_pair(80, 3)[0]            # (same seed-42 initialisation as rank 0: the steps did move the parameters)
+    assert np.abs(want - start.params.cpu().numpy()).max() > 1e-4
+
+
 def test_checkpoint_round_trip_tf_bundle(tmp_path):
     """save(fmt="tf") writes a Saver V2 bundle keyed by the TF variable names (+ Adam slots, global_step); load() restores
     it into a fresh Gnet / Optimizer: same parameters, same next step."""
