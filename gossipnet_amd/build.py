@@ -9,6 +9,8 @@ LIB = os.path.join(HERE, "libgossipnet_hip.so")
 SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "fc.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
+if os.environ.get("GNET_TRACE"):          # measurement build with per-workgroup time stamps (tools/wg_trace.py); never shipped
+    FLAGS = FLAGS + ["-DGNET_TRACE"]
 
 
 def _hipcc():
@@ -41,9 +43,11 @@ def build(force=False, verbose=False):
     """Compiles what changed and links the library.  Concurrent callers (one process per GPU) are serialised by an
     exclusive lock on csrc/build/.lock; a caller that waited finds the library current and returns."""
     import fcntl
-    objdir = os.path.join(CSRC, "build")
+    import hashlib
+    # objects of different flag sets (the GNET_TRACE measurement build) never mix: one directory per flag set
+    objdir = os.path.join(CSRC, "build", hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:8])
     os.makedirs(objdir, exist_ok=True)
-    with open(os.path.join(objdir, ".lock"), "w") as lock:
+    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and _up_to_date():

@@ -192,6 +192,7 @@ struct BlkNodeArgs {
   long long o_w4, o_b4, o_w3, o_b3;
   float* d_x; float* d_pc;
   float* arena; long long stride;
+  GNET_TRACE_FIELD
 };
 
 constexpr int BN_FLOATS = 2 * 32 * LD128 + 2 * 32 * LD64 + 3 * 32 * LD32 + 4 * 32 * 32;   // X, DZ, Rc|Rn, Rr|Dr, Rrn, Part
@@ -205,7 +206,15 @@ __device__ __forceinline__ int bn_winner_pos(const unsigned long long* __restric
 
 __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ g1c, const int* __restrict__ row_ptr,
                                                       const int* __restrict__ wrow, const int* __restrict__ tpos,
-                                                      int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn) {
+                                                      int n_det, float* __restrict__ d_rc, float* __restrict__ d_rn
+#ifdef GNET_TRACE
+                                                      , unsigned long long* trace_ptr
+#endif
+) {
+#ifdef GNET_TRACE
+  const struct { unsigned long long* trace; } tr = {trace_ptr};
+#endif
+  GSTAMP(tr, 0);
   const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= n_det) return;
   const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
@@ -228,6 +237,7 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 4; ++q) { sc.x = fmaf(w[q], c[q].x, sc.x); sc.y = fmaf(w[q], c[q].y, sc.y); sc.z = fmaf(w[q], c[q].z, sc.z); sc.w = fmaf(w[q], c[q].w, sc.w); }
   }
+  GSTAMP(tr, 1);
   for (int base = eb; base < ee; base += 64) {
     const int el = base + lane;
     int tp = -1;                                            // list position of the reversed pair, if it is a winner
@@ -259,6 +269,7 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
     *reinterpret_cast<float4*>(d_rc + (size_t)node * D_P + 4 * f4) = sc;
     *reinterpret_cast<float4*>(d_rn + (size_t)node * D_P + 4 * f4) = sn;
   }
+  GSTAMP(tr, 15);
 }
 
 // acc += X^T . Y over the 32 rows of a tile (weight-gradient shape), X / Y already offset to the lane's column: all 32
@@ -322,6 +333,7 @@ __device__ __forceinline__ void load_node_mid(NodeTileMid& m, const BlkNodeArgs&
 template <bool NF>
 __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  GSTAMP(a, 0);
   const int tid = threadIdx.x, lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   float* sX = smem;                          // [32][132] x_prev (= block_feats[b-1])
@@ -376,6 +388,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
     // the next tile of this workgroup is requested now and lands while this one is computed
     if (t + (int)gridDim.x < ntiles) load_node_tile<NF>(in, a, (t + gridDim.x) * 32, tid);
     __syncthreads();
+    GSTAMP(a, 1);
     if (a.do_pre) {
       // dr = drc . Wc^T + drn . Wn^T : role = (term, K half)
       {
@@ -432,6 +445,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
       }
       __syncthreads();
     }
+    GSTAMP(a, 2);
     if (a.do_post) {
       // dz = d_x * (x_out > 0): also the shortcut gradient of block b-1 (network.py:407-408)
       {
@@ -506,6 +520,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         }
       }
     }
+    GSTAMP(a, 3);
   }
   // ---- partial weight gradients of this workgroup
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
@@ -536,6 +551,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
     store_acc(ar + a.o_w4 + (size_t)32 * D_S + 32 * cw, D_S, aW4b, lane);
     store_acc(ar + a.o_w3 + (size_t)(32 * (cw >> 1)) * D_P + 32 * (cw & 1), D_P, aW3, lane);
   }
+  GSTAMP(a, 15);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1007,7 +1023,11 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     if (b <= B && E > 0) {
       GNET_LAUNCH(prof, GNET_K_GATHER, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
           buf->d_g1, buf->row_ptr, buf->wrow + (size_t)(b - 1) * G.tf_stride, buf->tpos + (size_t)(b - 1) * G.wl_stride, N,
-          buf->d_rc, buf->d_rn));
+          buf->d_rc, buf->d_rn
+#ifdef GNET_TRACE
+          , b == B / 2 ? gnet_trace_ptr("GNET_TRACE_GATHER") : nullptr
+#endif
+          ));
     }
     n.x_prev = b >= 2 ? buf->block_feats[b - 1] : buf->start_feat;
     if (b <= B) {
@@ -1025,6 +1045,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       n.o_w4 = K.w4; n.o_b4 = K.b4; n.o_w3 = K.w3; n.o_b3 = K.b3;
     } else { n.q = nullptr; n.pm = nullptr; n.w4 = n.w3 = nullptr; n.o_w4 = n.o_b4 = n.o_w3 = n.o_b3 = 0; }
     n.d_x = buf->d_x; n.d_pc = buf->d_pc; n.arena = buf->arena; n.stride = stride;
+    GNET_TRACE_SET(n, "NODE_BWD", b == B / 2);
     if (cfg->neighbor_feats) { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<true><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
     else { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<false><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
     // edge stage of block b-1

@@ -365,7 +365,44 @@ struct EdgeBwdWArgs {
   float* g1c;                       // [W,64] g1 of the winner rows, list order
   float* arena; long long stride;
   long long o_w1, o_w2, o_b2;
+  GNET_TRACE_FIELD
 };
+
+// Top of an edge_bwd_w tile: edge ids and the bias tile rc[c] + rn[n] (the forward kernel's operand order) into the wave's
+// LDS area, then h1 = relu(P . Wp + bias) with the forward kernel's operation sequence (same bits), in place.
+// x / y = the sixteen gathered bias-row chunks (lane = (row 4 i + q4, chunk f4)), pa = the lane's P row (A layout).
+__device__ __forceinline__ void ebw_stage_h1(float* sH, int* sE, const float* sWpT, const float4 (&x)[8], const float4 (&y)[8],
+                                             const f32x4 (&pa)[4], int my_e, int lane) {
+  const int col = lane & 31, half = lane >> 5, q4 = lane >> 4, f4 = lane & 15;
+  if (half == 0) sE[col] = my_e;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    *reinterpret_cast<float4*>(sH + (4 * i + q4) * (D_P + 4) + 4 * f4) =
+        make_float4(x[i].x + y[i].x, x[i].y + y[i].y, x[i].z + y[i].z, x[i].w + y[i].w);
+  wave_lds_sync();
+  f32x16 h1a, h1b;
+  float* hp = sH + (4 * half) * (D_P + 4) + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { h1a[r] = hp[crow(r, 0) * (D_P + 4)]; h1b[r] = hp[crow(r, 0) * (D_P + 4) + 32]; }
+  const float* b0 = sWpT + col * (D_E + 4) + 4 * half;
+  const float* b1 = b0 + 32 * (D_E + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x4 av = pa[k];
+    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
+    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { hp[crow(r, 0) * (D_P + 4)] = relu_bits(h1a[r]); hp[crow(r, 0) * (D_P + 4) + 32] = relu_bits(h1b[r]); }
+}
 
 constexpr int EBW_WAVES = 4;
 constexpr int EBW_SLOTS = 3;                                    // detections of a tile handled between two LDS hand-offs
@@ -391,6 +428,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sWpT = smem;                          // [64][36]  Wp^T[f][pf]: B operand of h1 (16-byte reads along pf)
   float* sW2 = sWpT + D_P * LD32;              // [64][68]  W2[f][j]:    B operand of g1 (16-byte reads along j)
+  GSTAMP(a, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* sH = sW2 + D_P * LD64 + wave * EBW_WAVE_FLOATS;   // [32][68] bias -> h1 -> g1 of this wave's tile
   int* sE = reinterpret_cast<int*>(sH + 32 * LD64);        // [32] edge of every tile row
@@ -440,79 +478,66 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     apB = a.apos[ob_]; dvB = a.d_pc[ob_]; tfB = a.tflag[max(cB_, 0)];                                   \
     apC = a.apos[oc_]; dvC = a.d_pc[oc_]; tfC = a.tflag[max(cC_, 0)];                                   \
   } while (0)
-  // the first tile's chain of dependent requests (list -> rows -> column records) runs beside the staging of the
-  // weights, not after it
-  if (t0 < t1) {
-    EBW_LOAD_LIST(t0);
+  // bias rows (rc[c] | rn[n], lane = (row 4 i + q4, 16-byte chunk f4)) and P rows (A layout) of the tile whose records are
+  // in nx_e / nx_c / nx_nz: all sixteen row requests in flight together, one exposed latency
+#define EBW_LOAD_TILE(bx, by, bpa)                                                                      \
+  do {                                                                                                  \
+    const float* ap_ = a.pw + (size_t)nx_e * D_E + 4 * half;                                            \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) bpa[k_] = *reinterpret_cast<const f32x4*>(ap_ + 8 * k_); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
+      const int row_ = 4 * i_ + q4;                                                                     \
+      const int cr_ = max(__shfl(nx_c, row_), 0), nzr_ = __shfl(nx_nz, row_);                           \
+      bx[i_] = ldg4_b(a.rc, (unsigned)cr_ * (D_P * 4u) + 16u * f4);                                     \
+      by[i_] = ldg4_b(a.rn, (unsigned)nzr_ * (D_P * 4u) + 16u * f4);                                    \
+    }                                                                                                   \
+  } while (0)
+  // Kernel front: the first tile's chain of dependent requests -- list entries -> row records -> (bias rows, P rows,
+  // column records): three round trips -- runs BESIDE the staging of the weights (16-byte loads into registers, then
+  // LDS), not after it, and the first tile's h1 is formed right behind the barrier: with one tile per wave or fewer (a
+  // single image) the front used to be 14 of the kernel's 36 us.  Later tiles form theirs at the top of the loop body.
+  const bool have_tiles = t0 < t1;
+  if (have_tiles) EBW_LOAD_LIST(t0);
+  if (have_tiles) {
     EBW_LOAD_ROWS(t0);
     if (t0 + 1 < t1) EBW_LOAD_LIST(t0 + 1);
   }
-  for (int i = tid; i < D_P * D_E; i += 64 * EBW_WAVES) {
-    const float v = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];          // W1[pf = i & 31][f = i >> 5]
-    sWpT[(i >> 5) * LD32 + (i & 31)] = v;
-  }
-  for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) sW2[(i >> 6) * LD64 + (i & 63)] = a.w2[i];
-  if (t0 < t1) EBW_LOAD_BIAS();
+  f32x4 wst[6];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int i = tid + 256 * j; wst[j] = *reinterpret_cast<const f32x4*>(a.w1t + (i >> 3) * (D_E + 2 * D_R) + 4 * (i & 7)); }   // W1[pf][f] as [f][pf]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; wst[2 + j] = *reinterpret_cast<const f32x4*>(a.w2 + 4 * i); }
+  __builtin_amdgcn_sched_barrier(0);
+  float4 fx[8], fy[8];
+  f32x4 fpa[4];
+  const int first_e = nx_e;
+  if (have_tiles) { EBW_LOAD_TILE(fx, fy, fpa); EBW_LOAD_BIAS(); }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sWpT + (i >> 3) * LD32 + 4 * (i & 7)) = wst[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sW2 + (i >> 4) * LD64 + 4 * (i & 15)) = wst[2 + j]; }
   __syncthreads();
+  GSTAMP(a, 1);
+  if (have_tiles) ebw_stage_h1(sH, sE, sWpT, fx, fy, fpa, first_e, lane);
+  GSTAMP(a, 2);
   for (int t = t0; t < t1; ++t) {
     const int p0 = t * 32;
     const int nrows = min(32, W - p0);
     const int my_e = nx_e, my_c = nx_c;
     const int tapA = apA, tapB = apB, tapC = apC, ttfA = tfA, ttfB = tfB, ttfC = tfC;
     const float tdvA = dvA, tdvB = dvB, tdvC = dvC;
-    // ---- stage: edge ids, bias tile (rc + rn: the forward kernel's operand order)
-    const int my_nz = nx_nz;
-    if (half == 0) sE[col] = my_e;
-    f32x4 pa[4];
-    {
-      const float* ap = a.pw + (size_t)my_e * D_E + 4 * half;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
-    }
-    {
-      float4 x[8], y[8];                                  // all sixteen row requests in flight: one exposed latency per tile
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + q4;
-        const int cr = max(__shfl(my_c, row), 0), nzr = __shfl(my_nz, row);
-        x[i] = ldg4_b(a.rc, (unsigned)cr * (D_P * 4u) + 16u * f4);
-        y[i] = ldg4_b(a.rn, (unsigned)nzr * (D_P * 4u) + 16u * f4);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<float4*>(sH + (4 * i + q4) * LD64 + 4 * f4) =
-            make_float4(x[i].x + y[i].x, x[i].y + y[i].y, x[i].z + y[i].z, x[i].w + y[i].w);
-    }
-    wave_lds_sync();
-    // ---- h1 = relu(P . Wp + (rc + rn)): the forward kernel's operation sequence (same bits)
-    {
-      f32x16 h1a, h1b;
-      float* hp = sH + (4 * half) * LD64 + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { h1a[r] = hp[crow(r, 0) * LD64]; h1b[r] = hp[crow(r, 0) * LD64 + 32]; }
-      const float* b0 = sWpT + col * LD32 + 4 * half;
-      const float* b1 = b0 + 32 * LD32;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x4 av = pa[k];
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { hp[crow(r, 0) * LD64] = relu_bits(h1a[r]); hp[crow(r, 0) * LD64 + 32] = relu_bits(h1b[r]); }
+    // ---- stage: edge ids, bias tile, h1 (the first tile's were formed in the kernel front)
+    if (t != t0) {
+      float4 x[8], y[8];
+      f32x4 pa[4];
+      EBW_LOAD_TILE(x, y, pa);
+      ebw_stage_h1(sH, sE, sWpT, x, y, pa, my_e, lane);
     }
     // the next tile's row records and P rows (its list entries arrived a tile ago); the list entries after those
     if (t + 1 < t1) EBW_LOAD_ROWS(t + 1);
     if (t + 2 < t1) EBW_LOAD_LIST(t + 2);
     wave_lds_sync();
+    if (t == t0) GSTAMP(a, 3);
     // ---- segments of the tile (rows sorted by centre): wave-uniform loop
     unsigned heads;
     {
@@ -637,6 +662,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       seg0 += EBW_SLOTS;
       if (hleft) wave_lds_sync();                        // the slots are rewritten by the next chunk
     }
+    if (t == t0) GSTAMP(a, 4);
     // ---- g1 = (h1 > 0) * (d h2 . W2^T); overwrites h1 in place
     {
       f32x16 g1a = zero16(), g1b = zero16();
@@ -668,6 +694,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     // the next tile's bias rows and first column records: requested BEFORE this tile's stores, in flight during the
     // d Wp / d P MFMAs
     if (t + 1 < t1) EBW_LOAD_BIAS();
+    if (t == t0) GSTAMP(a, 5);
     // ---- d Wp += P^T . g1
     {
       // X = P^T: P[row][pf = col] gathered again (the rows were read for the h1 MFMAs: L1 / L2 hits)
@@ -682,6 +709,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
         aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64 + 32], aWp1, 0, 0, 0);
       }
     }
+    if (t == t0) GSTAMP(a, 6);
     // ---- d P = g1 . Wp^T;  d_pw[e] += d P
     {
       f32x16 acc = zero16();
@@ -706,6 +734,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    if (t == t0) GSTAMP(a, 7);
     // ---- g1 rows -> compact list order (whole 256-byte rows; the buffer has slack rows past W)
     {
       float* dst = a.g1c + (size_t)p0 * D_P;
@@ -716,36 +745,49 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       }
     }
     wave_lds_sync();
+    GSTAMP(a, (10 + (t - t0)) < 14 ? 10 + (t - t0) : 13);
   }
 #undef EBW_LOAD_LIST
 #undef EBW_LOAD_ROWS
 #undef EBW_LOAD_BIAS
+#undef EBW_LOAD_TILE
   // ---- partial weight gradients of this workgroup: the four waves' accumulators are added in wave order
   __syncthreads();
-  float* red = sW2;                            // W2 + the waves' tile areas: 4352 + 4 * 2592 floats >= 4096 + 2048 + 64
-  float* redW2 = red;                          // [f][j]
-  float* redWp = red + D_P * D_P;              // [2][16][64] accumulator registers
-  float* redB = redWp + 2 * 16 * 64;           // [64]
-  for (int w = 0; w < EBW_WAVES; ++w) {
-    if (wave == w) {
+  GSTAMP(a, 14);
+  // the whole LDS allocation is free now (17 408 floats): two copies of the gradient block [W2 4096 | Wp 2048 | b2 64].
+  // Waves 0 / 1 store their accumulators into copy 0 / 1, waves 2 / 3 add theirs on top (every lane touches its own
+  // elements only), then all threads fold the two copies on the way to the arena: (w0 + w2) + (w1 + w3), a fixed order.
+  constexpr int RED = D_P * D_P + 2 * 16 * 64 + 64;
+  static_assert(2 * RED <= D_P * LD32 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS, "two reduction copies fit");
+  float* red = smem + (wave & 1) * RED;
+  for (int ph = 0; ph < 2; ++ph) {
+    if ((wave >> 1) == ph) {
 #pragma unroll
-      for (int f = 0; f < D_P; ++f) redW2[f * D_P + lane] = (w ? redW2[f * D_P + lane] : 0.f) + w2acc[f];
+      for (int f = 0; f < D_P; ++f) red[f * D_P + lane] = (ph ? red[f * D_P + lane] : 0.f) + w2acc[f];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        redWp[r * 64 + lane] = (w ? redWp[r * 64 + lane] : 0.f) + aWp0[r];
-        redWp[(16 + r) * 64 + lane] = (w ? redWp[(16 + r) * 64 + lane] : 0.f) + aWp1[r];
+        red[D_P * D_P + r * 64 + lane] = (ph ? red[D_P * D_P + r * 64 + lane] : 0.f) + aWp0[r];
+        red[D_P * D_P + (16 + r) * 64 + lane] = (ph ? red[D_P * D_P + (16 + r) * 64 + lane] : 0.f) + aWp1[r];
       }
-      redB[lane] = (w ? redB[lane] : 0.f) + gb2;
+      red[D_P * D_P + 2048 + lane] = (ph ? red[D_P * D_P + 2048 + lane] : 0.f) + gb2;
     }
     __syncthreads();
   }
+  const float* r0 = smem; const float* r1 = smem + RED;
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
-  for (int i = tid; i < D_P * D_P; i += 64 * EBW_WAVES) ar[a.o_w2 + i] = redW2[i];     // [f][j]
+  for (int i = tid; i < D_P * D_P / 4; i += 64 * EBW_WAVES) {                 // d W2 [f][j], 16-byte stores
+    const float4 u = *reinterpret_cast<const float4*>(r0 + 4 * i), v = *reinterpret_cast<const float4*>(r1 + 4 * i);
+    *reinterpret_cast<float4*>(ar + a.o_w2 + 4 * i) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
   if (wave < 2) {                              // rows 0-31 of pw_fc1 (pairwise features), f tile = wave
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ar[a.o_w1 + (size_t)crow(r, half) * D_P + 32 * wave + col] = redWp[(16 * wave + r) * 64 + lane];
+    for (int r = 0; r < 16; ++r) {
+      const int o = D_P * D_P + (16 * wave + r) * 64 + lane;
+      ar[a.o_w1 + (size_t)crow(r, half) * D_P + 32 * wave + col] = r0[o] + r1[o];
+    }
   }
-  if (tid < D_P) ar[a.o_b2 + tid] = redB[tid];
+  if (tid < D_P) ar[a.o_b2 + tid] = r0[D_P * D_P + 2048 + tid] + r1[D_P * D_P + 2048 + tid];
+  GSTAMP(a, 15);
 }
 
 }  // namespace
@@ -830,6 +872,7 @@ int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const Para
   e.w1t = pt + K.w1; e.w2 = params + K.w2;
   e.d_pw = buf->d_pw; e.g1c = buf->d_g1;
   e.arena = buf->arena; e.stride = arena_stride(L.total); e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
+  GNET_TRACE_SET(e, "EDGE_BWD", b == B / 2);
   GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_w<<<n_partials, 64 * EBW_WAVES, kEdgeBwdWSmem, s>>>(e));
   return GNET_OK;
 }

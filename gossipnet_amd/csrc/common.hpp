@@ -47,6 +47,29 @@ struct ProfScope {
 #define GNET_LAUNCH(prof, cls, stream, ...) \
   do { ProfScope _ps((prof), (cls), (stream)); __VA_ARGS__; } while (0)
 
+// ---- optional workgroup time stamps (measurement builds only: -DGNET_TRACE, see tools/wg_trace.py) ----------------
+// The shipped library carries none of this.  A trace build adds a pointer to a kernel's argument struct, taken from the
+// environment variable GNET_TRACE_<NAME> at the launch site; wave 0 of every workgroup writes wall_clock64() (the
+// 100 MHz constant clock, common to all CUs) into trace[blockIdx.x * 16 + slot].
+#ifdef GNET_TRACE
+#include <stdlib.h>
+#define GNET_TRACE_FIELD unsigned long long* trace;
+static inline unsigned long long* gnet_trace_ptr(const char* name) {
+  const char* v = getenv(name);
+  return v ? (unsigned long long*)strtoull(v, nullptr, 10) : nullptr;
+}
+#define GNET_TRACE_SET(args, name, cond) (args).trace = (cond) ? gnet_trace_ptr("GNET_TRACE_" name) : nullptr
+#define GSTAMP(args, slot)                                                                      \
+  do {                                                                                          \
+    if ((args).trace && threadIdx.x == 0 && (slot) < 16)                                        \
+      (args).trace[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64();                          \
+  } while (0)
+#else
+#define GNET_TRACE_FIELD
+#define GNET_TRACE_SET(args, name, cond) ((void)0)
+#define GSTAMP(args, slot) ((void)0)
+#endif
+
 // HIP keeps the last error of ANY runtime call of the thread (torch's included): clear it on entry.
 static inline void clear_hip_error() { (void)hipGetLastError(); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? GNET_OK : GNET_ERR_HIP; }

@@ -288,6 +288,7 @@ struct EdgeFwdArgs {
   float* h1_out;                 // [E+64,64] relu(pw_fc1) (KEEP variant only: tests / debugging)
   float* h2_out;                 // [E+64,64] h1.W2 + b2, the values the segment maximum is taken on (KEEP variant only)
   unsigned long long* parg;      // [N,64] (max bits << 32) | first edge attaining it (training), zeroed
+  GNET_TRACE_FIELD
 };
 
 // edge_fwd_w: every wave owns whole 32-edge x 64-column tiles (96 MFMAs per tile), no workgroup barriers in
@@ -324,6 +325,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   float* sWp = smem;                           // [64][36]  Wp^T[f][pf]
   float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T[j][f]
   float* sHw = sW2 + D_P * E_LD2;              // per wave: rc rows of the tile's first two centres [2][64]
+  GSTAMP(a, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
@@ -337,34 +339,31 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   const int gw = lb * EFW_WAVES + wave;
   const int t0 = gw * per, t1 = min(ntiles, t0 + per);
   float* sRC = sHw + wave * (2 * D_P);
-  // the first tile's records (edge -> centre / neighbour row -> rn / rc rows: three dependent round trips) are
-  // requested BEFORE the weights are staged, so that the chain runs beside the staging instead of after it
-  int nx_c = -1, nx_nz = 0;
+  // Kernel front = two dependent round trips, overlapped with the staging of the weights (at one or two tiles per
+  // wave -- a single image -- the front is a third of the kernel):
+  //   (1) the first tile's edge records (centre, neighbour row, the edge in front of the range) and its P rows,
+  //       then the weights as 16-byte loads into registers (6 per thread);
+  //   (2) as soon as the records are back (the in-order counter lets the P rows and weights stay in flight): the rn rows
+  //       and the rc rows of the first two centres;
+  //   (3) weights -> LDS, barrier.  The gathers of (2) land during (3).
+  int nx_c = -1, nx_nz = 0, c_before = -1;
   f32x4 pa[4];
-  if (t0 < t1) {
+  const bool have_tiles = t0 < t1;
+  if (have_tiles) {
     { const int e = t0 * 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
+    nx_nz = a.edge_nz[t0 * 32 + col];                                  // (the tail of edge_nz is padded)
+    if (t0 > 0) c_before = a.edge_c[t0 * 32 - 1];
     const float* ap = a.pw + (size_t)min(t0 * 32 + col, a.n_edge - 1) * D_E + 4 * half;
 #pragma unroll
     for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
-    nx_nz = a.edge_nz[t0 * 32 + col];                                  // (the tail of edge_nz is padded)
   }
-  for (int i = tid; i < D_P * D_E; i += 64 * EFW_WAVES) sWp[(i >> 5) * E_LD1 + (i & 31)] = a.w1t[(i >> 5) * (D_E + 2 * D_R) + (i & 31)];
-  for (int i = tid; i < D_P * D_P; i += 64 * EFW_WAVES) sW2[(i >> 6) * E_LD2 + (i & 63)] = a.w2t[i];
-  __syncthreads();
-  if (t0 >= t1) return;
-  const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
-  // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
-  // tools/mfma_valu_overlap.hip) -- every vector instruction in this loop is paid in MFMA time.  Hence:
-  //   * LAYER 1 IS COMPUTED TRANSPOSED: h1^T[f][edge] = Wp^T . P^T (the MFMA's operands swapped), so that its
-  //     accumulators -- lane = edge, registers = features 8 g + 4 half + q -- ARE the A operand of layer 2
-  //     (lane = row, 4 consecutive k per 16-byte group: the k pairing of mma_abt).  No LDS round trip, no
-  //     barrier and no layout shuffle between the two layers; every element is the same chain of products in the
-  //     same order as before (bit-identical h1 and h2);
-  //   * the accumulators start from rc[c] + rn[n] read as the lane's OWN rows (eight 16-byte gathers of rn per
-  //     lane and tile instead of 32 4-byte ones; rc rows of the tile's first two centres go through 512 bytes of
-  //     LDS and come back as broadcast reads); self pairs and the edge tail are resolved once per batch into
-  //     edge_nz (index of a zero row of rn): no clamps, no (c != n) selects;
-  //   * the segment maximum is taken on h2 + b2 and rectified once per segment, not per element.
+  GSTAMP(a, 13);
+  f32x4 wst[6];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int i = tid + 256 * j; wst[j] = *reinterpret_cast<const f32x4*>(a.w1t + (i >> 3) * (D_E + 2 * D_R) + 4 * (i & 7)); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; wst[2 + j] = *reinterpret_cast<const f32x4*>(a.w2t + 4 * i); }
+  __builtin_amdgcn_sched_barrier(0);
   // ---- prefetch state for the first tile (lane = edge e0 + col, both half-waves alike)
   float4 rnv[8];                                                       // rn[n][8 g + 4 half .. + 3]
 #pragma unroll
@@ -378,11 +377,34 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     if (hm) { hiA = __builtin_ctz(hm); cB = __builtin_amdgcn_readlane(nx_c, hiA); }
   }
   float4 rcAB = ldg4_b(a.rc, (unsigned)max((lane & 16) ? cB : cA, 0) * (D_P * 4u) + 16u * (lane & 15));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sWp + (i >> 3) * E_LD1 + 4 * (i & 7)) = wst[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sW2 + (i >> 4) * E_LD2 + 4 * (i & 15)) = wst[2 + j]; }
+  GSTAMP(a, 14);
+  __syncthreads();
+  GSTAMP(a, 1);
+  if (!have_tiles) return;
+  const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
+  // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
+  // tools/mfma_valu_overlap.hip) -- every vector instruction in this loop is paid in MFMA time.  Hence:
+  //   * LAYER 1 IS COMPUTED TRANSPOSED: h1^T[f][edge] = Wp^T . P^T (the MFMA's operands swapped), so that its
+  //     accumulators -- lane = edge, registers = features 8 g + 4 half + q -- ARE the A operand of layer 2
+  //     (lane = row, 4 consecutive k per 16-byte group: the k pairing of mma_abt).  No LDS round trip, no
+  //     barrier and no layout shuffle between the two layers; every element is the same chain of products in the
+  //     same order as before (bit-identical h1 and h2);
+  //   * the accumulators start from rc[c] + rn[n] read as the lane's OWN rows (eight 16-byte gathers of rn per
+  //     lane and tile instead of 32 4-byte ones; rc rows of the tile's first two centres go through 512 bytes of
+  //     LDS and come back as broadcast reads); self pairs and the edge tail are resolved once per batch into
+  //     edge_nz (index of a zero row of rn): no clamps, no (c != n) selects;
+  //   * the segment maximum is taken on h2 + b2 and rectified once per segment, not per element.
   int cur = -1; float m0 = 0.f, m1 = 0.f; unsigned k0 = 0, k1 = 0;     // running segment (wave-uniform centre)
   int g0 = 0, g1 = 0;                                                  // edge that first attains m0 / m1 (TRAIN)
   // does the first centre of this range start in the previous wave's range?
-  bool head_shared = e_begin > 0 && a.edge_c[e_begin - 1] == cA;
+  bool head_shared = e_begin > 0 && c_before == cA;
   drain_vmem_before_loop();
+  GSTAMP(a, 2);
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * 32;
     const int my_c = nx_c;
@@ -612,6 +634,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         cur = cseg; m0 = s0; k0 = q0; m1 = s1; k1 = q1; g0 = a0; g1 = a1;
       }
     }
+    GSTAMP(a, 3 + (t - t0));
   }
   if (cur >= 0) {
     // the last centre may continue in the next wave's range
@@ -629,6 +652,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       else __hip_atomic_fetch_max(ad, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  GSTAMP(a, 15);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -657,6 +681,7 @@ struct NodeFwdArgs {
   unsigned long long* pm_next; unsigned long long* parg_next; const int* row_ptr; int edge_span;
   const float* hw1t; const float* hb1; const float* hw2t; const float* hb2; const float* hwl; const float* hbl;
   float* head1; float* head2; float* pred;
+  GNET_TRACE_FIELD
 };
 
 __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
@@ -666,6 +691,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int row0 = blockIdx.x * 32;
+  GSTAMP(a, 0);
   // every global operand of the stages below is requested here, before the first barrier: the stages are a chain
   // of small products separated by barriers, and a load issued inside a stage costs that stage a memory latency
   BtRegs<D_P> gW3, gW4; BtRegs<32> gWr, gWrn, gW1;
@@ -704,6 +730,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       }
     }
     __syncthreads();
+    GSTAMP(a, 1);
     f32x16 acc = zero16();
     if (wave < 2) mma_abt_r<D_P>(acc, sY, E_LD2, gW3, lane);
     __syncthreads();
@@ -718,6 +745,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       }
     }
     __syncthreads();
+    GSTAMP(a, 2);
     acc = zero16();
     mma_abt_r<D_P>(acc, sX, E_LD2, gW4, lane);
     __syncthreads();
@@ -747,6 +775,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     }
     __syncthreads();
   }
+  GSTAMP(a, 3);
   if (a.do_pre) {
     if (a.pm_next) {
       int eb[8], ee[8];                                  // (all sixteen row_ptr reads before the first use)
@@ -805,6 +834,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       __syncthreads();
       sYn = sY2;
     }
+    GSTAMP(a, 4);
     // rc = r . W1[32:64] + b1 (waves 0,1) ; rn = r_n . W1[64:96] (waves 2,3; r_n = r without neighbor_feats)
     {
       const int part = wave >> 1, nt = wave & 1;
@@ -821,6 +851,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
     // row n_det of rn stays zero: the edge kernels read it for self pairs (edge_nz)
     if (blockIdx.x == 0 && tid < D_P) a.rn[(size_t)a.n_det * D_P + tid] = 0.f;
   }
+  GSTAMP(a, 5);
   if (a.do_head) {
     __syncthreads();
     f32x16 acc = zero16();
@@ -859,6 +890,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       if (part == 0 && row0 + row < a.n_det) a.pred[row0 + row] = s + a.hbl[0];
     }
   }
+  GSTAMP(a, 15);
 }
 
 }  // namespace
@@ -938,6 +970,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
     n.hwl = params + L.hwl; n.hbl = params + L.hbl;
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
+    GNET_TRACE_SET(n, "NODE_FWD", b == B / 2);
     GNET_LAUNCH(prof, GNET_K_NODE_FWD, s, node_fwd<<<ntile_n, 256, 0, s>>>(n));
     if (b < B) {
       if (E > 0) {
@@ -950,6 +983,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         e.h1_out = keep_h1 ? buf->blk_h1[b + 1] : nullptr;
         e.h2_out = keep_h1 ? buf->blk_h2[b + 1] : nullptr;
         e.parg = training ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
+        GNET_TRACE_SET(e, "EDGE_FWD", b == B / 2);
         const int wg = ef_wg;
         if (keep_h1) {
           if (!buf->blk_h1[b + 1] || !buf->blk_h2[b + 1]) return GNET_ERR_INVALID;   // planned without training == 2

@@ -18,7 +18,9 @@ for k in fetch:
     q = sq.get(k)
     if q:
         busy, mf, va = q.get("VALU_MFMA_BUSY_CYCLES", 0.0), q.get("INSTS_MFMA", 0.0), q.get("INSTS_VALU", 0.0)
-        gui = q.get("GRBM_GUI_ACTIVE", 0.0)          # GPU-active cycles of the launch = its duration at the clock it really ran at
+        # GPU-active cycles of the launch = its duration at the clock it really ran at (rocprofv3 reports the SUM over the
+        # 8 XCDs' GRBM instances: 3.5e6 for a 192 us launch = 8 x 2.28 GHz x 192 us)
+        gui = q.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         kernels[k].update({"sq_pass_avg_launch_us": round(q["avg_us"], 2), "valu_mfma_busy_cycles": busy, "insts_mfma": mf,
                            "insts_valu": va, "wait_inst_any": q.get("WAIT_INST_ANY"), "wait_inst_lds": q.get("WAIT_INST_LDS"),
                            "active_inst_any": q.get("ACTIVE_INST_ANY"), "wave_cycles": q.get("WAVE_CYCLES"), "gui_active_cycles": gui,
