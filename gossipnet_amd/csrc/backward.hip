@@ -224,18 +224,18 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   // positions tpos[e]; the first 64 of those are requested before the own rows are summed
   const int tp_first = eb + lane < ee ? tpos[eb + lane] : -1;
   const int p0 = wrow[node], p1 = wrow[node + 1];
-  // the sums are latency-bound: several rows per quarter-wave in flight (a missing row re-reads row p0 / position 0 with
+  // the sums are latency-bound: eight rows per quarter-wave in flight (a missing row re-reads row p0 / position 0 with
   // weight 0); ascending order per quarter-wave, the quarter-waves are folded at the end (fixed order)
-  for (int p = p0 + sub; p < p1; p += 16) {
-    float4 c[4]; float w[4];
+  for (int p = p0 + sub; p < p1; p += 32) {
+    float4 c[8]; float w[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const bool have = p + 4 * q < p1;
       w[q] = have ? 1.f : 0.f;
       c[q] = *reinterpret_cast<const float4*>(g1c + (size_t)(have ? p + 4 * q : p0) * D_P + 4 * f4);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sc.x = fmaf(w[q], c[q].x, sc.x); sc.y = fmaf(w[q], c[q].y, sc.y); sc.z = fmaf(w[q], c[q].z, sc.z); sc.w = fmaf(w[q], c[q].w, sc.w); }
+    for (int q = 0; q < 8; ++q) { sc.x = fmaf(w[q], c[q].x, sc.x); sc.y = fmaf(w[q], c[q].y, sc.y); sc.z = fmaf(w[q], c[q].z, sc.z); sc.w = fmaf(w[q], c[q].w, sc.w); }
   }
   GSTAMP(tr, 1);
   for (int base = eb; base < ee; base += 64) {
@@ -245,19 +245,20 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
     else if (el < ee) tp = tpos[el];
     unsigned long long mr = __ballot(tp >= 0);
     while (mr) {
-      // next 16 reversed rows: four per quarter-wave
-      int j[4] = {-1, -1, -1, -1};
+      // next 32 reversed rows: eight per quarter-wave, all requested before the first is added (a detection with many
+      // winning neighbours used to need one memory round trip per 16 rows: the slowest wave set the kernel's duration)
+      int j[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 #pragma unroll
-      for (int q = 0; q < 16; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if ((q & 3) == sub) j[q >> 2] = b; } }
-      float4 v[4]; float w[4];
+      for (int q = 0; q < 32; ++q) { if (mr) { const int b = __builtin_ctzll(mr); mr &= mr - 1; if ((q & 3) == sub) j[q >> 2] = b; } }
+      float4 v[8]; float w[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const int pq = __shfl(tp, j[q] < 0 ? 0 : j[q]);
         w[q] = j[q] >= 0 ? 1.f : 0.f;
         v[q] = *reinterpret_cast<const float4*>(g1c + (size_t)max(pq, 0) * D_P + 4 * f4);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { sn.x = fmaf(w[q], v[q].x, sn.x); sn.y = fmaf(w[q], v[q].y, sn.y); sn.z = fmaf(w[q], v[q].z, sn.z); sn.w = fmaf(w[q], v[q].w, sn.w); }
+      for (int q = 0; q < 8; ++q) { sn.x = fmaf(w[q], v[q].x, sn.x); sn.y = fmaf(w[q], v[q].y, sn.y); sn.z = fmaf(w[q], v[q].z, sn.z); sn.w = fmaf(w[q], v[q].w, sn.w); }
     }
   }
 #pragma unroll

@@ -302,14 +302,16 @@ __global__ void __launch_bounds__(256) list_fill(const ListArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// apos[node][j] = position in the block's winner list of the edge recorded as column j's arg-max, -1 when the
-// maximum is not positive (no gradient).  All blocks in one launch; off the backward chain.
+// apos[node][j] = (position in the block's winner list of the edge recorded as column j's arg-max) + 1 in bits 0-23, 0
+// when the maximum is not positive (no gradient); bit 30 = the detection's tie flag (edge_bwd_w reads one record per
+// (detection, column) instead of a record and a flag).  All blocks in one launch; off the backward chain.
 struct PosArgs {
   int n_det;
   long long bm_stride, ap_stride;
   const unsigned long long* ewin; const int* wprefix;
   const unsigned long long* parg[GNET_MAX_BLOCKS];
   int* apos;                        // [B][ap_stride]
+  const unsigned char* tflag; long long tf_stride;
 };
 
 __global__ void __launch_bounds__(256) winner_positions(const PosArgs a) {
@@ -320,7 +322,8 @@ __global__ void __launch_bounds__(256) winner_positions(const PosArgs a) {
   const long long total = (long long)a.n_det * D_P;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const unsigned long long pv = a.parg[blk][i];
-    apos[i] = (pv >> 32) != 0ull ? winner_pos(ewin, wprefix, (int)(unsigned)pv) : -1;
+    const int tie = a.tflag[(size_t)blk * a.tf_stride + (i >> 6)] ? (1 << 30) : 0;
+    apos[i] = ((pv >> 32) != 0ull ? winner_pos(ewin, wprefix, (int)(unsigned)pv) + 1 : 0) | tie;
   }
 }
 
@@ -357,8 +360,8 @@ struct EdgeBwdWArgs {
   const int* wcount;                // device: number of winner rows of this block
   const int* wlist;                 // ascending winner edges
   const int* edge_c; const int* edge_nz;
-  const int* apos;                  // [N,64] list position of column j's arg-max edge (-1: none)
-  const unsigned char* tflag; const unsigned long long* xmask;
+  const int* apos;                  // [N,64] (list position of column j's arg-max edge) + 1, 0 = none; bit 30 = the detection's tie flag
+  const unsigned long long* xmask;
   const float* pw; const float* rc; const float* rn; const float* d_pc;
   const float* w1t; const float* w2;      // pw_fc1 transposed [64][96]; pw_fc2 natural [64 (in f)][64 (out j)]
   float* d_pw;                      // [E,32] += d P on winner rows
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   int nx2_e = 0;                               // list entry two tiles ahead
   int nx_e = 0, nx_c = -1, nx_nz = 0;
   // column records (lane = column j) of the first two detections of the next tile
-  int apA = -1, apB = -1, apC = -1, tfA = 0, tfB = 0, tfC = 0;
+  int apA = 0, apB = 0, apC = 0;
   float dvA = 0.f, dvB = 0.f, dvC = 0.f;
 #define EBW_LOAD_LIST(tile_) do { nx2_e = a.wlist[min((tile_) * 32 + col, W - 1)]; } while (0)
 #define EBW_LOAD_ROWS(tile_)     /* uses nx2_e = list entries of tile_ */                               \
@@ -474,9 +477,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     }                                                                                                   \
     const unsigned oa_ = (unsigned)max(cA_, 0) * D_P + lane, ob_ = (unsigned)max(cB_, 0) * D_P + lane;  \
     const unsigned oc_ = (unsigned)max(cC_, 0) * D_P + lane;                                            \
-    apA = a.apos[oa_]; dvA = a.d_pc[oa_]; tfA = a.tflag[max(cA_, 0)];                                   \
-    apB = a.apos[ob_]; dvB = a.d_pc[ob_]; tfB = a.tflag[max(cB_, 0)];                                   \
-    apC = a.apos[oc_]; dvC = a.d_pc[oc_]; tfC = a.tflag[max(cC_, 0)];                                   \
+    apA = a.apos[oa_]; dvA = a.d_pc[oa_];                                                               \
+    apB = a.apos[ob_]; dvB = a.d_pc[ob_];                                                               \
+    apC = a.apos[oc_]; dvC = a.d_pc[oc_];                                                               \
   } while (0)
   // bias rows (rc[c] | rn[n], lane = (row 4 i + q4, 16-byte chunk f4)) and P rows (A layout) of the tile whose records are
   // in nx_e / nx_c / nx_nz: all sixteen row requests in flight together, one exposed latency
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     const int p0 = t * 32;
     const int nrows = min(32, W - p0);
     const int my_e = nx_e, my_c = nx_c;
-    const int tapA = apA, tapB = apB, tapC = apC, ttfA = tfA, ttfB = tfB, ttfC = tfC;
+    const int tapA = apA, tapB = apB, tapC = apC;
     const float tdvA = dvA, tdvB = dvB, tdvC = dvC;
     // ---- stage: edge ids, bias tile, h1 (the first tile's were formed in the kernel front)
     if (t != t0) {
@@ -566,12 +569,14 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
         hleft &= hleft - 1;
         hi[k] = have ? (hleft ? __builtin_ctz(hleft) : nrows) : 0;
         // lane j: column j of this detection (the first detections of a tile were requested a tile ago)
-        int ap; float dv; int tf;
-        if (seg0 == 0) { ap = k == 0 ? tapA : k == 1 ? tapB : tapC; dv = k == 0 ? tdvA : k == 1 ? tdvB : tdvC; tf = k == 0 ? ttfA : k == 1 ? ttfB : ttfC; }
+        int rec; float dv;
+        if (seg0 == 0) { rec = k == 0 ? tapA : k == 1 ? tapB : tapC; dv = k == 0 ? tdvA : k == 1 ? tdvB : tdvC; }
         else {
           const int cseg = max(__builtin_amdgcn_readlane(my_c, lo[k]), 0);
-          ap = a.apos[(size_t)cseg * D_P + lane]; dv = a.d_pc[(size_t)cseg * D_P + lane]; tf = a.tflag[cseg];
+          rec = a.apos[(size_t)cseg * D_P + lane]; dv = a.d_pc[(size_t)cseg * D_P + lane];
         }
+        const int ap = (rec & 0xffffff) - 1;                                   // list position, -1 = no gradient
+        const int tf = __builtin_amdgcn_readfirstlane(rec) >> 30;              // the detection's tie flag (same in all 64 records)
         const int rowj = ap - p0;
         const bool inj = have && ap >= 0 && rowj >= lo[k] && rowj < hi[k];     // the column's winner is a row of this tile
         sRJ[k * 64 + lane] = inj ? rowj : -1;
@@ -737,11 +742,14 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     if (t == t0) GSTAMP(a, 7);
     // ---- g1 rows -> compact list order (whole 256-byte rows; the buffer has slack rows past W)
     {
-      float* dst = a.g1c + (size_t)p0 * D_P;
+      // (uniform base + 32-bit byte offset: a per-lane 64-bit pointer kept across the tile loop was spilled, and its reload
+      // sat behind the sixteen atomics above -- the in-order memory counter made every tile wait for their round trip)
+      const unsigned off0 = (unsigned)(p0 + q4) * (D_P * 4u) + 16u * f4;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = 4 * i + q4;
-        *reinterpret_cast<float4*>(dst + row * D_P + 4 * f4) = *reinterpret_cast<const float4*>(sH + row * LD64 + 4 * f4);
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.g1c) + (off0 + (unsigned)i * (4u * D_P * 4u))) =
+            *reinterpret_cast<const float4*>(sH + row * LD64 + 4 * f4);
       }
     }
     wave_lds_sync();
@@ -836,6 +844,7 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   PosArgs p;
   p.n_det = N; p.bm_stride = (long long)G.bm_stride; p.ap_stride = (long long)G.ap_stride;
   p.ewin = (const unsigned long long*)buf->ewin; p.wprefix = buf->wprefix; p.apos = buf->apos;
+  p.tflag = (const unsigned char*)buf->tflag; p.tf_stride = (long long)G.tf_stride;
   for (int b = 1; b <= B; ++b) p.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_positions<<<dim3(min((N * D_P + 255) / 256, 1024), B), 256, 0, s>>>(p));
   TposArgs t;
@@ -866,7 +875,6 @@ int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const Para
   e.wlist = buf->wlist + (size_t)(b - 1) * G.wl_stride;
   e.edge_c = buf->edge_c; e.edge_nz = buf->edge_nz;
   e.apos = buf->apos + (size_t)(b - 1) * G.ap_stride;
-  e.tflag = (const unsigned char*)buf->tflag + (size_t)(b - 1) * G.tf_stride;
   e.xmask = (const unsigned long long*)buf->xmask + (size_t)(b - 1) * G.xm_stride;
   e.pw = buf->pw_feats; e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b]; e.d_pc = buf->d_pc;
   e.w1t = pt + K.w1; e.w2 = params + K.w2;

@@ -130,7 +130,7 @@ typedef struct gnet_buffers {
   int32_t* wlist;     /* [num_blocks][wl_stride] ascending winner edges of the block */
   uint64_t* xmask;    /* [num_blocks][xm_stride] per edge: columns whose (tied) maximum it attains besides the recorded arg-max edge; valid on rows of flagged detections only */
   uint8_t* tflag;     /* [num_blocks][tf_stride] the detection has a tied positive maximum in this block */
-  int32_t* apos;      /* [num_blocks][n_det+32,64] list position of the arg-max edge of every (detection, column); -1 = no gradient */
+  int32_t* apos;      /* [num_blocks][n_det+32,64] per (detection, column): bits 0-23 = list position of the arg-max edge + 1 (0 = no gradient), bit 30 = the detection's tie flag */
   int32_t* tpos;      /* [num_blocks][n_edge+64] list position of every edge's REVERSED pair in the block's winner list; -1 = not a winner (or a self pair) */
   int32_t* wrow;      /* [num_blocks][n_det+32] list position of the first winner of every detection's edge range (CSR row pointers of the winner lists) */
   int32_t* rl_scratch;/* scan scratch of the list construction; also holds the list lengths */
