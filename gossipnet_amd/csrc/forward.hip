@@ -144,23 +144,26 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
   const float bias3 = a.b3[tid & 31];
   // fc3: wave = (row tile mt, K quarter kq)
   const int mt = wave & 1, kq = wave >> 1;
-  // staging registers of the next tile: threads 0-127 one float4 of geo, 128-191 one (row, score) record
-  float4 st_geo = make_float4(0.f, 0.f, 0.f, 0.f);
-  int4 st_inf = make_int4(0, 0, 0, 0);
+  // The geometry columns [64][8] and (row, score) records [64] of a tile reach LDS by DMA (global_load_lds: 1 KB per
+  // wave-instruction, lane i -> 16 bytes at base + 16 i; waves 0 / 1 the two halves of the geometry, wave 2 the records),
+  // one tile ahead, into the staging buffer the previous tile has finished with.  No staging registers: at 128
+  // registers per wave they were spilled, and a spill reload behind the tile's h1 / h2 stores made the in-order memory
+  // counter wait for those stores.
   const int last = a.n_edge - 1;
-#define PW_PREFETCH(tile_)                                                                              \
+#define PW_STAGE_DMA(dst_, tile_)                                                                       \
   do {                                                                                                  \
-    if (tid < 2 * PW_T) {                                                                               \
+    if (wave < 2) {                                                                                     \
       const int e_ = min((tile_) * PW_T + (tid >> 1), last);                                            \
-      st_geo = *reinterpret_cast<const float4*>(a.geo + (size_t)e_ * 8 + 4 * (tid & 1));               \
-    } else if (tid < 3 * PW_T) {                                                                        \
-      st_inf = a.einfo[min((tile_) * PW_T + tid - 2 * PW_T, last)];                                     \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.geo + (size_t)e_ * 8 + 4 * (tid & 1)), \
+                                       (__attribute__((address_space(3))) void*)((dst_) + 256 * wave), 16, 0, 0);          \
+    } else if (wave == 2) {                                                                             \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.einfo + min((tile_) * PW_T + lane, last)), \
+                                       (__attribute__((address_space(3))) void*)((dst_) + PW_T * 8), 16, 0, 0);             \
     }                                                                                                   \
   } while (0)
   if ((int)blockIdx.x * PW_T < a.n_edge) {
-    PW_PREFETCH((int)blockIdx.x);
-    if (tid < 2 * PW_T) *reinterpret_cast<float4*>(sStage + (tid >> 1) * 8 + 4 * (tid & 1)) = st_geo;
-    else if (tid < 3 * PW_T) reinterpret_cast<int4*>(sStage + PW_T * 8)[tid - 2 * PW_T] = st_inf;
+    PW_STAGE_DMA(sStage, (int)blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's staging data (the loop's first barrier publishes it)
   }
   int it = 0;
 
@@ -170,6 +173,9 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     const float* sGeo = sStage + (it & 1) * (PW_T * 12);
     const int4* sInf = reinterpret_cast<const int4*>(sGeo + PW_T * 8);
     float* nGeo = sStage + ((it & 1) ^ 1) * (PW_T * 12);
+    // this tile's staging DMA was issued a tile ago, in front of at least the four pw stores of every wave: "all but
+    // the four youngest operations" covers it without waiting for those stores
+    if (wave < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
     // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output).  Edges are
     // sorted by centre, so the centre's row of W1 is re-read only when it changes (scalar branch: the
@@ -202,10 +208,10 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
     f32x16 acc0 = zero16(), acc1 = zero16();
     mma_abt2_gB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
-    // requested before this tile's stores: the next tile's geometry
+    // requested before this tile's stores: the next tile's geometry and records, straight into the other staging buffer
     {
       const int next = tile + (int)gridDim.x;
-      if (next * PW_T < a.n_edge) PW_PREFETCH(next);
+      if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
     }
     if (a.training) {      // fc1 activations: rows [8 wave, 8 wave + 8) of the tile (rows past E land in the slack)
 #pragma unroll
@@ -245,9 +251,6 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
           *reinterpret_cast<float4*>(a.h2 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
         }
       }
-      // the next tile's staging data (requested before the stores) -> the other staging buffer
-      if (tid < 2 * PW_T) *reinterpret_cast<float4*>(nGeo + (tid >> 1) * 8 + 4 * (tid & 1)) = st_geo;
-      else if (tid < 3 * PW_T) reinterpret_cast<int4*>(nGeo + PW_T * 8)[tid - 2 * PW_T] = st_inf;
       __syncthreads();   // every wave is done with the fc2 outputs: the partials may overwrite them
 #pragma unroll
       for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
@@ -263,7 +266,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
       a.pw[(size_t)e0 * D_E + idx] = fmaxf(v + bias3, 0.f);     // rows past E land in the buffer's slack
     }
   }
-#undef PW_PREFETCH
+#undef PW_STAGE_DMA
 }
 
 constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 2 * (PW_T * 8 + 4 * PW_T)) * sizeof(float);   // records = 4 ints per edge
