@@ -700,20 +700,11 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     // d Wp / d P MFMAs
     if (t + 1 < t1) EBW_LOAD_BIAS();
     if (t == t0) GSTAMP(a, 5);
-    // ---- d Wp += P^T . g1
-    {
-      // X = P^T: P[row][pf = col] gathered again (the rows were read for the h1 MFMAs: L1 / L2 hits)
-      const float* Y = sH + col;
-      float xs[16];
+    // X = P^T for the d Wp product below: P[row][pf = col] gathered again (the rows were read for the h1 MFMAs: L1 / L2
+    // hits), requested here so that the round trip runs under the d P MFMAs
+    float xs[16];
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) xs[kk] = ldg_b(a.pw, (unsigned)sE[2 * kk + half] * (D_E * 4u) + 4u * col);
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + half;
-        aWp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64], aWp0, 0, 0, 0);
-        aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64 + 32], aWp1, 0, 0, 0);
-      }
-    }
+    for (int kk = 0; kk < 16; ++kk) xs[kk] = ldg_b(a.pw, (unsigned)sE[2 * kk + half] * (D_E * 4u) + 4u * col);
     if (t == t0) GSTAMP(a, 6);
     // ---- d P = g1 . Wp^T;  d_pw[e] += d P
     {
@@ -740,6 +731,17 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       }
     }
     if (t == t0) GSTAMP(a, 7);
+    // ---- d Wp += P^T . g1 (issued behind the atomics: its operands were requested in front of them, so the in-order
+    // memory counter does not wait for the atomics' round trip)
+    {
+      const float* Y = sH + col;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + half;
+        aWp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64], aWp0, 0, 0, 0);
+        aWp1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[kk], Y[row * LD64 + 32], aWp1, 0, 0, 0);
+      }
+    }
     // ---- g1 rows -> compact list order (whole 256-byte rows; the buffer has slack rows past W)
     {
       // (uniform base + 32-bit byte offset: a per-lane 64-bit pointer kept across the tile loop was spilled, and its reload
