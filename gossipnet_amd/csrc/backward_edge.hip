@@ -446,12 +446,11 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   const int W = *a.wcount;
   const int ntiles = (W + 31) / 32;
   const int nwaves = gridDim.x * EBW_WAVES;
-  const int per = (ntiles + nwaves - 1) / nwaves;
   // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; XCD x gets the x-th contiguous eighth of the list,
   // so the rc / rn / d_pc / apos rows it gathers (one image's worth for an 8-image batch) stay in its L2
   const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const int gw = lb * EBW_WAVES + wave;
-  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  const int t0 = range_begin(gw, ntiles, nwaves), t1 = range_begin(gw + 1, ntiles, nwaves);     // balanced: every wave has work
   const int q4 = lane >> 4, f4 = lane & 15;    // row-layout accesses: rows 4 i + q4, 16-byte chunk f4
   // records of the next tile: edge, centre, neighbour row (lane = row, both half-waves alike), P in A layout
   int nx2_e = 0;                               // list entry two tiles ahead

@@ -158,6 +158,16 @@ static inline EdgeGeom edge_geom(int64_t E, int64_t N) {
   return g;
 }
 
+// ---- balanced contiguous ranges: n_items dealt to n_parts so that every part gets floor or ceil of the mean --------
+// part g owns [range_begin(g), range_begin(g + 1)); range_owner() is its inverse.  (Equal ceil-sized ranges leave the last
+// parts empty -- with the XCD-aware part numbering all of them on one XCD: edge_bwd_w ran on seven XCDs.)
+__host__ __device__ __forceinline__ int range_begin(int g, int n_items, int n_parts) {
+  return (int)(((long long)g * n_items) / n_parts);
+}
+__host__ __device__ __forceinline__ int range_owner(int item, int n_items, int n_parts) {
+  return (int)((((long long)item + 1) * n_parts - 1) / n_items);
+}
+
 // ---- fp32 MFMA tile primitives ---------------------------------------------------------
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // the 16 accumulator registers hold D[row][col] with col = l&31,

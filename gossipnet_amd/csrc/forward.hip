@@ -334,13 +334,12 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   const float bias0 = a.b2[col], bias1 = a.b2[32 + col];
   const int ntiles = (a.n_edge + 31) / 32;
   const int nwaves = gridDim.x * EFW_WAVES;
-  const int per = (ntiles + nwaves - 1) / nwaves;
   // XCD-aware range assignment: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
   // own L2.  Giving XCD x the x-th contiguous eighth of the edge list keeps the rc / rn rows it gathers (one
   // image's worth when the batch has 8 images) resident in that XCD's L2 instead of all images in every L2.
   const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const int gw = lb * EFW_WAVES + wave;
-  const int t0 = gw * per, t1 = min(ntiles, t0 + per);
+  const int t0 = range_begin(gw, ntiles, nwaves), t1 = range_begin(gw + 1, ntiles, nwaves);     // balanced: every wave has work
   float* sRC = sHw + wave * (2 * D_P);
   // Kernel front = two dependent round trips, overlapped with the staging of the weights (at one or two tiles per
   // wave -- a single image -- the front is a third of the kernel):
@@ -680,8 +679,8 @@ struct NodeFwdArgs {
   float* r; float* rc; float* rn; float* r_nb;
   // segment-max records of the NEXT block: rows of detections whose edges are split between two waves of
   // edge_fwd_w (combined atomically there) or that have no edge at all start from zero; every other row is
-  // written by a plain store.  edge_span = edges per wave range of edge_fwd_w.
-  unsigned long long* pm_next; unsigned long long* parg_next; const int* row_ptr; int edge_span;
+  // written by a plain store.  ef_tiles / ef_waves = the tile and wave counts of edge_fwd_w's range assignment.
+  unsigned long long* pm_next; unsigned long long* parg_next; const int* row_ptr; int ef_tiles, ef_waves;
   const float* hw1t; const float* hb1; const float* hw2t; const float* hb2; const float* hwl; const float* hbl;
   float* head1; float* head2; float* pred;
   GNET_TRACE_FIELD
@@ -790,7 +789,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int node = row0 + (tid >> 6) + 4 * j;
-        if (node < a.n_det && (ee[j] == eb[j] || eb[j] / a.edge_span != (ee[j] - 1) / a.edge_span)) {
+        if (node < a.n_det && (ee[j] == eb[j] || range_owner(eb[j] >> 5, a.ef_tiles, a.ef_waves) != range_owner((ee[j] - 1) >> 5, a.ef_tiles, a.ef_waves))) {
           a.pm_next[(size_t)node * D_P + (tid & 63)] = 0ull;
           if (a.parg_next) a.parg_next[(size_t)node * D_P + (tid & 63)] = 0ull;
         }
@@ -946,7 +945,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
   }
   const int ef_tiles = (E + 31) / 32, ef_waves = ef_wg * EFW_WAVES;
-  const int ef_span = max(1, (ef_tiles + ef_waves - 1) / ef_waves) * 32;       // edges per wave range
+
   for (int b = 0; b <= B; ++b) {
     // node stage between edge kernels: finish block b (b >= 1), start block b+1 (b < B)
     NodeFwdArgs n;
@@ -969,7 +968,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     } else { n.wrt = n.br = n.w1t = n.b1 = nullptr; n.r = n.rc = n.rn = nullptr; n.wrnt = n.brn = nullptr; n.r_nb = nullptr; }
     n.pm_next = b < B ? (unsigned long long*)buf->blk_pm[b + 1] : nullptr;
     n.parg_next = (b < B && training) ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
-    n.row_ptr = buf->row_ptr; n.edge_span = ef_span;
+    n.row_ptr = buf->row_ptr; n.ef_tiles = max(ef_tiles, 1); n.ef_waves = ef_waves;
     n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
     n.hwl = params + L.hwl; n.hbl = params + L.hbl;
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;

@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KERNELS = ["EDGE_FWD", "NODE_FWD", "EDGE_BWD", "GATHER", "NODE_BWD"]
-MAXWG = 2048
+MAXWG = 8192
 bufs = {}
 for k in KERNELS:
     bufs[k] = torch.zeros(MAXWG * 16, dtype=torch.int64, device="cuda")
@@ -47,3 +47,15 @@ for k in KERNELS:
             rel = d[have, s] - d[have, 0]
             print("   slot %2d: %4d wgs, entry -> stamp median %6.2f  p90 %6.2f  max %6.2f us;  first entry -> stamp max %6.2f"
                   % (s, have.sum(), np.median(rel), np.percentile(rel, 90), rel.max(), d[have, s].max() - t0))
+    # per-XCD picture (workgroups are dealt round-robin to the 8 XCDs): exit time relative to the first entry
+    if len(d) >= 64:
+        idx = np.nonzero(live)[0]
+        ex = d[:, 15] - t0
+        print("   exit by XCD (blockIdx % 8): " + "  ".join("%d: %.0f/%.0f" % (x, np.median(ex[idx % 8 == x]), ex[idx % 8 == x].max()) for x in range(8)) + "  (median/max us)")
+        G = int(idx.max()) + 1
+        if G % 8 == 0:
+            lb = (idx % 8) * (G // 8) + idx // 8          # the kernels' XCD-aware logical index = position in the edge list
+            order = np.argsort(lb)
+            chunks = np.array_split(ex[order], 16)
+            print("   exit along the edge list (16 slices of the logical index, median): " + " ".join("%.0f" % np.median(c) for c in chunks))
+        # same CU? workgroups b and b + 8*k share an XCD; spread within slices tells hardware from data effects
