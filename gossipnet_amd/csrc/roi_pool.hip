@@ -10,9 +10,11 @@
 //              bin's pixels are visited in the reference's order (h, then w; strict >: the first maximum wins), so
 //              top and argmax are bit-exact.  (The reference CUDA kernel -- one thread per output element, per-thread
 //              ROI decode, 4-byte accesses -- is not the model.)
-//   backward   deterministic (default): one wave per input PIXEL, lanes over the channels; the wave walks the ROIs in
-//              index order (scalar box test), and for the ROIs that contain the pixel the feasible bins in (ph, pw)
-//              order -- the CPU kernel's summation order, so bottom_diff is bit-exact and reproducible.
+//   backward   deterministic (default): one wave per input PIXEL (a workgroup = a 2 x 2 block of pixels, which share most
+//              of their reads through L1), lanes over the channels; the wave walks the ROIs in index order (scalar box
+//              test), and for the ROIs that contain the pixel the feasible bins in (ph, pw) order -- the CPU kernel's
+//              summation order, so bottom_diff is bit-exact and reproducible; the next entry's loads are in flight while
+//              the current one is added.
 //              atomic (roi_pool_bwd_atomic_f32): every pooled element adds its gradient to its arg-max with one float
 //              atomic: O(R PH PW C) instead of re-reading each pooled element once per pixel of its bin; the order of
 //              the additions is not fixed.  NB this is the plain arg-max scatter, which the reference's RoiPoolGrad is
@@ -29,10 +31,12 @@ struct RoiBox { int start_w, start_h, end_w, end_h, batch; float bin_h, bin_w; }
 __device__ __forceinline__ RoiBox roi_decode(const float* __restrict__ roi, float scale, int PH, int PW) {
   RoiBox b;
   b.batch = (int)roi[0];
-  b.start_w = (int)round((double)(roi[1] * scale));
-  b.start_h = (int)round((double)(roi[2] * scale));
-  b.end_w = (int)round((double)(roi[3] * scale));
-  b.end_h = (int)round((double)(roi[4] * scale));
+  // (roundf on the float product: the product is exactly representable as a double and half-away-from-zero rounding to
+  // an integer is the same function in either precision, so this IS round((double)x) -- at a fraction of the instructions)
+  b.start_w = (int)roundf(roi[1] * scale);
+  b.start_h = (int)roundf(roi[2] * scale);
+  b.end_w = (int)roundf(roi[3] * scale);
+  b.end_h = (int)roundf(roi[4] * scale);
   const int roi_width = max(b.end_w - b.start_w + 1, 1);
   const int roi_height = max(b.end_h - b.start_h + 1, 1);
   b.bin_h = (float)roi_height / (float)PH;
@@ -65,22 +69,33 @@ __global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ da
       float4 mv[4]; int4 mi[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { mv[i] = make_float4(init, init, init, init); mi[i] = make_int4(-1, -1, -1, -1); }
-      for (int h = hstart; h < hend; ++h)
-        for (int w = wstart; w < wend; ++w) {
-          const int pb = (h * W + w) * C + c0 + 4 * lane;
-          float4 v[4];
+      // the bin's pixels in the reference's order (h, then w), TWO per step: eight 16-byte loads per lane in flight
+      // (a bin has 4-9 pixels; one pixel per step was a chain of as many L2 round trips)
+      const int bw = wend - wstart, npix = is_empty ? 0 : (hend - hstart) * bw;
+      for (int p = 0; p < npix; p += 2) {
+        const int p1 = min(p + 1, npix - 1);                  // (odd count: the last pixel twice -- a repeated value never wins a strict >)
+        const int pb0 = ((hstart + p / bw) * W + wstart + p % bw) * C + c0 + 4 * lane;
+        const int pb1 = ((hstart + p1 / bw) * W + wstart + p1 % bw) * C + c0 + 4 * lane;
+        float4 v0[4], v1[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            v[i] = (c0 + 256 * i + 4 * lane < C) ? *reinterpret_cast<const float4*>(bottom + pb + 256 * i) : make_float4(init, init, init, init);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int bi = pb + 256 * i;
-            if (v[i].x > mv[i].x) { mv[i].x = v[i].x; mi[i].x = bi; }
-            if (v[i].y > mv[i].y) { mv[i].y = v[i].y; mi[i].y = bi + 1; }
-            if (v[i].z > mv[i].z) { mv[i].z = v[i].z; mi[i].z = bi + 2; }
-            if (v[i].w > mv[i].w) { mv[i].w = v[i].w; mi[i].w = bi + 3; }
-          }
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = c0 + 256 * i + 4 * lane < C;
+          v0[i] = ok ? *reinterpret_cast<const float4*>(bottom + pb0 + 256 * i) : make_float4(init, init, init, init);
+          v1[i] = ok ? *reinterpret_cast<const float4*>(bottom + pb1 + 256 * i) : make_float4(init, init, init, init);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b0 = pb0 + 256 * i, b1 = pb1 + 256 * i;
+          if (v0[i].x > mv[i].x) { mv[i].x = v0[i].x; mi[i].x = b0; }
+          if (v0[i].y > mv[i].y) { mv[i].y = v0[i].y; mi[i].y = b0 + 1; }
+          if (v0[i].z > mv[i].z) { mv[i].z = v0[i].z; mi[i].z = b0 + 2; }
+          if (v0[i].w > mv[i].w) { mv[i].w = v0[i].w; mi[i].w = b0 + 3; }
+          if (v1[i].x > mv[i].x) { mv[i].x = v1[i].x; mi[i].x = b1; }
+          if (v1[i].y > mv[i].y) { mv[i].y = v1[i].y; mi[i].y = b1 + 1; }
+          if (v1[i].z > mv[i].z) { mv[i].z = v1[i].z; mi[i].z = b1 + 2; }
+          if (v1[i].w > mv[i].w) { mv[i].w = v1[i].w; mi[i].w = b1 + 3; }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = c0 + 256 * i + 4 * lane;
@@ -101,57 +116,157 @@ __global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ da
   }
 }
 
-// deterministic backward: one wave per input pixel (n, h, w)
+// Forward for C = 1024.  Two measured facts shape it (rocprofv3 --pmc on the one-wave-per-bin kernel: 63 % of the wave
+// time waiting for an issue slot, ~900 instructions per wave of which 485 scalar -- ROI decode, window arithmetic and integer
+// division by the window width -- against 15 loads; the 803 MB of stores alone take 119 us):
+//   * the kernel is INSTRUCTION-ISSUE bound, not memory bound: one wave now handles a whole ROW of bins (roi, ph, all pw)
+//     of one 256-channel slice, so the ROI is decoded once per seven bins, and the window is walked by nested h / w loops
+//     (four pixels of a row in flight; a clamped repeat of the row's last pixel never wins a strict >) -- no divisions;
+//   * the channel dimension is dealt to the XCDs (workgroups go round-robin to the 8 XCDs, blockIdx % 8): the feature map of
+//     an image (9.8 MB) does not fit an XCD's 4 MB L2, a 256-channel slice (2.4 MB) does; XCDs 2 s and 2 s + 1 take slice s.
+// Pixels of a bin are visited in the reference's order (h, then w; strict >: the first maximum wins): top / argmax bit-exact.
+__global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict__ data, int H, int W,
+                                                         const float* __restrict__ rois, int nrows, int PH, int PW,
+                                                         float scale, float* __restrict__ top, int* __restrict__ argmax) {
+  constexpr int C = 1024;
+  const int lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, slice = xcd >> 1;
+  const int row = ((int)(blockIdx.x >> 3) * 2 + (xcd & 1)) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (row >= nrows) return;
+  const int ph = row % PH, r = row / PH;
+  const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
+  int hstart = (int)floorf(ph * b.bin_h), hend = (int)ceilf((ph + 1) * b.bin_h);
+  hstart = min(max(hstart + b.start_h, 0), H); hend = min(max(hend + b.start_h, 0), H);
+  // (uniform image base + a lane-constant byte offset: the loads take the scalar-base form, no per-lane address arithmetic;
+  //  the arg-max candidates are the UNIFORM pixel offsets -- a select with a scalar operand -- and the lane's channel offset is
+  //  added once per bin)
+  const float* img = data + (size_t)b.batch * C * H * W + 256 * slice;
+  const unsigned lane_b = 16u * lane;
+  const int cbase = 256 * slice + 4 * lane;
+  size_t out = ((size_t)row * PW) * C + cbase;
+  for (int pw = 0; pw < PW; ++pw, out += C) {
+    int wstart = (int)floorf(pw * b.bin_w), wend = (int)ceilf((pw + 1) * b.bin_w);
+    wstart = min(max(wstart + b.start_w, 0), W); wend = min(max(wend + b.start_w, 0), W);
+    const bool is_empty = (hend <= hstart) || (wend <= wstart);
+    const float init = is_empty ? 0.f : -3.402823466e+38f;
+    float4 mv = make_float4(init, init, init, init); int4 mi = make_int4(-1, -1, -1, -1);
+    if (!is_empty) {
+      // the window's pixels as one sequence (h, then w), four per step; slot q walks positions q, q + 4, ... with its own
+      // (h, w) pair advanced by scalar adds -- no division, no padding at row ends; past the end a slot repeats the last
+      // pixel, which never wins a strict >
+      const int bw = wend - wstart, npix = (hend - hstart) * bw;
+      int hq[4], wq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { hq[q] = hstart; wq[q] = wstart + q; while (wq[q] >= wend) { wq[q] -= bw; ++hq[q]; } }
+      const int last = ((hend - 1) * W + wend - 1) * C;
+      for (int p = 0; p < npix; p += 4) {
+        int pb[4]; float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          pb[q] = p + q < npix ? (hq[q] * W + wq[q]) * C : last;
+          v[q] = ldg4_b(img + pb[q], lane_b);
+          wq[q] += 4;
+          while (wq[q] >= wend) { wq[q] -= bw; ++hq[q]; }     // (scalar; measured: a branch-free select chain here is slower -- the kernel is issue-bound)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (v[q].x > mv.x) { mv.x = v[q].x; mi.x = pb[q]; }
+          if (v[q].y > mv.y) { mv.y = v[q].y; mi.y = pb[q]; }
+          if (v[q].z > mv.z) { mv.z = v[q].z; mi.z = pb[q]; }
+          if (v[q].w > mv.w) { mv.w = v[q].w; mi.w = pb[q]; }
+        }
+      }
+      mi.x = mi.x < 0 ? -1 : mi.x + cbase; mi.y = mi.y < 0 ? -1 : mi.y + cbase + 1;
+      mi.z = mi.z < 0 ? -1 : mi.z + cbase + 2; mi.w = mi.w < 0 ? -1 : mi.w + cbase + 3;
+    }
+    *reinterpret_cast<float4*>(top + out) = mv;
+    *reinterpret_cast<int4*>(argmax + out) = mi;
+  }
+}
+
+// deterministic backward: one wave per input pixel (n, h, w), the four waves of a workgroup = a 2 x 2 block of pixels.
+// A pooled element's (argmax, top_diff) vector is re-read by every pixel of its bin's window (2-3 wide after the floor /
+// ceil overlap): neighbouring pixels walk the same ROIs and bins in the same order at the same time, so three of the four
+// reads of a vector come from the CU's L1 instead of HBM.  The entries (roi, ph, pw) of a pixel are visited in the CPU
+// kernel's order with the NEXT entry's eight 16-byte loads in flight while the current one is added.
 template <bool VEC4>
 __global__ void __launch_bounds__(256) roi_pool_bwd_pixel(const float* __restrict__ top_diff, const int* __restrict__ argmax,
                                                           const float* __restrict__ rois, int B, int H, int W, int C, int R,
                                                           int PH, int PW, float scale, float* __restrict__ bottom_diff) {
-  const int lane = threadIdx.x & 63;
-  const long long pix = __builtin_amdgcn_readfirstlane((int)((long long)blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (pix >= (long long)B * H * W) return;
-  const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int bw2 = (W + 1) >> 1, bh2 = (H + 1) >> 1;
+  const int blk = blockIdx.x;
+  const int n = blk / (bw2 * bh2), rem = blk - n * (bw2 * bh2);
+  const int h = 2 * (rem / bw2) + (wv >> 1), w = 2 * (rem % bw2) + (wv & 1);
+  if (n >= B || h >= H || w >= W) return;
+  const long long pix = ((long long)n * H + h) * W + w;
   const int here = (h * W + w) * C;
-  constexpr int NV = VEC4 ? 4 : 16;         // channel groups a lane keeps: 4 x float4 (C <= 1024) / 16 floats
-  float4 acc4[4]; float acc1[16];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-  (void)NV;
   for (int c0 = 0; c0 < C; c0 += 1024) {     // 1024 channels per outer pass
-    for (int r = 0; r < R; ++r) {
-      const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
-      if (n != b.batch) continue;
-      if (!(w >= b.start_w && w <= b.end_w && h >= b.start_h && h <= b.end_h)) continue;
-      int phstart = (int)floorf((float)(h - b.start_h) / b.bin_h), phend = (int)ceilf((float)(h - b.start_h + 1) / b.bin_h);   // :428-431
-      int pwstart = (int)floorf((float)(w - b.start_w) / b.bin_w), pwend = (int)ceilf((float)(w - b.start_w + 1) / b.bin_w);
-      phstart = min(max(phstart, 0), PH); phend = min(max(phend, 0), PH);
-      pwstart = min(max(pwstart, 0), PW); pwend = min(max(pwend, 0), PW);
-      for (int ph = phstart; ph < phend; ++ph)
-        for (int pw = pwstart; pw < pwend; ++pw) {
-          const size_t o = ((size_t)r * PH * PW + (size_t)ph * PW + pw) * C + c0;
-          if (VEC4) {
+    float4 acc4[4]; float acc1[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int c = 256 * i + 4 * lane;
-              if (c0 + c < C) {
-                const int4 am = *reinterpret_cast<const int4*>(argmax + o + c);
-                const float4 g = *reinterpret_cast<const float4*>(top_diff + o + c);
-                const int want = here + c0 + c;
-                if (am.x == want) acc4[i].x += g.x;
-                if (am.y == want + 1) acc4[i].y += g.y;
-                if (am.z == want + 2) acc4[i].z += g.z;
-                if (am.w == want + 3) acc4[i].w += g.w;
-              }
-            }
-          } else {
+    for (int i = 0; i < 4; ++i) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int c = 64 * i + lane;
-              if (c0 + c < C && argmax[o + c] == here + c0 + c) acc1[i] += top_diff[o + c];
-            }
-          }
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+    // iterator over the pixel's entries in (roi, ph, pw) order: scalar state
+    int r = -1, ph = 0, pw = 0, phend = 0, pwstart = 0, pwend = 0;
+    auto next = [&](size_t& o) -> bool {
+      for (;;) {
+        if (r >= 0 && ph < phend) {
+          if (pw < pwend) { o = ((size_t)r * PH * PW + (size_t)ph * PW + pw) * C + c0; ++pw; return true; }
+          ++ph; pw = pwstart;
+          continue;
         }
+        ++r;
+        if (r >= R) return false;
+        const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
+        ph = 0; phend = 0;                                     // (no entries unless the box test passes)
+        if (n != b.batch) continue;
+        if (!(w >= b.start_w && w <= b.end_w && h >= b.start_h && h <= b.end_h)) continue;
+        int phs = (int)floorf((float)(h - b.start_h) / b.bin_h), phe = (int)ceilf((float)(h - b.start_h + 1) / b.bin_h);   // :428-431
+        int pws = (int)floorf((float)(w - b.start_w) / b.bin_w), pwe = (int)ceilf((float)(w - b.start_w + 1) / b.bin_w);
+        ph = min(max(phs, 0), PH); phend = min(max(phe, 0), PH);
+        pwstart = min(max(pws, 0), PW); pwend = min(max(pwe, 0), PW);
+        pw = pwstart;
+      }
+    };
+    if (VEC4) {
+      int4 am[4], am_n[4]; float4 g[4], g_n[4];
+      auto load = [&](size_t o, int4 (&a_)[4], float4 (&g_)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = 256 * i + 4 * lane;
+          const bool ok = c0 + c < C;
+          a_[i] = ok ? *reinterpret_cast<const int4*>(argmax + o + c) : make_int4(-1, -1, -1, -1);
+          g_[i] = ok ? *reinterpret_cast<const float4*>(top_diff + o + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      size_t o = 0;
+      bool have = next(o);
+      if (have) load(o, am, g);
+      while (have) {
+        const bool have_n = next(o);
+        if (have_n) load(o, am_n, g_n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int want = here + c0 + 256 * i + 4 * lane;
+          if (am[i].x == want) acc4[i].x += g[i].x;
+          if (am[i].y == want + 1) acc4[i].y += g[i].y;
+          if (am[i].z == want + 2) acc4[i].z += g[i].z;
+          if (am[i].w == want + 3) acc4[i].w += g[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { am[i] = am_n[i]; g[i] = g_n[i]; }
+        have = have_n;
+      }
+    } else {
+      size_t o = 0;
+      while (next(o)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int c = 64 * i + lane;
+          if (c0 + c < C && argmax[o + c] == here + c0 + c) acc1[i] += top_diff[o + c];
+        }
+      }
     }
     float* out = bottom_diff + (size_t)pix * C + c0;
     if (VEC4) {
@@ -159,14 +274,12 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_pixel(const float* __restric
       for (int i = 0; i < 4; ++i) {
         const int c = 256 * i + 4 * lane;
         if (c0 + c < C) *reinterpret_cast<float4*>(out + c) = acc4[i];
-        acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int c = 64 * i + lane;
         if (c0 + c < C) out[c] = acc1[i];
-        acc1[i] = 0.f;
       }
     }
   }
@@ -197,7 +310,11 @@ extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, 
   if (!bottom_data || !bottom_rois || !top_data || !argmax) return GNET_ERR_INVALID;
   if ((long long)H * W * C > 0x7fffffffLL || nbins > 0x7fffffffLL) return GNET_ERR_UNSUPPORTED;   // argmax is an int32 index within the image
   const unsigned grid = (unsigned)((nbins + 3) / 4);
-  if ((C & 3) == 0)
+  if (C == 1024 && (long long)R * pooled_h <= 0x0fffffffLL) {
+    const int nrows = R * pooled_h;
+    roi_pool_fwd_rows<<<(unsigned)(8 * ((nrows + 7) / 8)), 256, 0, (hipStream_t)stream>>>(bottom_data, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax);
+  }
+  else if ((C & 3) == 0)
     roi_pool_fwd<true><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);
   else
     roi_pool_fwd<false><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);
@@ -216,9 +333,9 @@ extern "C" int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, co
   const long long total = (long long)R * pooled_h * pooled_w * C;
   if (total == 0) { HIP_CHECK_RET(hipMemsetAsync(bottom_diff, 0, (size_t)B * image_elems * sizeof(float), s)); return GNET_OK; }
   if (!top_diff || !argmax || !bottom_rois) return GNET_ERR_INVALID;
-  const long long pixels = (long long)B * H * W;
-  if (pixels > 0x7fffffffLL) return GNET_ERR_UNSUPPORTED;
-  const unsigned grid = (unsigned)((pixels + 3) / 4);
+  const long long blocks = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);       // one workgroup per 2 x 2 block of pixels
+  if (blocks > 0x7fffffffLL) return GNET_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)blocks;
   if ((C & 3) == 0)
     roi_pool_bwd_pixel<true><<<grid, 256, 0, s>>>(top_diff, argmax, bottom_rois, B, H, W, C, R, pooled_h, pooled_w, spatial_scale, bottom_diff);
   else
