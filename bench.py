@@ -290,6 +290,11 @@ def main():
         torch.cuda.synchronize()
         probe = {k_: ms_ for k_, (ms_, c_) in net.read_kernel_timing().items()}
         dominant = max(probe.items(), key=lambda kv: kv[1])[0]
+        # edge_fwd (16 launches) and pw_bwd_main (1 launch) are within ~1 % of each other per step, so which one is
+        # "dominant" flipped from run to run; within 3 % of the maximum the per-edge block kernel north_star names is
+        # reported (both are in roofline.mfma_kernels either way)
+        if "edge_fwd" in probe and probe["edge_fwd"] >= 0.97 * probe[dominant]:
+            dominant = "edge_fwd"
         net.enable_kernel_timing(classes=[dominant], capacity=(args.steps + 1) * 64)
 
     torch.cuda.synchronize()

@@ -2,8 +2,8 @@
 // (matching_module/det_matching.cc:72-160), all on device (the reference op is CPU-only and
 // forces a D->H->D round trip per step).
 //
-//   anno_iou      det_anno_iou = _iou(dets, gt, crowd) with IoA on crowd columns, class-masked
-//   match_cand    per detection: best two non-crowd candidates (iou >= 0.5) and first crowd hit
+//   anno_rows     one wave per detection: det_anno_iou = _iou(dets, gt, crowd) with IoA on crowd columns, class-masked,
+//                 and in the same pass the detection's best two non-crowd candidates (iou >= 0.5) and first crowd hit
 //   match_rank    score order: rank = #{j : s_j > s_i or (s_j == s_i and j > i)}
 //                 (std::sort ascending + reverse with ties resolved "higher index first")
 //   match_greedy  one wave per image walks the detections in score order, 64 at a time, resolving each batch in
@@ -22,60 +22,78 @@ __device__ __forceinline__ int image_of(const int* __restrict__ off, int n_img, 
   return lo;
 }
 
-__global__ void __launch_bounds__(256) anno_iou(const float4* __restrict__ dets, const int* __restrict__ det_classes,
-                                                const int* __restrict__ det_off, const float4* __restrict__ gts,
-                                                const unsigned char* __restrict__ gt_crowd,
-                                                const int* __restrict__ gt_classes, const int* __restrict__ gt_off,
-                                                const long long* __restrict__ anno_off, int n_det, int n_img,
-                                                int multiclass, float* __restrict__ out) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= n_det) return;
-  const int img = image_of(det_off, n_img, d);
-  const int g0 = gt_off[img], g1 = gt_off[img + 1];
-  const int m = g1 - g0;
-  float* row = out + anno_off[img] + (long long)(d - det_off[img]) * m;
-  const float4 a = dets[d];
-  const float a_area = (a.z - a.x) * (a.w - a.y);
-  const int dc = multiclass ? det_classes[d] : 0;
-  for (int g = g0; g < g1; ++g) {
-    const float4 b = gts[g];
-    const float b_area = (b.z - b.x) * (b.w - b.y);
-    const float w = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
-    const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
-    const float inter = w * h;
-    float v;
-    if (gt_crowd && gt_crowd[g]) v = inter / a_area;         // network.py:485-488
-    else v = inter / ((a_area + b_area) - inter);            // network.py:480-481
-    if (multiclass && dc != gt_classes[g]) v = 0.0f;         // network.py:182-187
-    row[g - g0] = v;
+// wave-wide maximum of a 64-bit key (butterfly over the 64 lanes; every lane ends with the maximum)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned hi = __shfl_xor((unsigned)(k >> 32), o), lo = __shfl_xor((unsigned)k, o);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    k = other > k ? other : k;
   }
+  return k;
 }
 
-// Per detection: the two best non-crowd candidates as keys (iou bits << 32 | gt index): the
-// reference's inner loop keeps the maximum iou >= 0.5 and lets a later equal iou win
-// (det_matching.cc:142-148), i.e. the maximum key.  cfirst = first crowd GT with iou >= 0.5
-// (det_matching.cc:138 breaks at the next crowd once one matched).
-__global__ void __launch_bounds__(256) match_cand(const float* __restrict__ iou, const long long* __restrict__ anno_off,
-                                                  const int* __restrict__ det_off, const int* __restrict__ gt_off,
-                                                  const unsigned char* __restrict__ ignore, int n_det, int n_img,
-                                                  unsigned long long* __restrict__ k1, unsigned long long* __restrict__ k2,
-                                                  int* __restrict__ ncand, int* __restrict__ cfirst) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
+// One WAVE per detection, lanes over the ground-truth boxes of its image (64 per pass): the box IoU row
+// (network.py:475-488, IoA on crowd columns, class mask :182-187) leaves as one coalesced store per pass, and -- with
+// CAND -- the matching's per-detection candidate records come out of the same pass: the two best non-crowd candidates
+// as keys (iou bits << 32 | gt index; the reference's inner loop keeps the maximum iou >= 0.5 and lets a later equal iou
+// win, det_matching.cc:142-148, i.e. the maximum key), their number, and the first crowd GT with iou >= 0.5
+// (det_matching.cc:138).  IOU = false reads a given IoU matrix instead of computing it (the standalone op).
+// (A thread per detection walking its row -- 64 lanes on 64 different cache lines, one element each per step -- took
+// 1.9 ms beside the forward pass for a 5 MB matrix.)
+template <bool IOU, bool CAND>
+__global__ void __launch_bounds__(256) anno_rows(const float4* __restrict__ dets, const int* __restrict__ det_classes,
+                                                 const int* __restrict__ det_off, const float4* __restrict__ gts,
+                                                 const unsigned char* __restrict__ gt_crowd,
+                                                 const int* __restrict__ gt_classes, const int* __restrict__ gt_off,
+                                                 const long long* __restrict__ anno_off, int n_det, int n_img,
+                                                 int multiclass, float* __restrict__ out,
+                                                 unsigned long long* __restrict__ k1, unsigned long long* __restrict__ k2,
+                                                 int* __restrict__ ncand, int* __restrict__ cfirst) {
+  const int lane = threadIdx.x & 63;
+  const int d = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (d >= n_det) return;
   const int img = image_of(det_off, n_img, d);
   const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
-  const float* row = iou + anno_off[img] + (long long)(d - det_off[img]) * m;
+  float* row = out + anno_off[img] + (long long)(d - det_off[img]) * m;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float a_area = 0.f; int dc = 0;
+  if (IOU) { a = dets[d]; a_area = (a.z - a.x) * (a.w - a.y); dc = multiclass ? det_classes[d] : 0; }
   unsigned long long b1 = 0, b2 = 0;
   int nc = 0, cf = -1;
-  for (int g = 0; g < m; ++g) {
-    const float v = row[g];
-    if (!(v >= 0.5f)) continue;
-    if (ignore[g0 + g]) { if (cf < 0) cf = g; continue; }
-    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)g;
-    ++nc;
-    if (key > b1) { b2 = b1; b1 = key; } else if (key > b2) { b2 = key; }
+  for (int gb = 0; gb < m; gb += 64) {
+    const int g = gb + lane;
+    const bool in = g < m;
+    float v = 0.f;
+    const bool crowd = in && gt_crowd && gt_crowd[g0 + g];
+    if (IOU) {
+      if (in) {
+        const float4 b = gts[g0 + g];
+        const float b_area = (b.z - b.x) * (b.w - b.y);
+        const float w = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+        const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+        const float inter = w * h;
+        if (crowd) v = inter / a_area;                           // network.py:485-488
+        else v = inter / ((a_area + b_area) - inter);            // network.py:480-481
+        if (multiclass && dc != gt_classes[g0 + g]) v = 0.0f;    // network.py:182-187
+        row[g] = v;
+      }
+    } else if (in) {
+      v = row[g];
+    }
+    if (CAND) {
+      const bool hit = in && v >= 0.5f;
+      const unsigned long long crowd_hits = __ballot(hit && crowd);
+      if (cf < 0 && crowd_hits) cf = gb + (int)__builtin_ctzll(crowd_hits);
+      const bool cand = hit && !crowd;
+      nc += (int)__popcll(__ballot(cand));
+      const unsigned long long key = cand ? (((unsigned long long)__float_as_uint(v) << 32) | (unsigned)g) : 0ull;
+      const unsigned long long p1 = wave_max_u64(key);           // keys are distinct (the index is part of them)
+      const unsigned long long p2 = wave_max_u64(key == p1 ? 0ull : key);
+      // merge the pass's best two into the running best two
+      if (p1 > b1) { b2 = p2 > b1 ? p2 : b1; b1 = p1; } else if (p1 > b2) { b2 = p1; }
+    }
   }
-  k1[d] = b1; k2[d] = b2; ncand[d] = nc; cfirst[d] = cf;
+  if (CAND && lane == 0) { k1[d] = b1; k2[d] = b2; ncand[d] = nc; cfirst[d] = cf; }
 }
 
 // order[lo + rank] = d with rank = number of detections of the image that sort before d (score descending,
@@ -281,9 +299,9 @@ int run_matching(const float* iou, const long long* anno_off, const int* det_off
   const size_t lds = (size_t)cap * 5;
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)match_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kMaxGt * 5)));
   const MatchWs w = carve_match(ws, n_det);
-  const int grid = (n_det + 255) / 256;
   if (!have_cand)
-    match_cand<<<grid, 256, 0, s>>>(iou, anno_off, det_off, gt_off, ignore, n_det, n_img, w.k1, w.k2, w.ncand, w.cfirst);
+    anno_rows<false, true><<<(n_det + 3) / 4, 256, 0, s>>>(nullptr, nullptr, det_off, nullptr, ignore, nullptr, gt_off, anno_off, n_det, n_img, 0,
+                                                            const_cast<float*>(iou), w.k1, w.k2, w.ncand, w.cfirst);
   match_rank<<<(n_det + 63) / 64, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
   match_greedy<<<n_img, 64, lds, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
                                       labels, weights, assign, cap);
@@ -342,14 +360,12 @@ extern "C" int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shap
   if (st != GNET_OK || shape->n_det == 0) return st;
   hipStream_t s = (hipStream_t)stream;
   const int N = shape->n_det;
-  const int grid = (N + 255) / 256;
-  if (shape->n_gt > 0)
-    anno_iou<<<grid, 256, 0, s>>>((const float4*)in->dets, in->det_classes, in->det_off, (const float4*)in->gt_boxes,
-                                  in->gt_crowd, in->gt_classes, in->gt_off, (const long long*)in->anno_off, N,
-                                  shape->n_img, cfg->num_classes > 1, buf->det_anno_iou);
   const MatchWs w = carve_match((char*)buf->match_ws + 1024, N);
-  match_cand<<<grid, 256, 0, s>>>(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
-                                  N, shape->n_img, w.k1, w.k2, w.ncand, w.cfirst);
+  // det_anno_iou and the candidate records in ONE pass (one wave per detection; an image without ground truth has
+  // empty rows and gets the "no candidate" records)
+  anno_rows<true, true><<<(N + 3) / 4, 256, 0, s>>>((const float4*)in->dets, in->det_classes, in->det_off, (const float4*)in->gt_boxes,
+                                                    in->gt_crowd, in->gt_classes, in->gt_off, (const long long*)in->anno_off, N,
+                                                    shape->n_img, cfg->num_classes > 1, buf->det_anno_iou, w.k1, w.k2, w.ncand, w.cfirst);
   return launch_status();
 }
 
@@ -383,7 +399,8 @@ extern "C" int gnet_box_iou(const float* a_boxes, int32_t n_a, const float* b_bo
   if (n_a < 0 || n_b < 0 || n_img < 1) return GNET_ERR_INVALID;
   if (n_a == 0 || n_b == 0) return GNET_OK;
   if (!a_boxes || !b_boxes || !a_off || !b_off || !out_off || !out) return GNET_ERR_INVALID;
-  anno_iou<<<(n_a + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float4*)a_boxes, nullptr, a_off, (const float4*)b_boxes, nullptr,
-                                                                nullptr, b_off, (const long long*)out_off, n_a, n_img, 0, out);
+  anno_rows<true, false><<<(n_a + 3) / 4, 256, 0, (hipStream_t)stream>>>((const float4*)a_boxes, nullptr, a_off, (const float4*)b_boxes, nullptr,
+                                                                          nullptr, b_off, (const long long*)out_off, n_a, n_img, 0, out,
+                                                                          nullptr, nullptr, nullptr, nullptr);
   return launch_status();
 }
