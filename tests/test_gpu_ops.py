@@ -118,7 +118,10 @@ def test_roi_pool_kat():
 
 
 @pytest.mark.parametrize("B,H,W,C,R,ph,pw,scale,seed", [(1, 38, 63, 64, 50, 7, 7, 1 / 16., 0), (2, 20, 30, 16, 40, 6, 6, 1 / 3., 1),
-                                                        (1, 10, 10, 3, 8, 7, 7, 1.0, 2), (1, 38, 63, 1024, 300, 7, 7, 1 / 16., 3)])
+                                                        (1, 10, 10, 3, 8, 7, 7, 1.0, 2), (1, 38, 63, 1024, 300, 7, 7, 1 / 16., 3),
+                                                        # C = 1024 takes the row-of-bins forward kernel: two images, odd map
+                                                        # sizes (the backward's 2 x 2 pixel blocks hang over the edge), PH != PW
+                                                        (2, 9, 11, 1024, 37, 3, 5, 1 / 4., 4), (1, 5, 7, 1024, 9, 7, 7, 1.0, 5)])
 def test_roi_pool_random_vs_oracle(B, H, W, C, R, ph, pw, scale, seed):
     from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool
     rng = np.random.default_rng(seed)
