@@ -97,15 +97,17 @@ __global__ void __launch_bounds__(256) anno_rows(const float4* __restrict__ dets
 }
 
 // order[lo + rank] = d with rank = number of detections of the image that sort before d (score descending,
-// ties by index descending -- the stable argsort of det_matching.cc:95-100 read backwards).  Four adjacent lanes
-// share a detection and take interleaved columns of the LDS score tile; 64 detections per workgroup.
+// ties by index descending -- the stable argsort of det_matching.cc:95-100 read backwards).  Sixteen adjacent lanes
+// share a detection and take interleaved columns of the LDS score tile; 16 detections per workgroup (four lanes and 64
+// detections per workgroup left 32 workgroups for a 2 000-detection image: a 125-compare chain per lane on an eighth of the chip).
+constexpr int RANK_LANES = 16, RANK_DETS = 256 / RANK_LANES;
 __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ score, const int* __restrict__ det_off,
                                                   int n_det, int n_img, int* __restrict__ order) {
   __shared__ float ss[1024];
-  const int q = threadIdx.x & 3;
-  const int d = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int q = threadIdx.x & (RANK_LANES - 1);
+  const int d = blockIdx.x * RANK_DETS + (threadIdx.x / RANK_LANES);
   const int dd = min(d, n_det - 1);
-  const int b0 = blockIdx.x * 64, b1 = min(n_det, b0 + 64) - 1;
+  const int b0 = blockIdx.x * RANK_DETS, b1 = min(n_det, b0 + RANK_DETS) - 1;
   const int cmin = det_off[image_of(det_off, n_img, b0)];
   const int cmax = det_off[image_of(det_off, n_img, b1) + 1];
   const int img = image_of(det_off, n_img, dd);
@@ -118,13 +120,13 @@ __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ scor
     for (int i = threadIdx.x; i < tn; i += 256) ss[i] = score[c0 + i];
     __syncthreads();
     const int jlo = max(lo, c0), jhi = min(hi, c0 + tn);
-    for (int j = jlo + q; j < jhi; j += 4) {
+    for (int j = jlo + q; j < jhi; j += RANK_LANES) {
       const float t = ss[j - c0];
       rank += (t > s || (t == s && j > dd)) ? 1 : 0;
     }
   }
-  rank += __shfl_xor(rank, 1);
-  rank += __shfl_xor(rank, 2);
+#pragma unroll
+  for (int o = 1; o < RANK_LANES; o <<= 1) rank += __shfl_xor(rank, o);
   if (q == 0 && d < n_det) order[lo + rank] = d;
 }
 
@@ -230,7 +232,8 @@ __global__ void __launch_bounds__(64) match_greedy(const float* __restrict__ iou
 }
 
 // network.py:282-313.  One workgroup per image.
-__global__ void __launch_bounds__(256) loss_kernel(const float* __restrict__ pred, const float* __restrict__ labels,
+constexpr int LOSS_THREADS = 1024;     // one workgroup per image: 2 detections per thread at N = 2000 (it was a chain of 8)
+__global__ void __launch_bounds__(LOSS_THREADS) loss_kernel(const float* __restrict__ pred, const float* __restrict__ labels,
                                                    float* __restrict__ weights, const int* __restrict__ assign,
                                                    const int* __restrict__ det_off, const int* __restrict__ gt_off,
                                                    const unsigned char* __restrict__ gt_crowd,
@@ -238,13 +241,13 @@ __global__ void __launch_bounds__(256) loss_kernel(const float* __restrict__ pre
                                                    const float* __restrict__ class_weights, int num_classes,
                                                    int normalize, float loss_mult, float grad_scale,
                                                    float* __restrict__ loss, float* __restrict__ d_logits) {
-  __shared__ float red[256];
+  __shared__ float red[LOSS_THREADS];
   const int img = blockIdx.x;
   const int d0 = det_off[img], d1 = det_off[img + 1], g0 = gt_off[img];
   const int n = d1 - d0;
   const float gscale = grad_scale * loss_mult * (normalize ? (n > 0 ? 1.0f / (float)n : 0.f) : 1.0f);
   float acc = 0.f;
-  for (int d = d0 + threadIdx.x; d < d1; d += 256) {
+  for (int d = d0 + threadIdx.x; d < d1; d += LOSS_THREADS) {
     const int a = assign[d];
     int cls = 0;
     if (a >= 0 && !gt_crowd[g0 + a]) cls = gt_classes[g0 + a];        // :286-297
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256) loss_kernel(const float* __restrict__ pre
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = LOSS_THREADS / 2; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -302,7 +305,7 @@ int run_matching(const float* iou, const long long* anno_off, const int* det_off
   if (!have_cand)
     anno_rows<false, true><<<(n_det + 3) / 4, 256, 0, s>>>(nullptr, nullptr, det_off, nullptr, ignore, nullptr, gt_off, anno_off, n_det, n_img, 0,
                                                             const_cast<float*>(iou), w.k1, w.k2, w.ncand, w.cfirst);
-  match_rank<<<(n_det + 63) / 64, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
+  match_rank<<<(n_det + RANK_DETS - 1) / RANK_DETS, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
   match_greedy<<<n_img, 64, lds, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
                                       labels, weights, assign, cap);
   return launch_status();
@@ -385,7 +388,7 @@ extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const 
                     buf->prediction, N, shape->n_gt, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
                     buf->det_gt_matching, true, s);
   if (st != GNET_OK) return st;
-  loss_kernel<<<shape->n_img, 256, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,
+  loss_kernel<<<shape->n_img, LOSS_THREADS, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,
                                            in->det_off, in->gt_off, in->gt_crowd, in->gt_classes, class_weights,
                                            cfg->num_classes, cfg->normalize_loss, cfg->loss_multiplyer, grad_scale,
                                            buf->loss, buf->d_logits);
