@@ -708,6 +708,16 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       gXin[r] = (a.x_prev && node < a.n_det) ? a.x_prev[(size_t)node * D_S + 32 * wave + col] : 0.f;
     }
   }
+  // (the row_ptr pairs of the segment-max record initialisation below: requested here with everything else, not in the
+  //  middle of the kernel where their round trip was exposed)
+  int eb[8], ee[8];
+  if (a.do_pre && a.pm_next) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int node = min(row0 + (tid >> 6) + 4 * j, a.n_det - 1);
+      eb[j] = a.row_ptr[node]; ee[j] = a.row_ptr[node + 1];
+    }
+  }
   if (a.do_pre) {
     load_bt<32>(gWr, a.wrt + 32 * wave, D_S, lane);
     if (a.wrnt) load_bt<32>(gWrn, a.wrnt + 32 * wave, D_S, lane);
@@ -780,12 +790,6 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
   GSTAMP(a, 3);
   if (a.do_pre) {
     if (a.pm_next) {
-      int eb[8], ee[8];                                  // (all sixteen row_ptr reads before the first use)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int node = min(row0 + (tid >> 6) + 4 * j, a.n_det - 1);
-        eb[j] = a.row_ptr[node]; ee[j] = a.row_ptr[node + 1];
-      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int node = row0 + (tid >> 6) + 4 * j;
