@@ -72,12 +72,21 @@ struct GeoArgs {
   int* edge_nz;     // [E+64] n, or n_det for self pairs (their neighbour features are zeroed, network.py:371-374) and the tail
   int n_det;
   float mult;       // cfg.gnet.pw_feat_multiplyer (network.py:199-200: the whole feature row times it)
+  // per detection, once per step (the same for all blocks): 1 = its segment-max records must start from zero -- it has
+  // no edge, or its edges are split between two waves' ranges of edge_fwd_w (combined atomically there); 0 = one wave
+  // writes them with a plain store.  node_fwd reads the flag instead of dividing row pointers by the range size 16 times
+  // per thread and launch.
+  const int* row_ptr; int* straddle; int ef_tiles, ef_waves;
 };
 
 // _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns are kept
 // as (row, score) pairs; the 7 geometry columns are evaluated in the reference's fp32 operation order.
 __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
+  for (int i = e; i < a.n_det; i += gridDim.x * 256) {
+    const int eb = a.row_ptr[i], ee = a.row_ptr[i + 1];
+    a.straddle[i] = (ee == eb || range_owner(eb >> 5, a.ef_tiles, a.ef_waves) != range_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
+  }
   if (e >= a.n_edge) {
     if (e < a.n_edge + 64) a.edge_nz[e] = a.n_det;
     return;
@@ -679,8 +688,9 @@ struct NodeFwdArgs {
   float* r; float* rc; float* rn; float* r_nb;
   // segment-max records of the NEXT block: rows of detections whose edges are split between two waves of
   // edge_fwd_w (combined atomically there) or that have no edge at all start from zero; every other row is
-  // written by a plain store.  ef_tiles / ef_waves = the tile and wave counts of edge_fwd_w's range assignment.
-  unsigned long long* pm_next; unsigned long long* parg_next; const int* row_ptr; int ef_tiles, ef_waves;
+  // written by a plain store.
+  unsigned long long* pm_next; unsigned long long* parg_next;
+  const int* straddle;           // [N] see GeoArgs (NULL: the batch has no edge at all -- every record starts from zero)
   const float* hw1t; const float* hb1; const float* hw2t; const float* hb2; const float* hwl; const float* hbl;
   float* head1; float* head2; float* pred;
   GNET_TRACE_FIELD
@@ -708,15 +718,12 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       gXin[r] = (a.x_prev && node < a.n_det) ? a.x_prev[(size_t)node * D_S + 32 * wave + col] : 0.f;
     }
   }
-  // (the row_ptr pairs of the segment-max record initialisation below: requested here with everything else, not in the
-  //  middle of the kernel where their round trip was exposed)
-  int eb[8], ee[8];
+  // (the flags of the segment-max record initialisation below: requested here with everything else, not in the middle of
+  //  the kernel where their round trip was exposed)
+  int strad[8];
   if (a.do_pre && a.pm_next) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int node = min(row0 + (tid >> 6) + 4 * j, a.n_det - 1);
-      eb[j] = a.row_ptr[node]; ee[j] = a.row_ptr[node + 1];
-    }
+    for (int j = 0; j < 8; ++j) strad[j] = a.straddle ? a.straddle[min(row0 + (tid >> 6) + 4 * j, a.n_det - 1)] : 1;
   }
   if (a.do_pre) {
     load_bt<32>(gWr, a.wrt + 32 * wave, D_S, lane);
@@ -793,7 +800,7 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int node = row0 + (tid >> 6) + 4 * j;
-        if (node < a.n_det && (ee[j] == eb[j] || range_owner(eb[j] >> 5, a.ef_tiles, a.ef_waves) != range_owner((ee[j] - 1) >> 5, a.ef_tiles, a.ef_waves))) {
+        if (node < a.n_det && strad[j]) {
           a.pm_next[(size_t)node * D_P + (tid & 63)] = 0ull;
           if (a.parg_next) a.parg_next[(size_t)node * D_P + (tid & 63)] = 0ull;
         }
@@ -926,6 +933,8 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.dets = (const float4*)in->dets; g.scores = in->det_scores; g.classes = in->det_classes;
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
     g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
+    g.row_ptr = buf->row_ptr; g.straddle = buf->scratch_i;
+    g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
     GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
     a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.einfo = (const int4*)buf->einfo;
@@ -948,7 +957,6 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));
   }
-  const int ef_tiles = (E + 31) / 32, ef_waves = ef_wg * EFW_WAVES;
 
   for (int b = 0; b <= B; ++b) {
     // node stage between edge kernels: finish block b (b >= 1), start block b+1 (b < B)
@@ -972,7 +980,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     } else { n.wrt = n.br = n.w1t = n.b1 = nullptr; n.r = n.rc = n.rn = nullptr; n.wrnt = n.brn = nullptr; n.r_nb = nullptr; }
     n.pm_next = b < B ? (unsigned long long*)buf->blk_pm[b + 1] : nullptr;
     n.parg_next = (b < B && training) ? (unsigned long long*)buf->blk_parg[b + 1] : nullptr;
-    n.row_ptr = buf->row_ptr; n.ef_tiles = max(ef_tiles, 1); n.ef_waves = ef_waves;
+    n.straddle = E > 0 ? buf->scratch_i : nullptr;
     n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
     n.hwl = params + L.hwl; n.hbl = params + L.hbl;
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
