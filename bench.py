@@ -295,7 +295,9 @@ def main():
         # reported (both are in roofline.mfma_kernels either way)
         if "edge_fwd" in probe and probe["edge_fwd"] >= 0.97 * probe[dominant]:
             dominant = "edge_fwd"
-        net.enable_kernel_timing(classes=[dominant], capacity=(args.steps + 1) * 64)
+        # inside the timed region every 4th launch of the dominant class is bracketed (4 of 16 per step): an event pair
+        # costs the stream ~4 us, 16 of them per step were 1 % of the step
+        net.enable_kernel_timing(classes=[dominant], capacity=(args.steps + 1) * 64, stride=4)
 
     torch.cuda.synchronize()
     if dist is not None:
@@ -368,7 +370,8 @@ def main():
                 ex_tflops = ex / avg_s / 1e12 if ex else ach
                 roofline = {"bound": "mfma", "kernel": cls, "achieved": round(ex_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ex_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                            "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt, "flops_per_launch": ex if ex else fl,
+                            "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt, "launches_note": "every 4th launch of the class inside the timed region is bracketed by HIP events",
+                            "flops_per_launch": ex if ex else fl,
                             "flops": "MFMA FLOPs issued per launch = FLOPs of the algorithm as formulated here (DESIGN.md 4)",
                             "reference_formulation": {"flops_per_launch": fl, "tflops": round(ach, 3),
                                                       "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -58,7 +58,7 @@ class gnet_buffers(C.Structure):
 EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_graph_transpose", "gnet_workspace_bytes", "gnet_plan",
            "gnet_forward", "gnet_loss", "gnet_match_prepare", "gnet_backward", "gnet_backward_prepare", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
-           "gnet_profiler_destroy", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
+           "gnet_profiler_destroy", "gnet_profiler_set_stride", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
            "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
@@ -133,6 +133,8 @@ def load():
     lib.gnet_profiler_create.argtypes = [i32, C.c_uint32, P(vp)]
     lib.gnet_profiler_read.restype = C.c_int
     lib.gnet_profiler_read.argtypes = [vp, P(C.c_double), P(i32)]
+    lib.gnet_profiler_set_stride.restype = C.c_int
+    lib.gnet_profiler_set_stride.argtypes = [vp, i32]
     lib.gnet_profiler_destroy.restype = C.c_int
     lib.gnet_profiler_destroy.argtypes = [vp]
     lib.gnet_adam_step.restype = C.c_int

@@ -32,11 +32,13 @@ struct GnetProfiler {
   hipEvent_t* ev0;
   hipEvent_t* ev1;
   int* cls;
+  int stride;                       // bracket every stride-th launch of a selected class (1 = every launch)
+  int seen[GNET_KCLASS_COUNT];      // launches of each class since the last read
 };
 struct ProfScope {
   GnetProfiler* p; int idx; hipStream_t s;
   ProfScope(void* prof, int cls, hipStream_t stream) : p((GnetProfiler*)prof), idx(-1), s(stream) {
-    if (p && ((p->mask >> cls) & 1u) && p->n < p->cap) {
+    if (p && ((p->mask >> cls) & 1u) && (p->seen[cls]++ % p->stride) == 0 && p->n < p->cap) {
       idx = p->n++;
       p->cls[idx] = cls;
       (void)hipEventRecord(p->ev0[idx], s);

@@ -134,7 +134,8 @@ extern "C" int gnet_plan(const gnet_config* cfg, const gnet_shape* shape, int tr
 extern "C" int gnet_profiler_create(int32_t capacity, uint32_t class_mask, void** out) {
   if (capacity <= 0 || !out) return GNET_ERR_INVALID;
   GnetProfiler* p = new GnetProfiler();
-  p->mask = class_mask; p->cap = capacity; p->n = 0;
+  p->mask = class_mask; p->cap = capacity; p->n = 0; p->stride = 1;
+  memset(p->seen, 0, sizeof(p->seen));
   p->ev0 = new hipEvent_t[capacity]; p->ev1 = new hipEvent_t[capacity]; p->cls = new int[capacity];
   for (int i = 0; i < capacity; ++i) {
     if (hipEventCreate(&p->ev0[i]) != hipSuccess || hipEventCreate(&p->ev1[i]) != hipSuccess) return GNET_ERR_HIP;
@@ -154,6 +155,14 @@ extern "C" int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count
     count[p->cls[i]] += 1;
   }
   p->n = 0;
+  memset(p->seen, 0, sizeof(p->seen));
+  return GNET_OK;
+}
+
+extern "C" int gnet_profiler_set_stride(void* profiler, int32_t stride) {
+  GnetProfiler* p = (GnetProfiler*)profiler;
+  if (!p || stride < 1) return GNET_ERR_INVALID;
+  p->stride = stride;
   return GNET_OK;
 }
 

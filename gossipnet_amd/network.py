@@ -566,8 +566,9 @@ class Gnet(object):
         reads = w1c * g_w1c + (pw1 - w1c) * g_w1 + (pw - pw1) * g_pw + B * (edge_p * g_edge + (blk - edge_p) * g_node) + head * g_head
         return {"winners_per_block": float(totals[:B].mean()), "pw_rows": int(totals[B]), "arena_bytes_read": int(reads) * 4}
 
-    def enable_kernel_timing(self, classes=None, capacity=4096):
-        """HIP-event timing of the selected kernel classes (names in _lib.KCLASSES) on the launch stream."""
+    def enable_kernel_timing(self, classes=None, capacity=4096, stride=1):
+        """HIP-event timing of the selected kernel classes (names in _lib.KCLASSES) on the launch stream; stride > 1
+        brackets only every stride-th launch of a class (a sample: an event pair costs the stream a few microseconds)."""
         mask = 0
         for i, nm in enumerate(_lib.KCLASSES):
             if classes is None or nm in classes:
@@ -577,6 +578,8 @@ class Gnet(object):
         out = C.c_void_p()
         _lib.check(self._lib.gnet_profiler_create(capacity, mask, C.byref(out)), "gnet_profiler_create")
         self._profiler = out.value
+        if stride != 1:
+            _lib.check(self._lib.gnet_profiler_set_stride(self._profiler, int(stride)), "gnet_profiler_set_stride")
 
     def read_kernel_timing(self):
         ms = (C.c_double * len(_lib.KCLASSES))()

@@ -292,6 +292,9 @@ enum {
 };
 int gnet_profiler_create(int32_t capacity, uint32_t class_mask, void** out);
 int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count);
+/* Bracket only every stride-th launch of each selected class (default 1): an event pair costs a few microseconds of the
+ * stream's time, so a timed region that wants a kernel's average duration samples its launches instead of bracketing all. */
+int gnet_profiler_set_stride(void* profiler, int32_t stride);
 int gnet_profiler_destroy(void* profiler);
 
 /* Version / build info string (static storage). */

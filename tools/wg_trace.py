@@ -59,3 +59,9 @@ for k in KERNELS:
             chunks = np.array_split(ex[order], 16)
             print("   exit along the edge list (16 slices of the logical index, median): " + " ".join("%.0f" % np.median(c) for c in chunks))
         # same CU? workgroups b and b + 8*k share an XCD; spread within slices tells hardware from data effects
+        if os.environ.get("WG_TRACE_DETAIL") == k:
+            s1 = d[:, 1] - d[:, 0]
+            order = np.argsort(idx)
+            print("   slot 1 (front) by dispatch order, 24 slices, median/max: " + " ".join("%.1f/%.1f" % (np.median(c), c.max()) for c in np.array_split(s1[order], 24)))
+            late = idx[s1 > np.percentile(s1, 85)]
+            print("   late workgroups: blockIdx %% 8 histogram %s; blockIdx // 8 quartiles %s" % (np.bincount(late % 8, minlength=8).tolist(), np.percentile(late // 8, [0, 25, 50, 75, 100]).tolist()))
