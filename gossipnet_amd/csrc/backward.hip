@@ -595,6 +595,17 @@ __device__ __forceinline__ void dma_rows32(float* sdst, const float* __restrict_
                                      (__attribute__((address_space(3))) void*)(sdst + row * LD256), 16, 0, 0);
   }
 }
+// ... with the four row indices of this wave already in registers (fetched a tile earlier): the copies are issued back to
+// back.  (Fetching an index right in front of its copy made the in-order memory counter wait for the copies issued before
+// it -- a 1 KB HBM round trip each -- before the next one could start.)
+__device__ __forceinline__ void dma_rows32_ids(float* sdst, const float* __restrict__ g, const int (&er)[4], int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* src = g + (size_t)er[q] * D_H + 4 * lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sdst + (wave * 4 + q) * LD256), 16, 0, 0);
+  }
+}
 
 __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -624,8 +635,10 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   // the row indices themselves are fetched one tile earlier still (ra / rb / rs), so the d3 source requests
   // never wait for an index
   int ra = 0, rb = 0, rs = 0, rs_tile = 0;
+  int dr[4] = {0, 0, 0, 0};                  // rows of the tile's h1 / h2 copies issued by this wave
 #define PB_LOAD_ROWIDS(tile_)                                                                           \
   do {                                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dr[q_] = PB_ROW(tile_, wave * 4 + q_);             \
     ra = PB_ROW(tile_, tid >> 5); rb = PB_ROW(tile_, (tid >> 5) + 16);                                  \
     rs = (tile_) * 32 + (tid & 31) < n_rows ? a.rows[(tile_) * 32 + (tid & 31)] : a.n_edge;   /* slack row */ \
   } while (0)
@@ -689,8 +702,8 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     // next tile's h1/h2 -> the other buffer (last read during the previous tile).  Issued here: the
     // d W2 phase below touches only LDS, so the in-order vmcnt never waits on this copy.
     if (t + (int)gridDim.x < ntiles) {
-      dma_rows32(nH1, a.h1, a.rows, e0 + (int)gridDim.x * 32, n_rows, wave, lane);
-      dma_rows32(nH1 + 32 * LD256, a.h2, a.rows, e0 + (int)gridDim.x * 32, n_rows, wave, lane);
+      dma_rows32_ids(nH1, a.h1, dr, wave, lane);
+      dma_rows32_ids(nH1 + 32 * LD256, a.h2, dr, wave, lane);
       PB_PREFETCH_D3();
       if (t + 2 * (int)gridDim.x < ntiles) PB_LOAD_ROWIDS(t + 2 * (int)gridDim.x);
     }
