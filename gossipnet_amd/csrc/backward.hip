@@ -366,8 +366,6 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
   if ((int)blockIdx.x < ntiles) load_node_tile<NF>(in, a, blockIdx.x * 32, tid);
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int row0 = t * 32;                    // first detection of this tile
-    NodeTileMid mid;
-    load_node_mid(mid, a, row0, tid);
     __syncthreads();                              // the previous tile's readers are done
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -386,6 +384,11 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         *reinterpret_cast<float4*>(sRn + row * LD64 + 4 * c4) = in.vn[j];
       }
     }
+    // this tile's post-stage inputs (q, segment-max records) are requested HERE, behind the staging of `in`: requested
+    // in front of it they sat between the tile's top loads and the (conservative: loop-carried, conditional loads) full
+    // memory wait of the staging, which then exposed their round trip at the top of every tile
+    NodeTileMid mid;
+    load_node_mid(mid, a, row0, tid);
     // the next tile of this workgroup is requested now and lands while this one is computed
     if (t + (int)gridDim.x < ntiles) load_node_tile<NF>(in, a, (t + gridDim.x) * 32, tid);
     __syncthreads();
@@ -448,6 +451,18 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
     }
     GSTAMP(a, 2);
     if (a.do_post) {
+      // q and the segment maxima -> LDS first: their registers are waited for BEFORE this stage's d_x stores are issued
+      // (behind the stores the in-order memory counter would wait for the stores' acknowledgement as well)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
+        *reinterpret_cast<float4*>(sQ + row * LD64 + 4 * c4) = mid.vq[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
+        sP[row * LD64 + ff] = __uint_as_float((unsigned)(mid.vpm[j] >> 32));
+      }
       // dz = d_x * (x_out > 0): also the shortcut gradient of block b-1 (network.py:407-408)
       {
         float4 g[4], x[4];
@@ -465,16 +480,6 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
           *reinterpret_cast<float4*>(sDZ + row * LD128 + 4 * c4) = v;
           if (row0 + row < a.n_det) *reinterpret_cast<float4*>(a.d_x + (size_t)(row0 + row) * D_S + 4 * c4) = v;
         }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int i = tid + 256 * j, row = i >> 4, c4 = i & 15;
-        *reinterpret_cast<float4*>(sQ + row * LD64 + 4 * c4) = mid.vq[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = tid + 256 * j, row = i >> 6, ff = i & 63;
-        sP[row * LD64 + ff] = __uint_as_float((unsigned)(mid.vpm[j] >> 32));
       }
       __syncthreads();
       // d W4 += q^T . dz : role cw owns output column tile cw
