@@ -189,6 +189,11 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output).  Edges are
     // sorted by centre, so the centre's row of W1 is re-read only when it changes (scalar branch: the
     // pair index is wave-uniform).
+    // the centre rows of the thread's first and last edge are requested up front, beside the first batch of neighbour
+    // rows: a tile rarely spans more than two centres, and a row fetched at the edge where the centre changes cost a
+    // full round trip with every other request of the batch drained behind it
+    const int rxA = __builtin_amdgcn_readfirstlane(sInf[eh].x), rxB = __builtin_amdgcn_readfirstlane(sInf[2 * (PW_T / 2 - 1) + eh].x);
+    const float wcA = a.w1[(size_t)rxA * D_H + f], wcB = a.w1[(size_t)rxB * D_H + f];
     int rc_prev = -1; float wc = 0.f;
 #pragma unroll
     for (int kb = 0; kb < PW_T / 2; kb += 16) {        // neighbour rows in two batches of 16 requests
@@ -204,7 +209,10 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
         const int el = 2 * (kb + k) + eh;
         const int4 inf = sInf[el];
         const int rx = __builtin_amdgcn_readfirstlane(inf.x);
-        if (rx != rc_prev) { wc = a.w1[(size_t)rx * D_H + f]; rc_prev = rx; }
+        if (rx != rc_prev) {
+          if (rx == rxA) wc = wcA; else if (rx == rxB) wc = wcB; else wc = a.w1[(size_t)rx * D_H + f];
+          rc_prev = rx;
+        }
         float v = __int_as_float(inf.z) * wc;
         v = fmaf(__int_as_float(inf.w), wn[k], v);
 #pragma unroll
