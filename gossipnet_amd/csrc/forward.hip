@@ -129,6 +129,7 @@ struct PwFwdArgs {
   const float* w3t; const float* b3;    // transposed [32,256]
   float* h1; float* h2; float* pw;
   int training;
+  GNET_TRACE_FIELD
 };
 
 // Memory discipline (vmcnt is one in-order counter for loads AND stores: a wait on a load also waits for
@@ -185,7 +186,9 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     // this tile's staging DMA was issued a tile ago, in front of at least the four pw stores of every wave: "all but
     // the four youngest operations" covers it without waiting for those stores
     if (wave < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (it == 10) GSTAMP(a, 0);
     __syncthreads();
+    if (it == 10) GSTAMP(a, 1);
     // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output).  Edges are
     // sorted by centre, so the centre's row of W1 is re-read only when it changes (scalar branch: the
     // pair index is wave-uniform).
@@ -221,7 +224,9 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting every edge's LDS reads (spills)
       }
     }
+    if (it == 10) GSTAMP(a, 2);
     __syncthreads();
+    if (it == 10) GSTAMP(a, 3);
     // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
     f32x16 acc0 = zero16(), acc1 = zero16();
     mma_abt2_gB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
@@ -237,7 +242,9 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
         *reinterpret_cast<float4*>(a.h1 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
       }
     }
+    if (it == 10) GSTAMP(a, 4);
     __syncthreads();   // every wave has finished reading fc1 activations
+    if (it == 10) GSTAMP(a, 5);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, half);
@@ -248,7 +255,9 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     f32x4 w3f[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3t + (size_t)col * D_H + 64 * kq + 4 * half + 8 * k);
+    if (it == 10) GSTAMP(a, 6);
     __syncthreads();
+    if (it == 10) GSTAMP(a, 7);
     // ---- phase 3: fc3 (256 -> 32): wave = (row tile, K quarter), partial sums through LDS
     {
       f32x16 acc = zero16();
@@ -268,7 +277,9 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
           *reinterpret_cast<float4*>(a.h2 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
         }
       }
+      if (it == 10) GSTAMP(a, 8);
       __syncthreads();   // every wave is done with the fc2 outputs: the partials may overwrite them
+      if (it == 10) GSTAMP(a, 9);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
     }
@@ -282,6 +293,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
       v += sR[3 * PW_T * D_E + idx];
       a.pw[(size_t)e0 * D_E + idx] = fmaxf(v + bias3, 0.f);     // rows past E land in the buffer's slack
     }
+    if (it == 10) GSTAMP(a, 15);
   }
 #undef PW_STAGE_DMA
 }
@@ -950,6 +962,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
     a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
     a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
+    GNET_TRACE_SET(a, "PW_FWD", true);
     const int tiles = (E + PW_T - 1) / PW_T;
     // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
