@@ -238,13 +238,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  (GNET_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist -- a functional check of the
+    # N > 1 code path on a one-GPU box, tests/test_gpu_train.py; the driver's runs use RCCL, one GPU per rank.)
+    backend = os.environ.get("GNET_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
 
     from gossipnet_amd.config import cfg, reset_cfg
