@@ -160,6 +160,35 @@ def _scatter_by_argmax(argmax, grad, rois, shape):
     return out.reshape(shape)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,R,lo,hi", [(256, 200, 0.5, 3.0), (512, 150, 0.2, 1.5), (1024, 330, 1.0, 8.0)])
+def test_roi_pool_backward_many_small_rois(C, R, lo, hi):
+    """The block backward (C a multiple of 256) places the bins of 64 ROIs at a time one per lane: small ROIs put all 49 bins of
+    a ROI on one 2 x 2 block, so a step has several hundred bins (many passes of 64), bins that no pixel of the block is valid
+    for, empty bins (arg-max -1) and bins whose arg-max lies in a neighbouring block.  Bit-exact against the CPU kernel."""
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool_raw, roi_pool_grad
+    rng = np.random.default_rng(C + R)
+    B, H, W, P = 2, 7, 6, 7
+    data = rng.normal(size=(B, H, W, C)).astype(np.float32)
+    xy = rng.uniform(-1, max(H, W), (R, 2)).astype(np.float32)
+    wh = rng.uniform(lo, hi, (R, 2)).astype(np.float32)
+    rois = np.concatenate([rng.integers(0, B, (R, 1)).astype(np.float32), xy, xy + wh], 1)
+    rtop, ram = native.roi_pool(data, rois, P, P, 1.0)
+    gtop = rng.normal(size=rtop.shape).astype(np.float32)
+    rgrad = native.roi_pool_grad((B, H, W, C), rois, ram, gtop, P, P, 1.0)
+    d = "cuda:0"
+    top, am = roi_pool_raw(torch.tensor(data, device=d), torch.tensor(rois, device=d), P, P, 1.0)
+    assert np.array_equal(am.cpu().numpy(), ram)
+    got = roi_pool_grad(torch.tensor(data, device=d), torch.tensor(rois, device=d), am, torch.tensor(gtop, device=d), P, P, 1.0, True)
+    assert np.array_equal(got.cpu().numpy(), rgrad)
+    # an arg-max input that is NOT the forward's (shifted by one pixel): the reference's window test decides, not the scatter
+    am2 = np.where(ram >= 0, (ram + C) % (H * W * C), -1).astype(np.int32)
+    rgrad2 = native.roi_pool_grad((B, H, W, C), rois, am2, gtop, P, P, 1.0)
+    got2 = roi_pool_grad(torch.tensor(data, device=d), torch.tensor(rois, device=d), torch.tensor(am2, device=d),
+                         torch.tensor(gtop, device=d), P, P, 1.0, True)
+    assert np.array_equal(got2.cpu().numpy(), rgrad2)
+
+
 def test_roi_pool_attr_errors():
     from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool
     from gossipnet_amd._lib import InvalidArgumentError

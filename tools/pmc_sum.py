@@ -11,7 +11,7 @@ NAMES = [("edge_bwd_w", "edge_bwd"), ("edge_fwd_w", "edge_fwd"), ("pw_bwd_main",
          ("list_fill", "list_fill"), ("list_count", "list_count"), ("blk_bwd_node", "node_bwd"), ("node_fwd", "node_fwd"),
          ("reduce_partials", "reduce_partials"), ("graph_sweep", "graph_sweep"), ("head_bwd", "head_bwd"),
          ("match_greedy", "match_greedy"), ("edge_geometry", "edge_geometry"), ("roi_pool_fwd", "roi_pool_fwd"),
-         ("roi_pool_bwd_pixel", "roi_pool_bwd_pixel"), ("roi_pool_bwd_atomic", "roi_pool_bwd_atomic"), ("imfeat", "imfeat")]
+         ("roi_pool_bwd_pixel", "roi_pool_bwd_pixel"), ("roi_pool_bwd_block", "roi_pool_bwd_block"), ("roi_pool_bwd_atomic", "roi_pool_bwd_atomic"), ("imfeat", "imfeat")]
 
 
 def summarise(path):
