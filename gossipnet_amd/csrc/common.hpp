@@ -170,6 +170,37 @@ __host__ __device__ __forceinline__ int range_owner(int item, int n_items, int n
   return (int)((((long long)item + 1) * n_parts - 1) / n_items);
 }
 
+// ---- edge_fwd_w's tile ranges ------------------------------------------------------------------------------------------
+// With three workgroups per CU the SIMD's issue arbiter favours the OLDEST wave: measured (tools/wg_trace.py, 8 images), the
+// first workgroup dispatched to a CU walks a tile in 8.5 us, the second in 10.4, the third in 13, and with equal ranges they
+// left at 125 / 143 / 160 us of a 170 us launch -- the last 35 us ran at one or two waves per SIMD.  The workgroups of an XCD
+// are dispatched in blockIdx order, a third of them per "layer" of the CUs, so the ranges are sized by layer: 1.18 : 1.00 :
+// 0.77 of the mean (1.215 : 1.02 : 0.765).  (If the dispatcher ever orders them differently only the balance is lost, not the result: the ranges
+// still tile the list, and efw_owner() -- used for the per-detection straddle flags -- is the inverse of efw_begin().)
+__host__ __device__ __forceinline__ bool efw_layered(int n_tiles, int n_waves) {
+  return n_waves % (8 * 3 * 4) == 0 && n_tiles >= 6 * n_waves;
+}
+__host__ __device__ __forceinline__ int efw_layer_cut(int k) { return k <= 0 ? 0 : k == 1 ? 405 : k == 2 ? 745 : 1000; }   // per mille, cumulative
+__host__ __device__ __forceinline__ int efw_begin(int gw, int n_tiles, int n_waves) {
+  if (!efw_layered(n_tiles, n_waves)) return range_begin(gw, n_tiles, n_waves);
+  if (gw >= n_waves) return n_tiles;
+  const int wpx = n_waves / 8, tw = wpx / 3;                 // waves per XCD, per layer of an XCD
+  const int x = gw / wpx, jx = gw - x * wpx, k = jx / tw, j = jx - k * tw;
+  const int x0 = range_begin(x, n_tiles, 8), tx = range_begin(x + 1, n_tiles, 8) - x0;
+  const int b0 = x0 + (int)((long long)tx * efw_layer_cut(k) / 1000), b1 = x0 + (int)((long long)tx * efw_layer_cut(k + 1) / 1000);
+  return b0 + range_begin(j, b1 - b0, tw);
+}
+__host__ __device__ __forceinline__ int efw_owner(int tile, int n_tiles, int n_waves) {
+  if (!efw_layered(n_tiles, n_waves)) return range_owner(tile, n_tiles, n_waves);
+  const int wpx = n_waves / 8, tw = wpx / 3;
+  const int x = range_owner(tile, n_tiles, 8);
+  const int x0 = range_begin(x, n_tiles, 8), tx = range_begin(x + 1, n_tiles, 8) - x0;
+  const int c1 = x0 + (int)((long long)tx * efw_layer_cut(1) / 1000), c2 = x0 + (int)((long long)tx * efw_layer_cut(2) / 1000);
+  const int k = tile >= c2 ? 2 : tile >= c1 ? 1 : 0;
+  const int b0 = k == 0 ? x0 : k == 1 ? c1 : c2, b1 = k == 0 ? c1 : k == 1 ? c2 : x0 + tx;
+  return x * wpx + k * tw + range_owner(tile - b0, b1 - b0, tw);
+}
+
 // ---- fp32 MFMA tile primitives ---------------------------------------------------------
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // the 16 accumulator registers hold D[row][col] with col = l&31,

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   for (int i = e; i < a.n_det; i += gridDim.x * 256) {
     const int eb = a.row_ptr[i], ee = a.row_ptr[i + 1];
-    a.straddle[i] = (ee == eb || range_owner(eb >> 5, a.ef_tiles, a.ef_waves) != range_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
+    a.straddle[i] = (ee == eb || efw_owner(eb >> 5, a.ef_tiles, a.ef_waves) != efw_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
   }
   if (e >= a.n_edge) {
     if (e < a.n_edge + 64) a.edge_nz[e] = a.n_det;
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   // image's worth when the batch has 8 images) resident in that XCD's L2 instead of all images in every L2.
   const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const int gw = lb * EFW_WAVES + wave;
-  const int t0 = range_begin(gw, ntiles, nwaves), t1 = range_begin(gw + 1, ntiles, nwaves);     // balanced: every wave has work
+  const int t0 = efw_begin(gw, ntiles, nwaves), t1 = efw_begin(gw + 1, ntiles, nwaves);     // (common.hpp: sized by dispatch layer)
   float* sRC = sHw + wave * (2 * D_P);
   // Kernel front = two dependent round trips, overlapped with the staging of the weights (at one or two tiles per
   // wave -- a single image -- the front is a third of the kernel):

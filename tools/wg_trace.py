@@ -63,5 +63,11 @@ for k in KERNELS:
             s1 = d[:, 1] - d[:, 0]
             order = np.argsort(idx)
             print("   slot 1 (front) by dispatch order, 24 slices, median/max: " + " ".join("%.1f/%.1f" % (np.median(c), c.max()) for c in np.array_split(s1[order], 24)))
+            o = idx // 8                                    # dispatch order within the XCD
+            oo = np.argsort(o, kind="stable")
+            print("   exit by dispatch order within the XCD (blockIdx // 8), 12 slices, median/max: " + " ".join("%.0f/%.0f" % (np.median(c), c.max()) for c in np.array_split(ex[oo], 12)))
+            for sl in (5, 9, 13):
+                if (d[:, sl] > 0).all():
+                    print("   slot %d by dispatch order, 12 slices, median: " % sl + " ".join("%.0f" % np.median(c) for c in np.array_split((d[:, sl] - t0)[oo], 12)))
             late = idx[s1 > np.percentile(s1, 85)]
             print("   late workgroups: blockIdx %% 8 histogram %s; blockIdx // 8 quartiles %s" % (np.bincount(late % 8, minlength=8).tolist(), np.percentile(late // 8, [0, 25, 50, 75, 100]).tolist()))
