@@ -77,12 +77,14 @@ struct GeoArgs {
   // writes them with a plain store.  node_fwd reads the flag instead of dividing row pointers by the range size 16 times
   // per thread and launch.
   const int* row_ptr; int* straddle; int ef_tiles, ef_waves;
+  int* pw_claim; int pw_claim0;   // pw_fwd's tile counter and its start value (the tiles behind every workgroup's first two)
 };
 
 // _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns are kept
 // as (row, score) pairs; the 7 geometry columns are evaluated in the reference's fp32 operation order.
 __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e == 0) *a.pw_claim = a.pw_claim0;
   for (int i = e; i < a.n_det; i += gridDim.x * 256) {
     const int eb = a.row_ptr[i], ee = a.row_ptr[i + 1];
     a.straddle[i] = (ee == eb || efw_owner(eb >> 5, a.ef_tiles, a.ef_waves) != efw_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
@@ -129,6 +131,7 @@ struct PwFwdArgs {
   const float* w3t; const float* b3;    // transposed [32,256]
   float* h1; float* h2; float* pw;
   int training;
+  int* claim;                           // tile counter (reset by edge_geometry, the launch in front of this one)
   GNET_TRACE_FIELD
 };
 
@@ -176,8 +179,15 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's staging data (the loop's first barrier publishes it)
   }
   int it = 0;
+  // Tiles are CLAIMED, not dealt: of a CU's two workgroups the older one wins the issue arbitration and walks a tile ~15 %
+  // faster -- dealt round-robin, the older half of the grid ran out of tiles at 1.46 ms of a 1.71 ms launch (wg_trace, slot
+  // 14) and every CU spent the last 15 % with one workgroup.  A workgroup's first two tiles are fixed (blockIdx, blockIdx +
+  // grid); every further one comes from a counter, claimed two tiles ahead (the atomic's round trip hides behind fc3, the
+  // staging DMA of a tile is issued one tile ahead as before).  Which workgroup computes a tile changes no bit of it.
+  __shared__ int sClaim;
+  int tile = blockIdx.x, next = blockIdx.x + gridDim.x;
 
-  for (int tile = blockIdx.x; tile * PW_T < a.n_edge; tile += gridDim.x, ++it) {
+  for (; tile * PW_T < a.n_edge; ++it) {
     const int e0 = tile * PW_T;
     // ---- phase 0: the tile's geometry columns and (row, score) pairs were staged during the previous tile
     const float* sGeo = sStage + (it & 1) * (PW_T * 12);
@@ -231,10 +241,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     f32x16 acc0 = zero16(), acc1 = zero16();
     mma_abt2_gB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
     // requested before this tile's stores: the next tile's geometry and records, straight into the other staging buffer
-    {
-      const int next = tile + (int)gridDim.x;
-      if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
-    }
+    if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
     if (a.training) {      // fc1 activations: rows [8 wave, 8 wave + 8) of the tile (rows past E land in the slack)
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -255,6 +262,8 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     f32x4 w3f[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3t + (size_t)col * D_H + 64 * kq + 4 * half + 8 * k);
+    int claimed = 0;
+    if (tid == 0) claimed = atomicAdd(a.claim, 1);            // (beside the W3 loads; read behind the fc3 MFMAs)
     if (it == 10) GSTAMP(a, 6);
     __syncthreads();
     if (it == 10) GSTAMP(a, 7);
@@ -283,6 +292,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
     }
+    if (tid == 0) sClaim = claimed;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -293,8 +303,11 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
       v += sR[3 * PW_T * D_E + idx];
       a.pw[(size_t)e0 * D_E + idx] = fmaxf(v + bias3, 0.f);     // rows past E land in the buffer's slack
     }
+    tile = next;
+    next = __builtin_amdgcn_readfirstlane(sClaim);             // (rewritten only behind the next tile's barriers)
     if (it == 10) GSTAMP(a, 15);
   }
+  GSTAMP(a, 14);                               // (trace builds: when the workgroup ran out of tiles)
 #undef PW_STAGE_DMA
 }
 
@@ -954,6 +967,8 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
     g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
     g.row_ptr = buf->row_ptr; g.straddle = buf->scratch_i;
+    const int pw_tiles = (E + PW_T - 1) / PW_T, pw_grid = min(pw_tiles, 512);
+    g.pw_claim = buf->scratch_i + N; g.pw_claim0 = 2 * pw_grid;
     g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
     GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
@@ -961,12 +976,11 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     a.w1 = params + L.pw1; a.b1 = params + L.pb1;
     a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
     a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
-    a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training;
+    a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training; a.claim = buf->scratch_i + N;
     GNET_TRACE_SET(a, "PW_FWD", true);
-    const int tiles = (E + PW_T - 1) / PW_T;
     // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
-    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<min(tiles, 512), 512, kPwFwdSmem, s>>>(a));
+    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<pw_grid, 512, kPwFwdSmem, s>>>(a));
   }
 
   const int ntile_n = (N + 31) / 32;

@@ -139,7 +139,7 @@ typedef struct gnet_buffers {
   float* w1_t;        /* [n_det,256] sum of d_h1 over the reversed pairs (neighbour role)          */
   float* packed_t;    /* [param_count] transposed copies of the weight matrices */
   float* arena;       /* per-workgroup partial weight gradients */
-  int32_t* scratch_i; /* [n_det + 1024] per detection: 1 = its segment-max records start from zero in every block (no edge, or its edges are split between two waves' ranges of the forward edge kernel), written once per step by gnet_forward */
+  int32_t* scratch_i; /* [n_det + 1024] per detection: 1 = its segment-max records start from zero in every block (no edge, or its edges are split between two waves' ranges of the forward edge kernel), written once per step by gnet_forward; [n_det], [n_det + 1]: tile counters of the pairwise-feature kernels (reset and used inside gnet_forward / gnet_backward) */
   void* match_ws;     /* det_matching_workspace_bytes(n_det, n_gt) */
   size_t match_ws_bytes;
   size_t arena_floats;

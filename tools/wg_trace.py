@@ -66,7 +66,7 @@ for k in KERNELS:
             o = idx // 8                                    # dispatch order within the XCD
             oo = np.argsort(o, kind="stable")
             print("   exit by dispatch order within the XCD (blockIdx // 8), 12 slices, median/max: " + " ".join("%.0f/%.0f" % (np.median(c), c.max()) for c in np.array_split(ex[oo], 12)))
-            for sl in (5, 9, 13):
+            for sl in (5, 9, 13, 14):
                 if (d[:, sl] > 0).all():
                     print("   slot %d by dispatch order, 12 slices, median: " % sl + " ".join("%.0f" % np.median(c) for c in np.array_split((d[:, sl] - t0)[oo], 12)))
             late = idx[s1 > np.percentile(s1, 85)]
