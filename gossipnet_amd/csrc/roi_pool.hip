@@ -320,37 +320,55 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_pixel(const float* __restric
 // ROIs' bounding ranges places the step's bins, in (roi, ph, pw) order, one per lane, each with the four pixels it is valid for;
 // the walk is then two readlanes, two loads and the compare-adds per bin.  Bit-exact: each (pixel, channel) sum is formed by one
 // lane, in the reference's order, in a register, from exactly the entries the reference's window test admits.
-template <int D>
-__global__ void __launch_bounds__(256) roi_pool_bwd_block(const float* __restrict__ top_diff, const int* __restrict__ argmax,
+// The four waves of a workgroup are the (up to) four 256-channel slices of ONE block: their bookkeeping is identical, so they
+// share it -- in a round of four 64-ROI steps wave w does step w's scan and places its bins, leaves (bin, valid) per lane in
+// LDS, and after a barrier every wave walks the four steps' bins for its own channels.  (A step with more than 64 * RPB_PASSES
+// bins -- many tiny ROIs on one block -- is flagged and redone in full by each wave: correct, just not shared.)
+constexpr int RPB_PASSES = 2;
+// CPL channels per lane (4: 16-byte loads, 256-channel slices; 2: 8-byte loads, 128-channel slices), NW waves = slices per workgroup
+template <int D, int CPL, int NW>
+__global__ void __launch_bounds__(64 * NW) roi_pool_bwd_block(const float* __restrict__ top_diff, const int* __restrict__ argmax,
                                                           const float* __restrict__ rois, int B, int H, int W, int C, int R,
                                                           int PH, int PW, float scale, int nwork, float* __restrict__ bottom_diff) {
+  constexpr int SLC = 64 * CPL;                               // channels of a slice
+  __shared__ int sBins[2][NW][RPB_PASSES][2][64];             // [round parity][step][pass][bin | valid][lane]
+  __shared__ int sTotal[2][NW];                                // bins of the step, or -1: redo it in full
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (L >= nwork) return;
-  const int nsl = C >> 8, tw_n = (W + 3) >> 2, th_n = (H + 3) >> 2;
-  const int sl = L % nsl;
-  int t = L / nsl;
+  const int nsl = C / SLC, nsg = (nsl + NW - 1) / NW, tw_n = (W + 3) >> 2, th_n = (H + 3) >> 2;
+  const int sl = NW * (L % nsg) + wv;                          // this wave's slice (past the last one: bookkeeping only)
+  int t = L / nsg;
+  const int sub = t & 3;                                      // consecutive work items: the four blocks of a 4 x 4 tile
+  t >>= 2;
   const int n = t / (th_n * tw_n);
   t -= n * (th_n * tw_n);
-  const int hb = (t / tw_n) * 4 + 2 * (wv >> 1), wb = (t % tw_n) * 4 + 2 * (wv & 1);   // the block's first pixel
-  if (hb >= H || wb >= W) return;
+  const int hb = (t / tw_n) * 4 + 2 * (sub >> 1), wb = (t % tw_n) * 4 + 2 * (sub & 1);   // the block's first pixel
+  if (hb >= H || wb >= W) return;                             // (the whole workgroup)
+  const bool live = sl < nsl;
   const bool row1 = hb + 1 < H, col1 = wb + 1 < W;
-  const int c = 256 * sl + 4 * lane;
+  const int c = live ? SLC * sl + CPL * lane : 0;
   float* out = bottom_diff + (((size_t)n * H + hb) * W + wb) * C + c;
   const size_t o_row = (size_t)W * C;
-  float4 acc[4];
+  float acc[4][CPL];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[p][i] = 0.f;
+  typedef int ivec __attribute__((ext_vector_type(CPL)));
+  typedef float fvec __attribute__((ext_vector_type(CPL)));
   const int* am_lane = argmax + c;
   const float* g_lane = top_diff + c;
   const int pix0 = (hb * W + wb) * C;                         // argmax - c of pixel 0's elements; + C, + W C, + W C + C for the others
 
-  for (int r0 = 0; r0 < R; r0 += 64) {
-    // lane j: ROI r0 + j.  rows / cols: [lo, hi) bin range of each row / column of the block as four bytes (empty = 0, 0);
-    // box: the bounding range of the block (ph_lo, pw_lo, width) and cnt = its number of bins
-    int cnt = 0;
-    unsigned rows = 0u, cols = 0u, box = 0u;
+  // lane j: ROI r0 + j.  rows / cols: [lo, hi) bin range of each row / column of the block as four bytes (empty = 0, 0);
+  // box: the bounding range of the block (ph_lo, pw_lo, width); cnt = its number of bins; pre = exclusive prefix of cnt
+  int cnt = 0, pre = 0, total = 0;
+  unsigned rows = 0u, cols = 0u, box = 0u;
+  unsigned long long hm = 0ull;
+  auto scan = [&](int r0) {
+    cnt = 0; rows = 0u; cols = 0u; box = 0u; total = 0;
     if (r0 + lane < R) {
       const RoiBox b = roi_decode(rois + (size_t)(r0 + lane) * 5, scale, PH, PW);
       if (b.batch == n) {
@@ -375,86 +393,133 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_block(const float* __restric
         box = (unsigned)ph_lo | ((unsigned)pw_lo << 8) | ((unsigned)max(pw_hi - pw_lo, 1) << 16);
       }
     }
-    const unsigned long long hm = __ballot(cnt > 0);
-    if (hm == 0ull) continue;
-    int pre = cnt;                                            // inclusive prefix sum over the lanes
+    hm = __ballot(cnt > 0);
+    if (hm == 0ull) return;
+    pre = cnt;                                                // inclusive prefix sum over the lanes
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) { const int up = __shfl_up(pre, sft); if (lane >= sft) pre += up; }
-    const int total = __builtin_amdgcn_readlane(pre, 63);
+    total = __builtin_amdgcn_readlane(pre, 63);
     pre -= cnt;
-    for (int base = 0; base < total; base += 64) {
-      // bin base + lane of the step: which ROI, which bin of its bounding range
-      int k = 0, e_r = 0;
-      unsigned e_rows = 0u, e_cols = 0u, e_box = 1u << 16;
-      for (unsigned long long hh = hm; hh != 0ull; hh &= hh - 1ull) {
-        const int j = __builtin_ctzll(hh);
-        const int pj = __builtin_amdgcn_readlane(pre, j), cj = __builtin_amdgcn_readlane(cnt, j);
-        if (pj + cj <= base) continue;
-        if (pj >= base + 64) break;
-        const unsigned d = (unsigned)(lane + base - pj);
-        if (d < (unsigned)cj) {
-          k = (int)d; e_r = r0 + j;
-          e_rows = (unsigned)__builtin_amdgcn_readlane((int)rows, j); e_cols = (unsigned)__builtin_amdgcn_readlane((int)cols, j);
-          e_box = (unsigned)__builtin_amdgcn_readlane((int)box, j);
+  };
+  // bin base + lane of the scanned step: which ROI, which bin of its bounding range, which of the four pixels take it
+  auto place = [&](int r0, int base, int& binv, int& validv) {
+    int k = 0, e_r = 0;
+    unsigned e_rows = 0u, e_cols = 0u, e_box = 1u << 16;
+    for (unsigned long long hh = hm; hh != 0ull; hh &= hh - 1ull) {
+      const int j = __builtin_ctzll(hh);
+      const int pj = __builtin_amdgcn_readlane(pre, j), cj = __builtin_amdgcn_readlane(cnt, j);
+      if (pj + cj <= base) continue;
+      if (pj >= base + 64) break;
+      const unsigned d = (unsigned)(lane + base - pj);
+      if (d < (unsigned)cj) {
+        k = (int)d; e_r = r0 + j;
+        e_rows = (unsigned)__builtin_amdgcn_readlane((int)rows, j); e_cols = (unsigned)__builtin_amdgcn_readlane((int)cols, j);
+        e_box = (unsigned)__builtin_amdgcn_readlane((int)box, j);
+      }
+    }
+    // k / width for small integers: (k + 0.5) / width is at least 0.5 / 255 away from an integer, the rcp's error far below
+    const int bww = (int)(e_box >> 16);
+    const int qd = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)bww));
+    const int ph = (int)(e_box & 255u) + qd, pw = (int)((e_box >> 8) & 255u) + (k - qd * bww);
+    binv = (e_r * PH + ph) * PW + pw;
+    const bool r0ok = ph >= (int)(e_rows & 255u) && ph < (int)((e_rows >> 8) & 255u);
+    const bool r1ok = ph >= (int)((e_rows >> 16) & 255u) && ph < (int)(e_rows >> 24);
+    const bool c0ok = pw >= (int)(e_cols & 255u) && pw < (int)((e_cols >> 8) & 255u);
+    const bool c1ok = pw >= (int)((e_cols >> 16) & 255u) && pw < (int)(e_cols >> 24);
+    validv = (r0ok && c0ok ? 1 : 0) | (r0ok && c1ok ? 2 : 0) | (r1ok && c0ok ? 4 : 0) | (r1ok && c1ok ? 8 : 0);
+  };
+  // the walk over m <= 64 placed bins: groups of D bins, the next group's loads in flight while one is added (unconditional
+  // loads -- a slot past the end re-reads element 0 with no pixel valid -- so that the waits are counted, not drained).  D = 2
+  // measured best (4: +3 %, 8: +10 %): the walk is bound by instruction issue, not by loads in flight, and a deeper group
+  // means more padding slots
+  auto walk = [&](const int binv, const int validv, const int m) {
+    ivec amA[D], amB[D]; fvec gA[D], gB[D];
+    auto issue = [&](int e, ivec (&a_)[D], fvec (&g_)[D]) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const int bin = __builtin_amdgcn_readlane(binv, min(e + q, 63));
+        const size_t o = e + q < m ? (size_t)bin * C : (size_t)0;
+        a_[q] = *reinterpret_cast<const ivec*>(am_lane + o); g_[q] = *reinterpret_cast<const fvec*>(g_lane + o);
+      }
+    };
+    auto consume = [&](int e, const ivec (&a_)[D], const fvec (&g_)[D]) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const int v = e + q < m ? __builtin_amdgcn_readlane(validv, min(e + q, 63)) : 0;
+        int ax[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) ax[i] = a_[q][i] - c - i;     // = pixel * C where it is this lane's channel
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          // (uniform: the pixel's offset)  compare-into-EXEC, add under it, EXEC back to all lanes (every lane of the wave is
+          // live here): two vector instructions per (pixel, component) instead of three; pixels the reference's window test
+          // excludes for this bin are skipped
+          if (!((v >> p) & 1)) continue;                      // (uniform)
+          const int wq = pix0 + (p & 1) * C + (p >> 1) * W * C;
+#pragma unroll
+          for (int i = 0; i < CPL; ++i)
+            asm volatile("v_cmpx_eq_i32_e32 vcc, %2, %1\n\tv_add_f32_e32 %0, %0, %3\n\ts_mov_b64 exec, -1"
+                         : "+v"(acc[p][i]) : "v"(ax[i]), "s"(wq), "v"(g_[q][i]) : "vcc");
         }
       }
-      // k / width for small integers: (k + 0.5) / width is at least 0.5 / 255 away from an integer, the rcp's error far below
-      const int bww = (int)(e_box >> 16);
-      const int qd = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)bww));
-      const int ph = (int)(e_box & 255u) + qd, pw = (int)((e_box >> 8) & 255u) + (k - qd * bww);
-      const int binv = (e_r * PH + ph) * PW + pw;
-      const bool r0ok = ph >= (int)(e_rows & 255u) && ph < (int)((e_rows >> 8) & 255u);
-      const bool r1ok = ph >= (int)((e_rows >> 16) & 255u) && ph < (int)(e_rows >> 24);
-      const bool c0ok = pw >= (int)(e_cols & 255u) && pw < (int)((e_cols >> 8) & 255u);
-      const bool c1ok = pw >= (int)((e_cols >> 16) & 255u) && pw < (int)(e_cols >> 24);
-      const int validv = (r0ok && c0ok ? 1 : 0) | (r0ok && c1ok ? 2 : 0) | (r1ok && c0ok ? 4 : 0) | (r1ok && c1ok ? 8 : 0);
-      const int m = min(64, total - base);
-      // the walk: groups of D bins, the next group's loads in flight while one is added (unconditional loads -- a slot past the
-      // end re-reads element 0 with no pixel valid -- so that the waits are counted, not drained).  D = 2 measured best (4: +3 %,
-      // 8: +10 %): the walk is bound by instruction issue, not by loads in flight, and a deeper group means more padding slots
-      int4 amA[D], amB[D]; float4 gA[D], gB[D];
-      auto issue = [&](int e, int4 (&a_)[D], float4 (&g_)[D]) {
-#pragma unroll
-        for (int q = 0; q < D; ++q) {
-          const int bin = __builtin_amdgcn_readlane(binv, min(e + q, 63));
-          const size_t o = e + q < m ? (size_t)bin * C : (size_t)0;
-          a_[q] = *reinterpret_cast<const int4*>(am_lane + o); g_[q] = *reinterpret_cast<const float4*>(g_lane + o);
-        }
-      };
-      auto consume = [&](int e, const int4 (&a_)[D], const float4 (&g_)[D]) {
-#pragma unroll
-        for (int q = 0; q < D; ++q) {
-          const int v = e + q < m ? __builtin_amdgcn_readlane(validv, min(e + q, 63)) : 0;
-          const int ax = a_[q].x - c, ay = a_[q].y - c - 1, az = a_[q].z - c - 2, aw = a_[q].w - c - 3;   // = pixel * C where it is this lane's channel
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            // (uniform: the pixel's offset or a value no arg-max has)  compare-into-EXEC, add under it, EXEC back to all lanes
-            // (every lane of the wave is live here): two vector instructions per (pixel, component) instead of three
-            if (!((v >> p) & 1)) continue;                    // (uniform)
-            const int wq = pix0 + (p & 1) * C + (p >> 1) * W * C;
-            asm volatile("v_cmpx_eq_i32_e32 vcc, %8, %4\n\tv_add_f32_e32 %0, %0, %9\n\ts_mov_b64 exec, -1\n\t"
-                         "v_cmpx_eq_i32_e32 vcc, %8, %5\n\tv_add_f32_e32 %1, %1, %10\n\ts_mov_b64 exec, -1\n\t"
-                         "v_cmpx_eq_i32_e32 vcc, %8, %6\n\tv_add_f32_e32 %2, %2, %11\n\ts_mov_b64 exec, -1\n\t"
-                         "v_cmpx_eq_i32_e32 vcc, %8, %7\n\tv_add_f32_e32 %3, %3, %12\n\ts_mov_b64 exec, -1"
-                         : "+v"(acc[p].x), "+v"(acc[p].y), "+v"(acc[p].z), "+v"(acc[p].w)
-                         : "v"(ax), "v"(ay), "v"(az), "v"(aw), "s"(wq), "v"(g_[q].x), "v"(g_[q].y), "v"(g_[q].z), "v"(g_[q].w)
-                         : "vcc");
+    };
+    issue(0, amA, gA);
+    for (int e = 0; e < m; e += 2 * D) {
+      issue(e + D, amB, gB);
+      consume(e, amA, gA);
+      issue(e + 2 * D, amA, gA);
+      consume(e + D, amB, gB);
+    }
+  };
+
+  int par = 0;
+  for (int rr = 0; rr < R; rr += 64 * NW, par ^= 1) {
+    // this wave's step of the round: scan, place, publish
+    {
+      const int r0 = rr + 64 * wv;
+      int tot = 0;
+      if (r0 < R) {
+        scan(r0);
+        tot = total;
+        if (tot > 64 * RPB_PASSES) tot = -1;
+        else
+          for (int ps = 0; ps * 64 < tot; ++ps) {
+            int binv, validv;
+            place(r0, ps * 64, binv, validv);
+            sBins[par][wv][ps][0][lane] = binv; sBins[par][wv][ps][1][lane] = validv;
           }
+      }
+      if (lane == 0) sTotal[par][wv] = tot;
+    }
+    __syncthreads();       // (one barrier per round: a slot of this parity is rewritten two rounds on, behind the next barrier)
+    if (!live) continue;
+    for (int w2 = 0; w2 < NW; ++w2) {
+      const int tot = sTotal[par][w2];
+      if (tot == 0) continue;
+      if (tot > 0) {
+        for (int ps = 0; ps * 64 < tot; ++ps) walk(sBins[par][w2][ps][0][lane], sBins[par][w2][ps][1][lane], min(64, tot - ps * 64));
+      } else {             // too many bins for the shared slots: the whole step here
+        const int r0 = rr + 64 * w2;
+        scan(r0);
+        for (int base = 0; base < total; base += 64) {
+          int binv, validv;
+          place(r0, base, binv, validv);
+          walk(binv, validv, min(64, total - base));
         }
-      };
-      issue(0, amA, gA);
-      for (int e = 0; e < m; e += 2 * D) {
-        issue(e + D, amB, gB);
-        consume(e, amA, gA);
-        issue(e + 2 * D, amA, gA);
-        consume(e + D, amB, gB);
       }
     }
   }
-  *reinterpret_cast<float4*>(out) = acc[0];
-  if (col1) *reinterpret_cast<float4*>(out + C) = acc[1];
-  if (row1) *reinterpret_cast<float4*>(out + o_row) = acc[2];
-  if (row1 && col1) *reinterpret_cast<float4*>(out + o_row + C) = acc[3];
+  if (!live) return;
+  auto put = [&](float* dst, const float (&a_)[CPL]) {
+    fvec v;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = a_[i];
+    *reinterpret_cast<fvec*>(dst) = v;
+  };
+  put(out, acc[0]);
+  if (col1) put(out + C, acc[1]);
+  if (row1) put(out + o_row, acc[2]);
+  if (row1 && col1) put(out + o_row + C, acc[3]);
 }
 
 __global__ void __launch_bounds__(256) roi_pool_bwd_atomic(const float* __restrict__ top_diff, const int* __restrict__ argmax,
@@ -509,11 +574,14 @@ extern "C" int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, co
   if (blocks > 0x7fffffffLL) return GNET_ERR_UNSUPPORTED;
   const unsigned grid = (unsigned)blocks;
   if ((C & 255) == 0 && pooled_h <= 255 && pooled_w <= 255 && (long long)R * pooled_h * pooled_w < 0x7fffffffLL) {
-    const long long nwork = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * (C >> 8);     // workgroup = a 4 x 4 tile of one slice
+    // 4 channels per lane, 4 slices per workgroup.  Measured at the contract shape: 2 channels per lane x 8 waves 707 us, 8 x 2
+    // 719 us, 8 x 4 (two of the waves bookkeeping only) 683 us, this one 617 us
+    constexpr int CPL = 4, NW = 4;
+    const long long nwork = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) * 4 * ((C / (64 * CPL) + NW - 1) / NW);   // workgroup = a 2 x 2 block, NW slices
     if (nwork > 0x7ffffff0LL) return GNET_ERR_UNSUPPORTED;
     const unsigned g8 = 8u * (unsigned)((nwork + 7) / 8);
-    roi_pool_bwd_block<2><<<g8, 256, 0, s>>>(top_diff, argmax, bottom_rois, B, H, W, C, R, pooled_h, pooled_w, spatial_scale, (int)nwork,
-                                            bottom_diff);
+    roi_pool_bwd_block<2, CPL, NW><<<g8, 64 * NW, 0, s>>>(top_diff, argmax, bottom_rois, B, H, W, C, R, pooled_h, pooled_w, spatial_scale,
+                                                         (int)nwork, bottom_diff);
   }
   else if ((C & 3) == 0)
     roi_pool_bwd_pixel<true><<<grid, 256, 0, s>>>(top_diff, argmax, bottom_rois, B, H, W, C, R, pooled_h, pooled_w, spatial_scale, bottom_diff);
