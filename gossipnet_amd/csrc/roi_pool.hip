@@ -320,19 +320,20 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_pixel(const float* __restric
 // ROIs' bounding ranges places the step's bins, in (roi, ph, pw) order, one per lane, each with the four pixels it is valid for;
 // the walk is then two readlanes, two loads and the compare-adds per bin.  Bit-exact: each (pixel, channel) sum is formed by one
 // lane, in the reference's order, in a register, from exactly the entries the reference's window test admits.
-// The four waves of a workgroup are the (up to) four 256-channel slices of ONE block: their bookkeeping is identical, so they
-// share it -- in a round of four 64-ROI steps wave w does step w's scan and places its bins, leaves (bin, valid) per lane in
-// LDS, and after a barrier every wave walks the four steps' bins for its own channels.  (A step with more than 64 * RPB_PASSES
-// bins -- many tiny ROIs on one block -- is flagged and redone in full by each wave: correct, just not shared.)
-constexpr int RPB_PASSES = 2;
+// The NW waves of a workgroup are channel slices of ONE block: their bookkeeping is identical, so they share it -- in a round
+// of NW 64-ROI steps wave w does step w's scan and places its bins into the round's list in LDS (bin << 4 | valid pixels, in
+// (roi, ph, pw) order), and every wave then walks the list for its own channels as ONE stream: the load pipeline is filled and
+// drained once per round, not once per 64 bins.  (A round with more than RPB_CAP bins -- many tiny ROIs on one block -- is
+// redone step by step by each wave: correct, just not shared.)
+constexpr int RPB_CAP = 512;        // bins of a round that go through LDS (more: every wave redoes the round's steps itself)
 // CPL channels per lane (4: 16-byte loads, 256-channel slices; 2: 8-byte loads, 128-channel slices), NW waves = slices per workgroup
 template <int D, int CPL, int NW>
 __global__ void __launch_bounds__(64 * NW) roi_pool_bwd_block(const float* __restrict__ top_diff, const int* __restrict__ argmax,
                                                           const float* __restrict__ rois, int B, int H, int W, int C, int R,
                                                           int PH, int PW, float scale, int nwork, float* __restrict__ bottom_diff) {
   constexpr int SLC = 64 * CPL;                               // channels of a slice
-  __shared__ int sBins[2][NW][RPB_PASSES][2][64];             // [round parity][step][pass][bin | valid][lane]
-  __shared__ int sTotal[2][NW];                                // bins of the step, or -1: redo it in full
+  __shared__ int sList[2][RPB_CAP];                           // [round parity][bin of the round]: bin << 4 | valid pixels
+  __shared__ int sTotal[2][NW];                               // bins of each step of the round                                // bins of the step, or -1: redo it in full
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -428,86 +429,92 @@ __global__ void __launch_bounds__(64 * NW) roi_pool_bwd_block(const float* __res
     const bool c1ok = pw >= (int)((e_cols >> 16) & 255u) && pw < (int)(e_cols >> 24);
     validv = (r0ok && c0ok ? 1 : 0) | (r0ok && c1ok ? 2 : 0) | (r1ok && c0ok ? 4 : 0) | (r1ok && c1ok ? 8 : 0);
   };
-  // the walk over m <= 64 placed bins: groups of D bins, the next group's loads in flight while one is added (unconditional
-  // loads -- a slot past the end re-reads element 0 with no pixel valid -- so that the waits are counted, not drained).  D = 2
-  // measured best (4: +3 %, 8: +10 %): the walk is bound by instruction issue, not by loads in flight, and a deeper group
-  // means more padding slots
-  auto walk = [&](const int binv, const int validv, const int m) {
-    ivec amA[D], amB[D]; fvec gA[D], gB[D];
-    auto issue = [&](int e, ivec (&a_)[D], fvec (&g_)[D]) {
+  // the pooled vector of one bin against the block's pixels: compare-into-EXEC, add under it, EXEC back to all lanes (every lane
+  // of the wave is live here) -- two vector instructions per (pixel, component) instead of three; pixels the reference's window
+  // test excludes for this bin (v) are skipped by uniform branches
+  auto add_bin = [&](const ivec& a_, const fvec& g_, const int v) {
+    int ax[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) ax[i] = a_[i] - c - i;      // = pixel * C where it is this lane's channel
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (!((v >> p) & 1)) continue;
+      const int wq = pix0 + (p & 1) * C + (p >> 1) * W * C;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+        asm volatile("v_cmpx_eq_i32_e32 vcc, %2, %1\n\tv_add_f32_e32 %0, %0, %3\n\ts_mov_b64 exec, -1"
+                     : "+v"(acc[p][i]) : "v"(ax[i]), "s"(wq), "v"(g_[i]) : "vcc");
+    }
+  };
+  // the walk over a round's T bins (LDS list): groups of D, the next group's loads in flight while one is added; the loads are
+  // unconditional -- a slot past the end re-reads element 0 with no pixel valid -- so that the waits are counted, not drained
+  // (D = 2, 4, 8 measured 628 / 643 / 652 us at the contract shape: loads in flight are not what bounds the walk)
+  auto walk_list = [&](const int* __restrict__ list, const int T) {
+    ivec amA[D], amB[D]; fvec gA[D], gB[D]; int vA[D], vB[D];
+    auto issue = [&](int e, ivec (&a_)[D], fvec (&g_)[D], int (&v_)[D]) {
+      int pk[D];
+#pragma unroll
+      for (int q = 0; q < D; ++q) pk[q] = list[min(e + q, RPB_CAP - 1)];
 #pragma unroll
       for (int q = 0; q < D; ++q) {
-        const int bin = __builtin_amdgcn_readlane(binv, min(e + q, 63));
-        const size_t o = e + q < m ? (size_t)bin * C : (size_t)0;
+        const int pq = e + q < T ? __builtin_amdgcn_readfirstlane(pk[q]) : 0;
+        v_[q] = pq & 15;
+        const size_t o = (size_t)(pq >> 4) * C;
         a_[q] = *reinterpret_cast<const ivec*>(am_lane + o); g_[q] = *reinterpret_cast<const fvec*>(g_lane + o);
       }
     };
-    auto consume = [&](int e, const ivec (&a_)[D], const fvec (&g_)[D]) {
+    issue(0, amA, gA, vA);
+    for (int e = 0; e < T; e += 2 * D) {
+      issue(e + D, amB, gB, vB);
 #pragma unroll
-      for (int q = 0; q < D; ++q) {
-        const int v = e + q < m ? __builtin_amdgcn_readlane(validv, min(e + q, 63)) : 0;
-        int ax[CPL];
+      for (int q = 0; q < D; ++q) add_bin(amA[q], gA[q], vA[q]);
+      issue(e + 2 * D, amA, gA, vA);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) ax[i] = a_[q][i] - c - i;     // = pixel * C where it is this lane's channel
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          // (uniform: the pixel's offset)  compare-into-EXEC, add under it, EXEC back to all lanes (every lane of the wave is
-          // live here): two vector instructions per (pixel, component) instead of three; pixels the reference's window test
-          // excludes for this bin are skipped
-          if (!((v >> p) & 1)) continue;                      // (uniform)
-          const int wq = pix0 + (p & 1) * C + (p >> 1) * W * C;
-#pragma unroll
-          for (int i = 0; i < CPL; ++i)
-            asm volatile("v_cmpx_eq_i32_e32 vcc, %2, %1\n\tv_add_f32_e32 %0, %0, %3\n\ts_mov_b64 exec, -1"
-                         : "+v"(acc[p][i]) : "v"(ax[i]), "s"(wq), "v"(g_[q][i]) : "vcc");
-        }
-      }
-    };
-    issue(0, amA, gA);
-    for (int e = 0; e < m; e += 2 * D) {
-      issue(e + D, amB, gB);
-      consume(e, amA, gA);
-      issue(e + 2 * D, amA, gA);
-      consume(e + D, amB, gB);
+      for (int q = 0; q < D; ++q) add_bin(amB[q], gB[q], vB[q]);
+    }
+  };
+  // ... and over m <= 64 bins placed in this wave's registers (the unshared path)
+  auto walk_regs = [&](const int binv, const int validv, const int m) {
+    for (int e = 0; e < m; ++e) {
+      const size_t o = (size_t)__builtin_amdgcn_readlane(binv, e) * C;
+      const ivec a_ = *reinterpret_cast<const ivec*>(am_lane + o);
+      const fvec g_ = *reinterpret_cast<const fvec*>(g_lane + o);
+      add_bin(a_, g_, __builtin_amdgcn_readlane(validv, e));
     }
   };
 
   int par = 0;
   for (int rr = 0; rr < R; rr += 64 * NW, par ^= 1) {
-    // this wave's step of the round: scan, place, publish
-    {
-      const int r0 = rr + 64 * wv;
-      int tot = 0;
-      if (r0 < R) {
-        scan(r0);
-        tot = total;
-        if (tot > 64 * RPB_PASSES) tot = -1;
-        else
-          for (int ps = 0; ps * 64 < tot; ++ps) {
-            int binv, validv;
-            place(r0, ps * 64, binv, validv);
-            sBins[par][wv][ps][0][lane] = binv; sBins[par][wv][ps][1][lane] = validv;
-          }
+    // this wave's step of the round: scan; its bins' place in the round's list is known when every wave has scanned
+    const int r0 = rr + 64 * wv;
+    total = 0;
+    if (r0 < R) scan(r0);
+    if (lane == 0) sTotal[par][wv] = total;
+    __syncthreads();
+    int off = 0, T = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) { const int tw = sTotal[par][w2]; off += w2 < wv ? tw : 0; T += tw; }
+    const bool shared = T <= RPB_CAP && ((long long)R * PH * PW < (1ll << 27));
+    if (shared)
+      for (int base = 0; base < total; base += 64) {
+        int binv, validv;
+        place(r0, base, binv, validv);
+        if (base + lane < total) sList[par][off + base + lane] = (binv << 4) | validv;
       }
-      if (lane == 0) sTotal[par][wv] = tot;
-    }
-    __syncthreads();       // (one barrier per round: a slot of this parity is rewritten two rounds on, behind the next barrier)
-    if (!live) continue;
-    for (int w2 = 0; w2 < NW; ++w2) {
-      const int tot = sTotal[par][w2];
-      if (tot == 0) continue;
-      if (tot > 0) {
-        for (int ps = 0; ps * 64 < tot; ++ps) walk(sBins[par][w2][ps][0][lane], sBins[par][w2][ps][1][lane], min(64, tot - ps * 64));
-      } else {             // too many bins for the shared slots: the whole step here
-        const int r0 = rr + 64 * w2;
-        scan(r0);
+    __syncthreads();       // (a list of this parity is rewritten two rounds on, behind the next round's barriers)
+    if (!live || T == 0) continue;
+    if (shared) walk_list(sList[par], T);
+    else
+      for (int w2 = 0; w2 < NW; ++w2) {            // too many bins for the list: every step in full, here
+        const int q0 = rr + 64 * w2;
+        if (q0 >= R) break;
+        scan(q0);
         for (int base = 0; base < total; base += 64) {
           int binv, validv;
-          place(r0, base, binv, validv);
-          walk(binv, validv, min(64, total - base));
+          place(q0, base, binv, validv);
+          walk_regs(binv, validv, min(64, total - base));
         }
       }
-    }
   }
   if (!live) return;
   auto put = [&](float* dst, const float (&a_)[CPL]) {
