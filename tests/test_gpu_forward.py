@@ -94,3 +94,50 @@ def test_argmax_edges_recorded_for_backward(n, c, b, seed):
     for blk in range(1, b + 1):
         H = winner_records_exact(net, blk)
         assert rel_err(H, ref["pre"]["sel"][blk - 1]) < TOL
+
+
+def _efw_begin(gw, tiles, waves):
+    """Python restatement of common.hpp's efw_begin (edge_fwd_w's tile ranges, sized by dispatch layer)."""
+    rb = lambda g, n, p: (g * n) // p
+    if waves % 96 != 0 or tiles < 6 * waves:
+        return rb(gw, tiles, waves)
+    if gw >= waves:
+        return tiles
+    wpx = waves // 8
+    tw = wpx // 3
+    x, jx = divmod(gw, wpx)
+    k, j = divmod(jx, tw)
+    cut = (0, 405, 745, 1000)
+    x0 = rb(x, tiles, 8)
+    tx = rb(x + 1, tiles, 8) - x0
+    b0, b1 = x0 + tx * cut[k] // 1000, x0 + tx * cut[k + 1] // 1000
+    return b0 + rb(j, b1 - b0, tw)
+
+
+@pytest.mark.parametrize("images", [1, 8])
+def test_segment_record_flags_follow_the_edge_kernel_ranges(images):
+    """A detection whose edges are split between two waves' tile ranges of edge_fwd_w (or that has none) must have its
+    segment-max records start from zero (flag 1), every other one is written by a plain store (flag 0): the flags
+    (edge_geometry, through efw_owner) and the ranges the kernel walks (efw_begin) have to describe the same partition --
+    at 8 images the layered one, at 1 image the equal one.  Checked against a restatement of the ranges in Python."""
+    from gossipnet_amd.network import DeviceBatch
+    net, _ = make_pair(80, 2)
+    dev = torch.device("cuda", 0)
+    b = DeviceBatch([make_image(2000, 80, seed=i, preset="dense") for i in range(images)], dev)
+    net.run(b, training=False)
+    torch.cuda.synchronize()
+    E, N = int(net.num_edges), int(net.num_dets)
+    tiles = (E + 31) // 32
+    waves = max(1, min(3 * 256, (tiles + 3) // 4)) * 4
+    begins = np.array([_efw_begin(g, tiles, waves) for g in range(waves + 1)], dtype=np.int64)
+    assert begins[0] == 0 and begins[-1] == tiles and np.all(np.diff(begins) >= 0)
+    assert (tiles >= 6 * waves) == (images == 8), "the batch takes the layered ranges, a single image the equal ones"
+    rp = net.row_ptr.cpu().numpy().astype(np.int64)
+    owner = lambda t: np.searchsorted(begins, t, side="right") - 1           # the wave whose range holds tile t
+    eb, ee = rp[:-1], rp[1:]
+    want = (ee == eb) | (owner(eb >> 5) != owner(np.maximum(ee - 1, 0) >> 5))
+    got = net._view(net._buf.scratch_i, N, torch.int32).cpu().numpy()
+    assert np.array_equal(got != 0, want)
+    if images == 8:      # the layers really differ in size
+        per = np.diff(begins)
+        assert per[:waves // 24].mean() > 1.15 * per[2 * waves // 24:3 * waves // 24].mean()
