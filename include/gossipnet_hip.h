@@ -274,8 +274,9 @@ int roi_pool_bwd_f32(const float* top_diff, const int32_t* argmax, const float* 
                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h,
                      int32_t pooled_w, float spatial_scale, float* bottom_diff, gnet_stream_t stream);
 /* roi_pool_bwd_f32 sums in the CPU kernel's order (ROI index, then bin): bit-exact and reproducible.  The _atomic
- * variant scatters every pooled element's gradient to its arg-max with a float atomic: less traffic, summation
- * order not fixed, and NOT the reference's result where its in-ROI / feasible-bin tests (roi_pooling_op.cc:405-431)
+ * variant scatters every pooled element's gradient to its arg-max with a float atomic: less traffic (but, since round 3,
+ * 3-4x SLOWER than the ordered kernel at the contract shape: 2.3 ms against 0.62 ms), summation order not fixed, and NOT
+ * the reference's result where its in-ROI / feasible-bin tests (roi_pooling_op.cc:405-431)
  * drop an element (arg-max pixel one past the rounded ROI end). */
 int roi_pool_bwd_atomic_f32(const float* top_diff, const int32_t* argmax, const float* bottom_rois,
                             int32_t B, int32_t H, int32_t W, int32_t C, int32_t R, int32_t pooled_h,
