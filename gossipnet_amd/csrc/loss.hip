@@ -112,12 +112,15 @@ __global__ void __launch_bounds__(256) match_rank(const float* __restrict__ scor
   const int cmax = det_off[image_of(det_off, n_img, b1) + 1];
   const int img = image_of(det_off, n_img, dd);
   const int lo = det_off[img], hi = det_off[img + 1];
-  const float s = score[dd];
+  // (a NaN score -- a diverged run -- ranks as -inf: `>` and `==` are false for it, the ranks would collide and leave
+  //  entries of `order` unwritten, i.e. stale indices of an earlier batch for match_greedy to follow out of bounds)
+  float s = score[dd];
+  s = s == s ? s : -INFINITY;
   int rank = 0;
   for (int c0 = cmin; c0 < cmax; c0 += 1024) {
     __syncthreads();
     const int tn = min(1024, cmax - c0);
-    for (int i = threadIdx.x; i < tn; i += 256) ss[i] = score[c0 + i];
+    for (int i = threadIdx.x; i < tn; i += 256) { const float v = score[c0 + i]; ss[i] = v == v ? v : -INFINITY; }
     __syncthreads();
     const int jlo = max(lo, c0), jhi = min(hi, c0 + tn);
     for (int j = jlo + q; j < jhi; j += RANK_LANES) {

@@ -206,3 +206,41 @@ def test_checkpoint_round_trip_tf_bundle(tmp_path):
     train_step(net2, opt2, batch, 1e-3)
     torch.cuda.synchronize()
     assert torch.equal(net2.params, net.params)
+
+
+@pytest.mark.gpu
+def test_a_diverged_run_yields_nan_not_a_memory_fault():
+    """A diverging optimisation (SGD on the summed loss did it in a soak run) overflows the activations: the logits become
+    inf / NaN.  The score ranking of the matching then compared NaNs (`>` and `==` false), left entries of the score order
+    unwritten, and match_greedy followed stale indices of an earlier, larger batch out of bounds: a GPU memory fault instead of
+    a NaN loss.  Non-finite parameters must give non-finite numbers and leave the device usable."""
+    from gossipnet_amd.network import DeviceBatch
+    net, _ = make_pair(80, 4)
+    dev = torch.device("cuda", 0)
+    big = DeviceBatch([make_image(n, 80, seed=s) for n, s in ((1163, 1), (1965, 2), (2123, 3), (439, 4))], dev)
+    small = DeviceBatch([make_image(n, 80, seed=s) for n, s in ((300, 5), (1291, 6), (55, 7))], dev)
+    net.run(big); torch.cuda.synchronize()                       # a larger batch first: its index arrays are what goes stale
+    good = net.params.clone()
+    net.run(small); torch.cuda.synchronize()
+    ref_loss, ref_grads = net.loss.clone(), net.grads.clone()
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    for scale in (1e4, 1e8, 1e16, 1e30, float("nan")):
+        net.params.copy_(good * scale)
+        if scale == 1e8:                                         # a mixed state: some tensors huge, some NaN, some sane
+            m = torch.rand(good.numel(), generator=gen).to(dev)
+            net.params.copy_(torch.where(m < 0.3, good * 1e20, torch.where(m < 0.4, torch.full_like(good, float("nan")), good)))
+        net.run(small); torch.cuda.synchronize()
+        assert net.det_gt_matching.min().item() >= -1 and net.det_gt_matching.max().item() < 400
+        net.run(small, training=False); torch.cuda.synchronize()
+    # the standalone op with NaN / inf scores: every detection still gets a label in {0, 1} and a weight
+    from gossipnet_amd.matching_module import detection_matching
+    iou = torch.rand(500, 40, generator=gen).to(dev)
+    score = torch.randn(500, generator=gen).to(dev)
+    score[::3] = float("nan"); score[1::7] = float("inf"); score[2::11] = -float("inf")
+    labels, weights, assign = detection_matching(iou, score, torch.zeros(40, dtype=torch.bool, device=dev))
+    torch.cuda.synchronize()
+    assert set(np.unique(labels.cpu().numpy()).tolist()) <= {0.0, 1.0} and int(assign.max().item()) < 40
+    # and the device still computes: the same step as before, bit for bit
+    net.params.copy_(good)
+    net.run(small); torch.cuda.synchronize()
+    assert torch.equal(net.loss, ref_loss) and torch.equal(net.grads, ref_grads)
