@@ -30,7 +30,7 @@ struct RoiBox { int start_w, start_h, end_w, end_h, batch; float bin_h, bin_w; }
 // roi_pooling_op.cc:143-156: round() = half away from zero, evaluated on the float product
 __device__ __forceinline__ RoiBox roi_decode(const float* __restrict__ roi, float scale, int PH, int PW) {
   RoiBox b;
-  b.batch = (int)roi[0];
+  b.batch = roi[0] == roi[0] ? (int)roi[0] : -1;        // (a NaN index: no image, like any index outside the batch)
   // (roundf on the float product: the product is exactly representable as a double and half-away-from-zero rounding to
   // an integer is the same function in either precision, so this IS round((double)x) -- at a fraction of the instructions)
   b.start_w = (int)roundf(roi[1] * scale);
@@ -45,7 +45,7 @@ __device__ __forceinline__ RoiBox roi_decode(const float* __restrict__ roi, floa
 }
 
 template <bool VEC4>
-__global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ data, int H, int W, int C,
+__global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ data, int B, int H, int W, int C,
                                                     const float* __restrict__ rois, long long nbins, int PH, int PW,
                                                     float scale, float* __restrict__ top, int* __restrict__ argmax) {
   const int lane = threadIdx.x & 63;
@@ -58,9 +58,12 @@ __global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ da
   int hend = (int)ceilf((ph + 1) * b.bin_h), wend = (int)ceilf((pw + 1) * b.bin_w);
   hstart = min(max(hstart + b.start_h, 0), H); hend = min(max(hend + b.start_h, 0), H);
   wstart = min(max(wstart + b.start_w, 0), W); wend = min(max(wend + b.start_w, 0), W);
-  const bool is_empty = (hend <= hstart) || (wend <= wstart);
+  // (a ROI whose image index is not one of the batch's -- undefined behaviour in the reference, which reads that address --
+  //  pools nothing: zeros and arg-max -1)
+  const bool no_image = b.batch < 0 || b.batch >= B;
+  const bool is_empty = (hend <= hstart) || (wend <= wstart) || no_image;
   const float init = is_empty ? 0.f : -3.402823466e+38f;
-  const float* bottom = data + (size_t)b.batch * C * H * W;
+  const float* bottom = data + (size_t)(no_image ? 0 : b.batch) * C * H * W;
   float* tp = top + (size_t)bin * C; int* ap = argmax + (size_t)bin * C;
   if (VEC4) {
     // 1024 channels per pass = four 16-byte groups per lane, all four requested per pixel before the compares (the op
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ da
 //   * the channel dimension is dealt to the XCDs (workgroups go round-robin to the 8 XCDs, blockIdx % 8): the feature map of
 //     an image (9.8 MB) does not fit an XCD's 4 MB L2, a 256-channel slice (2.4 MB) does; XCDs 2 s and 2 s + 1 take slice s.
 // Pixels of a bin are visited in the reference's order (h, then w; strict >: the first maximum wins): top / argmax bit-exact.
-__global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict__ data, int H, int W,
+__global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict__ data, int B, int H, int W,
                                                          const float* __restrict__ rois, int nrows, int PH, int PW,
                                                          float scale, float* __restrict__ top, int* __restrict__ argmax) {
   constexpr int C = 1024;
@@ -137,10 +140,12 @@ __global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict
   const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
   int hstart = (int)floorf(ph * b.bin_h), hend = (int)ceilf((ph + 1) * b.bin_h);
   hstart = min(max(hstart + b.start_h, 0), H); hend = min(max(hend + b.start_h, 0), H);
+  const bool no_image = b.batch < 0 || b.batch >= B;     // (undefined in the reference; here such a ROI pools nothing)
+  if (no_image) hend = hstart;
   // (uniform image base + a lane-constant byte offset: the loads take the scalar-base form, no per-lane address arithmetic;
   //  the arg-max candidates are the UNIFORM pixel offsets -- a select with a scalar operand -- and the lane's channel offset is
   //  added once per bin)
-  const float* img = data + (size_t)b.batch * C * H * W + 256 * slice;
+  const float* img = data + (size_t)(no_image ? 0 : b.batch) * C * H * W + 256 * slice;
   const unsigned lane_b = 16u * lane;
   const int cbase = 256 * slice + 4 * lane;
   size_t out = ((size_t)row * PW) * C + cbase;
@@ -534,9 +539,10 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_atomic(const float* __restri
                                                            long long image_elems, int B, float* __restrict__ bottom_diff) {
   for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < total; b += (long long)gridDim.x * 256) {
     const int idx = argmax[b];
-    if (idx < 0) continue;
+    if (idx < 0 || idx >= image_elems) continue;            // (-1 = an empty bin; an index past the image: not ours to write)
     const long long r = b / per_roi;
-    const int bi = (int)rois[r * 5];
+    const float bf = rois[r * 5];
+    const int bi = bf == bf ? (int)bf : -1;
     if (bi < 0 || bi >= B) continue;
     atomic_add_f32(bottom_diff + (size_t)bi * image_elems + idx, top_diff[b]);
   }
@@ -556,12 +562,12 @@ extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, 
   const unsigned grid = (unsigned)((nbins + 3) / 4);
   if (C == 1024 && (long long)R * pooled_h <= 0x0fffffffLL) {
     const int nrows = R * pooled_h;
-    roi_pool_fwd_rows<<<(unsigned)(8 * ((nrows + 7) / 8)), 256, 0, (hipStream_t)stream>>>(bottom_data, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax);
+    roi_pool_fwd_rows<<<(unsigned)(8 * ((nrows + 7) / 8)), 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax);
   }
   else if ((C & 3) == 0)
-    roi_pool_fwd<true><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);
+    roi_pool_fwd<true><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);
   else
-    roi_pool_fwd<false><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);
+    roi_pool_fwd<false><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);
   return launch_status();
 }
 

@@ -360,3 +360,38 @@ def test_roi_pool_contract_shape():
     assert np.array_equal(got[..., :cs], ref)
     exact = _scatter_by_argmax(ram[..., :cs] if False else am_s, np.ascontiguousarray(g[..., :cs]), rb, (1, 38, 63, cs))
     assert np.abs(got_a[..., :cs] - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [64, 1024])
+def test_roi_pool_hostile_rois_do_not_fault(C):
+    """ROIs the reference leaves undefined -- an image index outside the batch (roi_pooling_op.cc:144,174 reads that address),
+    NaN / infinite / huge / negative coordinates -- must not take the device down: a ROI of no image pools nothing (zeros,
+    arg-max -1), the others clamp to the map like any ROI; the ordered backward ignores what the forward did not produce, the
+    atomic one ignores arg-max indices outside the image.  Well-formed ROIs in the same call are unaffected."""
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool_raw, roi_pool_grad
+    rng = np.random.default_rng(C)
+    B, H, W, P = 2, 12, 9, 7
+    d = "cuda:0"
+    data = rng.normal(size=(B, H, W, C)).astype(np.float32)
+    good = np.array([[0, 1, 1, 7, 9], [1, 0, 2, 5, 11], [1, 3, 3, 4, 4]], np.float32)
+    bad = np.array([[2, 1, 1, 5, 5], [-1, 1, 1, 5, 5], [7.5e9, 0, 0, 3, 3], [0, np.nan, 1, 5, 5], [1, -np.inf, -np.inf, np.inf, np.inf],
+                    [0, 1e30, 1e30, 2e30, 2e30], [1, -1e9, -1e9, -5e8, -5e8], [0, 5, 5, 1, 1], [np.nan, 1, 1, 3, 3]], np.float32)
+    rois = np.concatenate([good[:1], bad, good[1:]], 0)
+    top, am = roi_pool_raw(torch.tensor(data, device=d), torch.tensor(rois, device=d), P, P, 1.0)
+    torch.cuda.synchronize()
+    rtop, ram = native.roi_pool(data, good, P, P, 1.0)
+    keep = [0, len(rois) - 2, len(rois) - 1]
+    assert np.array_equal(top.cpu().numpy()[keep], rtop) and np.array_equal(am.cpu().numpy()[keep], ram)
+    no_image = [1, 2, 3, 9]                                        # image index 2, -1, 7.5e9 (not an int32), NaN
+    assert bool((top[no_image] == 0).all()) and bool((am[no_image] == -1).all())
+    assert int(am.max().item()) < H * W * C and int(am.min().item()) >= -1
+    g = torch.tensor(rng.normal(size=top.shape).astype(np.float32), device=d)
+    for det in (True, False):
+        bd = roi_pool_grad(torch.tensor(data, device=d), torch.tensor(rois, device=d), am, g, P, P, 1.0, det)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(bd).all().item())
+    wild = torch.tensor(rng.integers(-5, 2 ** 31 - 1, size=tuple(am.shape)).astype(np.int32), device=d)   # arg-max not from any forward
+    for det in (True, False):
+        roi_pool_grad(torch.tensor(data, device=d), torch.tensor(rois, device=d), wild, g, P, P, 1.0, det)
+        torch.cuda.synchronize()
