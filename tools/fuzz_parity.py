@@ -1,0 +1,71 @@
+"""Differential fuzz: the nasty-but-legal batches of tools/fuzz.py (sizes at the tile edges, duplicates, no / all-crowd / many
+ground-truth boxes, tied scores, everything-overlaps, no edges) at sizes the CPU oracle handles, compared with
+it the way tests/test_gpu_backward.py does -- neighbour indices / matching bit-exact, activations and loss <= 1e-5, masks
+within 2e-6 of a kink, gradients on the common piece <= 1e-5.   python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tests.util import make_pair
+from tests.test_gpu_backward import check_outputs, pinned_errors, kink_report, KINK, PINNED
+from gossipnet_amd.synthetic import make_image
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+NC, NB = 80, 2
+net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32))
+net.keep_edge_activations = True
+SIZES = [1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257]
+
+
+def nasty_image():
+    n = int(rng.choice(SIZES)) if rng.uniform() < 0.6 else int(rng.integers(1, 300))
+    im = make_image(n, NC, seed=int(rng.integers(1 << 30)), preset=("dense", "coco_like")[int(rng.integers(2))])
+    mode = int(rng.integers(0, 8))
+    if mode == 0 and n > 1:
+        idx = rng.integers(0, max(n // 4, 1), n)
+        im["dets"], im["det_classes"] = im["dets"][idx].copy(), im["det_classes"][idx].copy()
+    elif mode == 2:
+        for k in ("gt_boxes", "gt_crowd", "gt_classes"):
+            im[k] = im[k][:0].copy()
+    elif mode == 3:
+        im["gt_crowd"] = np.ones_like(im["gt_crowd"])
+    elif mode == 4:
+        im["det_scores"] = rng.choice(np.array([0.0, 1.0, 0.5, 0.25], np.float32), n).astype(np.float32)
+    elif mode == 5:
+        im["det_classes"][:] = 1; im["gt_classes"][:] = 1
+        im["dets"] = (im["dets"][:1] + np.abs(rng.normal(0, 0.5, (n, 4)))).astype(np.float32)
+        im["dets"][:, 2:] += 8.0
+    elif mode == 6:
+        im["dets"] = (np.arange(n, dtype=np.float32)[:, None] * 50.0 + np.array([0, 0, 10, 10], np.float32)[None]).astype(np.float32)
+    elif mode == 7:
+        g = int(rng.integers(50, 400))
+        b = rng.uniform(0, 500, (g, 2)).astype(np.float32)
+        im["gt_boxes"] = np.concatenate([b, b + rng.uniform(5, 120, (g, 2)).astype(np.float32)], 1)
+        im["gt_crowd"] = rng.uniform(size=g) < 0.1
+        im["gt_classes"] = rng.integers(1, NC + 1, g).astype(np.int32)
+    return im, mode
+
+
+t0 = time.time()
+worst_pin, worst_kink = 0.0, 0.0
+for case in range(cases):
+    pairs = [nasty_image()]
+    imgs = pairs[0][0]                       # (one image per case: the oracle works per image)
+    desc = [(int(im["dets"].shape[0]), int(im["gt_boxes"].shape[0]), m) for im, m in pairs]
+    try:
+        ref, gref = orc.forward_backward(imgs, keep=True)
+        net.run(imgs)
+        torch.cuda.synchronize()
+        check_outputs(net, ref)
+        n_diff, worst, where = kink_report(net, ref)
+        assert worst <= KINK, ("mask entry differs away from a kink", n_diff, worst, where)
+        pinned = pinned_errors(net, orc, imgs, NC, NB)
+        assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
+        worst_pin, worst_kink = max(worst_pin, max(pinned.values())), max(worst_kink, worst)
+    except Exception as e:
+        print("case %d (dets, gts, mode) %s: %s: %s" % (case, desc, type(e).__name__, e), flush=True)
+        raise
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case", case, desc, "E", int(net.num_edges), "pinned %.2e" % max(pinned.values()), flush=True)
+print("parity fuzz: %d cases in %.1f s; worst gradient error on the common piece %.2e, worst kink distance %.2e" % (cases, time.time() - t0, worst_pin, worst_kink))
