@@ -1,12 +1,13 @@
 """Differential fuzz: the nasty-but-legal batches of tools/fuzz.py (sizes at the tile edges, duplicates, no / all-crowd / many
 ground-truth boxes, tied scores, everything-overlaps, no edges) at sizes the CPU oracle handles, compared with
 it the way tests/test_gpu_backward.py does -- neighbour indices / matching bit-exact, activations and loss <= 1e-5, masks
-within 2e-6 of a kink, gradients on the common piece <= 1e-5.   python tools/fuzz_parity.py [cases] [seed]"""
+within 2e-6 of a kink, gradients on the common piece <= 1e-5 (of the tensor's largest element + 0.01).   python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from tests.util import make_pair
+from tests.util import make_pair, gpu_pins
+from oracle import gnet_oracle as go
 from tests.test_gpu_backward import check_outputs, pinned_errors, kink_report, KINK, PINNED
 from gossipnet_amd.synthetic import make_image
 
@@ -60,7 +61,15 @@ for case in range(cases):
         check_outputs(net, ref)
         n_diff, worst, where = kink_report(net, ref)
         assert worst <= KINK, ("mask entry differs away from a kink", n_diff, worst, where)
-        pinned = pinned_errors(net, orc, imgs, NC, NB)
+        # per tensor: |g_hip - g_ref| <= 1e-5 max |g_ref| + 1e-7.  (The tests' purely relative bar needs a tensor whose largest
+        # element is not itself a cancelled sum: with two or three detections a head bias gradient is +0.2542 - 0.2516, and one
+        # ulp of a summand is 1e-5 of the result.)
+        _, gpin = orc.forward_backward(imgs, pins=gpu_pins(net, None))
+        pinned = {}
+        for name, _shape in go.param_spec(NC, NB):
+            g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
+            gr = np.asarray(gpin[name], np.float64).reshape(-1)
+            pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 1e-2)) if gr.size else 0.0
         assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
         worst_pin, worst_kink = max(worst_pin, max(pinned.values())), max(worst_kink, worst)
     except Exception as e:
