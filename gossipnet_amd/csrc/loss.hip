@@ -380,8 +380,12 @@ extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const 
                          gnet_stream_t stream) {
   clear_hip_error();
   int st = check_loss_args(cfg, shape, in, buf);
-  if (st != GNET_OK || shape->n_det == 0) return st;
+  if (st != GNET_OK) return st;
   hipStream_t s = (hipStream_t)stream;
+  if (shape->n_det == 0) {                 // no detection: the per-image losses are zero (not what an earlier step left there)
+    if (buf->loss && shape->n_img > 0) HIP_CHECK_RET(hipMemsetAsync(buf->loss, 0, (size_t)2 * shape->n_img * sizeof(float), s));
+    return GNET_OK;
+  }
   const int N = shape->n_det;
   if (!prepared) {
     st = gnet_match_prepare(cfg, shape, in, buf, stream);

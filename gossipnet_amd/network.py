@@ -76,6 +76,11 @@ class DeviceBatch(object):
     def __init__(self, images, device):
         if isinstance(images, dict):
             images = [images]
+        if len(images) == 0:
+            # a data-parallel rank without an image in this step (fewer images than ranks): one image without detections --
+            # zero gradients into the all-reduce, no loss terms
+            images = [{"dets": np.zeros((0, 4), np.float32), "det_scores": np.zeros(0, np.float32), "det_classes": np.zeros(0, np.int32),
+                       "gt_boxes": np.zeros((0, 4), np.float32), "gt_crowd": np.zeros(0, np.uint8), "gt_classes": np.zeros(0, np.int32)}]
         self.n_img = len(images)
         f32, i32 = np.float32, np.int32
 

@@ -244,3 +244,32 @@ def test_a_diverged_run_yields_nan_not_a_memory_fault():
     net.params.copy_(good)
     net.run(small); torch.cuda.synchronize()
     assert torch.equal(net.loss, ref_loss) and torch.equal(net.grads, ref_grads)
+
+
+@pytest.mark.gpu
+def test_a_rank_without_images_contributes_zero():
+    """Fewer images than ranks in a data-parallel step: shard_images hands some rank an empty list.  Such a step must run --
+    loss 0, gradient exactly 0 (also right after a step that left non-zero losses and gradients in the buffers) -- and so must
+    an image without detections; the sum of the shards' gradients equals the gradient of the whole step."""
+    from gossipnet_amd.network import DeviceBatch
+    from gossipnet_amd.data_parallel import shard_images
+    net, _ = make_pair(80, 2)
+    dev = torch.device("cuda", 0)
+    imgs = [make_image(120, 80, seed=1), make_image(75, 80, seed=2), make_image(33, 80, seed=3)]
+    net.grad_scale = 1.0 / len(imgs)
+    net.run(DeviceBatch(imgs, dev)); torch.cuda.synchronize()
+    whole, whole_loss = net.grads.clone(), float(net.loss)
+    assert whole.abs().max().item() > 0
+    shards = [shard_images(imgs, r, 5, costs=[3.0, 2.0, 1.0]) for r in range(5)]
+    assert sorted(len(s) for s in shards) == [0, 0, 1, 1, 1]
+    total, total_loss = torch.zeros_like(whole), 0.0
+    for s in shards:
+        net.run(DeviceBatch(s, dev)); torch.cuda.synchronize()
+        if not s:
+            assert float(net.loss) == 0.0 and float(net.loss_normed) == 0.0 and net.grads.abs().max().item() == 0.0
+        total += net.grads; total_loss += float(net.loss)
+    assert abs(total_loss - whole_loss) <= 1e-5 * max(1.0, abs(whole_loss))
+    assert float((total - whole).abs().max() / whole.abs().max()) <= 1e-5
+    empty = {k: v[:0] for k, v in make_image(5, 80, seed=4).items()}
+    net.run(DeviceBatch([empty], dev)); torch.cuda.synchronize()
+    assert float(net.loss) == 0.0 and net.grads.abs().max().item() == 0.0
