@@ -362,6 +362,10 @@ class Gnet(object):
         torch.cuda.current_stream(self.device).wait_event(self._count_done)
         shape = _lib.gnet_shape(db.n_img, N, db.n_gt, E, db.n_anno)
         training = self._mode(training)
+        if training and E > (1 << 24) - 128:
+            # (before the workspace is sized for it: gnet_backward[_prepare] returns GNET_ERR_UNSUPPORTED -- the backward pass
+            #  addresses the [E, 64] fp32 arrays with 32-bit byte offsets)
+            raise _lib.GnetError("%d neighbour pairs in one step: a training step supports at most %d (split the batch)" % (E, (1 << 24) - 128))
         need = lib.gnet_workspace_bytes(C.byref(self._cfg), C.byref(shape), int(training))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
