@@ -288,8 +288,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    E = int(net.num_edges)
-    N_local = int(net.num_dets)
     # Per-kernel HIP events cost ~4% of the step when every launch is bracketed (~150 launches), so the timed
     # region brackets only the DOMINANT kernel class (picked from one fully instrumented, untimed step);
     # the complete per-class table is measured in a second, untimed pass after the timed region.
@@ -318,6 +316,8 @@ def main():
         step()
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0               # this rank's own K steps (before waiting for the others)
+    E = int(net.num_edges)                               # (read here: with --warmup 0 and no kernel timing no step ran before)
+    N_local = int(net.num_dets)
     per_rank = None
     if dist is not None:
         dist.barrier()
