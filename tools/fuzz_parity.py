@@ -1,7 +1,7 @@
-"""Differential fuzz: the nasty-but-legal batches of tools/fuzz.py (sizes at the tile edges, duplicates, no / all-crowd / many
+"""Differential fuzz: the nasty-but-legal images of tools/fuzz.py, alone or two to four in a step, (sizes at the tile edges, duplicates, no / all-crowd / many
 ground-truth boxes, tied scores, everything-overlaps, no edges) at sizes the CPU oracle handles, compared with
 it the way tests/test_gpu_backward.py does -- neighbour indices / matching bit-exact, activations and loss <= 1e-5, masks
-within 2e-6 of a kink, gradients on the common piece <= 1e-5 (of the tensor's largest element + 0.01).   python tools/fuzz_parity.py [cases] [seed]"""
+within 2e-6 of a kink, gradients on the common piece <= 1e-5 (of the tensor's largest element + 0.05).   python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -51,25 +51,41 @@ def nasty_image():
 t0 = time.time()
 worst_pin, worst_kink = 0.0, 0.0
 for case in range(cases):
-    pairs = [nasty_image()]
-    imgs = pairs[0][0]                       # (one image per case: the oracle works per image)
+    pairs = [nasty_image() for _ in range(1 if rng.uniform() < 0.6 else int(rng.integers(2, 5)))]
+    imgs = [p[0] for p in pairs]
     desc = [(int(im["dets"].shape[0]), int(im["gt_boxes"].shape[0]), m) for im, m in pairs]
     try:
-        ref, gref = orc.forward_backward(imgs, keep=True)
-        net.run(imgs)
+        net.run(imgs if len(imgs) > 1 else imgs[0])
         torch.cuda.synchronize()
-        check_outputs(net, ref)
-        n_diff, worst, where = kink_report(net, ref)
-        assert worst <= KINK, ("mask entry differs away from a kink", n_diff, worst, where)
-        # per tensor: |g_hip - g_ref| <= 1e-5 max |g_ref| + 1e-7.  (The tests' purely relative bar needs a tensor whose largest
-        # element is not itself a cancelled sum: with two or three detections a head bias gradient is +0.2542 - 0.2516, and one
-        # ulp of a summand is 1e-5 of the result.)
-        _, gpin = orc.forward_backward(imgs, pins=gpu_pins(net, None))
+        # the oracle works per image: outputs and masks per image, the step's gradient = the sum over its images
+        d_off = net._dbatch.det_off_h
+        gsum, worst = None, 0.0
+        for i, im in enumerate(imgs):
+            image = i if len(imgs) > 1 else None
+            ref, _ = orc.forward_backward(im, keep=True)
+            sl = slice(int(d_off[i]), int(d_off[i + 1]))
+            if len(imgs) == 1:
+                check_outputs(net, ref)
+            else:
+                assert np.array_equal(net.labels.cpu().numpy()[sl], ref["labels"]), "labels of image %d" % i
+                assert np.array_equal(net.det_gt_matching.cpu().numpy()[sl], ref["det_gt_matching"]), "assignments of image %d" % i
+                pr = ref["prediction"].detach().numpy()
+                assert np.abs(net.prediction.cpu().numpy()[sl] - pr).max() <= 1e-5 * max(1.0, np.abs(pr).max() if pr.size else 1.0)
+                assert abs(float(net.image_losses[i, 0]) - float(ref["loss_unnormed"])) <= 1e-5 * max(1.0, abs(float(ref["loss_unnormed"])))
+            n_diff, w, where = kink_report(net, ref, image)
+            assert w <= KINK, ("mask entry differs away from a kink", i, n_diff, w, where)
+            worst = max(worst, w)
+            _, gpin = orc.forward_backward(im, pins=gpu_pins(net, image))
+            gsum = {k: np.asarray(v, np.float64) for k, v in gpin.items()} if gsum is None else {k: gsum[k] + np.asarray(gpin[k], np.float64) for k in gsum}
+        # per tensor: |g_hip - g_ref| <= 1e-5 (max |g_ref| + 0.05), i.e. an absolute floor of 5e-7.  (The tests' purely relative
+        # bar needs a tensor whose largest element is not itself a cancelled sum: with two or three detections a head bias
+        # gradient is +0.2542 - 0.2516 -- one ulp of a summand is 1e-5 of the result -- and the 128-term dot products behind
+        # predict/fc1's bias gradient, summed in another order, differ by a few 1e-7 whatever the size of their sum.)
         pinned = {}
         for name, _shape in go.param_spec(NC, NB):
             g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
-            gr = np.asarray(gpin[name], np.float64).reshape(-1)
-            pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 1e-2)) if gr.size else 0.0
+            gr = gsum[name].reshape(-1)
+            pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 5e-2)) if gr.size else 0.0
         assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
         worst_pin, worst_kink = max(worst_pin, max(pinned.values())), max(worst_kink, worst)
     except Exception as e:
