@@ -13,8 +13,33 @@ from gossipnet_amd.synthetic import make_image
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-NC, NB = 80, 2
-net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32))
+# configuration (argv[3]): 0 = 80 classes, 2 blocks, class weights; 1 = one class, 3 blocks, normalised loss; 2 = 80 classes, one
+# block, biases 0.5, pw_feat_multiplyer 0.7; 3 = neighbor_feats (a second reduce FC per block), 2 blocks
+CONF = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+NF = CONF == 3
+if CONF == 0:
+    NC, NB = 80, 2
+    net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32))
+elif CONF == 1:
+    NC, NB = 1, 3
+    net, orc = make_pair(NC, NB, normalize_loss=True)
+elif CONF == 2:
+    NC, NB = 80, 1
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet
+    reset_cfg(); cfg.gnet.num_blocks = NB; cfg.gnet.bias_const_init = 0.5; cfg.gnet.pw_feat_multiplyer = 0.7
+    params = go.init_params(NC, NB, bias_init=0.5)
+    net = Gnet(NC); net.load_params(params)
+    orc = go.GnetOracle(NC, NB, params=params, pw_feat_multiplyer=0.7) if "pw_feat_multiplyer" in go.GnetOracle.__init__.__code__.co_varnames else None
+else:
+    NC, NB = 80, 2
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet
+    reset_cfg(); cfg.gnet.num_blocks = NB; cfg.gnet.neighbor_feats = True
+    params = go.init_params(NC, NB, neighbor_feats=True)
+    net = Gnet(NC); net.load_params(params)
+    orc = go.GnetOracle(NC, NB, params=params, neighbor_feats=True)
+assert orc is not None, "this oracle has no pw_feat_multiplyer argument"
 net.keep_edge_activations = True
 SIZES = [1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257]
 
@@ -82,7 +107,7 @@ for case in range(cases):
         # gradient is +0.2542 - 0.2516 -- one ulp of a summand is 1e-5 of the result -- and the 128-term dot products behind
         # predict/fc1's bias gradient, summed in another order, differ by a few 1e-7 whatever the size of their sum.)
         pinned = {}
-        for name, _shape in go.param_spec(NC, NB):
+        for name, _shape in go.param_spec(NC, NB, None, NF):
             g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
             gr = gsum[name].reshape(-1)
             pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 5e-2)) if gr.size else 0.0
