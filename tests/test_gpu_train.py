@@ -103,12 +103,14 @@ if use_dist: dist.destroy_process_group()
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
 
 
-def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path):
+@pytest.mark.parametrize("n_images", [5, 1])
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, n_images):
     """N > 1 on the PRODUCT path before an 8-GPU node ever runs it: two processes share cuda:0 under a `gloo` group
     (it accepts device tensors); each runs train_step(net, opt, shard, lr, dist=dist) on its LPT-by-edge-count shard of
     a 5-image global step -- HIP gradients into the flat buffer, ONE all-reduce, grad_scale = 1 / images of the step,
     reg_scale = 1 / world, parameters broadcast from rank 0 -- and after two optimizer steps both replicas hold the
-    parameters of the single-process run over all five images (reduction order differs: <= 1e-6 relative)."""
+    parameters of the single-process run over all five images (reduction order differs: <= 1e-6 relative).  With ONE image
+    in the global step the second rank's shard is empty: it contributes zeros and still ends with rank 0's parameters."""
     import subprocess, sys, os, socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = """
@@ -133,10 +135,10 @@ cfg.random_seed = 42 + rank                     # replicas start DIFFERENT: the 
 net = Gnet(80, weight_reg=0.0005)
 if world > 1: broadcast_parameters(net.params, dist, src=0)
 opt = Optimizer(net)
-imgs = [make_image(n, 80, seed=s) for n, s in ((150, 0), (90, 1), (200, 2), (60, 3), (120, 4))]
+imgs = [make_image(n, 80, seed=s) for n, s in ((150, 0), (90, 1), (200, 2), (60, 3), (120, 4))][:%d]
 costs = [float(Gnet.count_edges(im["dets"], "cuda:0")) for im in imgs]
 mine = shard_images(imgs, rank, world, costs=costs)
-assert 1 <= len(mine) < len(imgs) or world == 1
+assert 1 <= len(mine) < len(imgs) or world == 1 or len(imgs) == 1
 net.grad_scale = 1.0 / len(imgs)
 for it in range(2):
     train_step(net, opt, mine, 1e-2, dist=dist)
@@ -144,7 +146,7 @@ torch.cuda.synchronize()
 np.save(out, net.params.cpu().numpy())
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
-""" % root
+""" % (root, n_images)
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = str(s_.getsockname()[1]); s_.close()
     single = str(tmp_path / "single.npy")
     subprocess.run([sys.executable, "-c", script, single, "0", "1", port], check=True, cwd=root, timeout=600)
