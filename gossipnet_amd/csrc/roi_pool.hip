@@ -119,22 +119,26 @@ __global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ da
   }
 }
 
-// Forward for C = 1024.  Two measured facts shape it (rocprofv3 --pmc on the one-wave-per-bin kernel: 63 % of the wave
+// Forward for C = 256 / 512 / 1024 / 2048 (measured at 1024).  Two measured facts shape it (rocprofv3 --pmc on the one-wave-per-bin kernel: 63 % of the wave
 // time waiting for an issue slot, ~900 instructions per wave of which 485 scalar -- ROI decode, window arithmetic and integer
 // division by the window width -- against 15 loads; the 803 MB of stores alone take 119 us):
 //   * the kernel is INSTRUCTION-ISSUE bound, not memory bound: one wave now handles a whole ROW of bins (roi, ph, all pw)
 //     of one 256-channel slice, so the ROI is decoded once per seven bins, and the window is walked by nested h / w loops
 //     (four pixels of a row in flight; a clamped repeat of the row's last pixel never wins a strict >) -- no divisions;
 //   * the channel dimension is dealt to the XCDs (workgroups go round-robin to the 8 XCDs, blockIdx % 8): the feature map of
-//     an image (9.8 MB) does not fit an XCD's 4 MB L2, a 256-channel slice (2.4 MB) does; XCDs 2 s and 2 s + 1 take slice s.
+//     an image (9.8 MB) does not fit an XCD's 4 MB L2, a 256-channel slice (2.4 MB) does; at C = 1024 XCDs 2 s and 2 s + 1 take slice s.
 // Pixels of a bin are visited in the reference's order (h, then w; strict >: the first maximum wins): top / argmax bit-exact.
+// (C = 256, 512, 1024, 2048 -- the usual trunk widths: 8 / C256 XCDs per 256-channel slice, C a compile-time constant of the
+//  address arithmetic)
+template <int C>
 __global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict__ data, int B, int H, int W,
                                                          const float* __restrict__ rois, int nrows, int PH, int PW,
                                                          float scale, float* __restrict__ top, int* __restrict__ argmax) {
-  constexpr int C = 1024;
+  constexpr int XPS = 8 / (C / 256);                          // XCDs per slice
+  static_assert(C % 256 == 0 && XPS >= 1 && XPS * (C / 256) == 8, "1, 2, 4 or 8 slices");
   const int lane = threadIdx.x & 63;
-  const int xcd = blockIdx.x & 7, slice = xcd >> 1;
-  const int row = ((int)(blockIdx.x >> 3) * 2 + (xcd & 1)) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7, slice = xcd / XPS;
+  const int row = ((int)(blockIdx.x >> 3) * XPS + (xcd % XPS)) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (row >= nrows) return;
   const int ph = row % PH, r = row / PH;
   const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
@@ -560,9 +564,13 @@ extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, 
   if (!bottom_data || !bottom_rois || !top_data || !argmax) return GNET_ERR_INVALID;
   if ((long long)H * W * C > 0x7fffffffLL || nbins > 0x7fffffffLL) return GNET_ERR_UNSUPPORTED;   // argmax is an int32 index within the image
   const unsigned grid = (unsigned)((nbins + 3) / 4);
-  if (C == 1024 && (long long)R * pooled_h <= 0x0fffffffLL) {
+  if ((C == 256 || C == 512 || C == 1024 || C == 2048) && (long long)R * pooled_h <= 0x0fffffffLL) {
     const int nrows = R * pooled_h;
-    roi_pool_fwd_rows<<<(unsigned)(8 * ((nrows + 7) / 8)), 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax);
+    const int xps = 8 / (C / 256);                             // a workgroup = 4 rows of one slice; 8 workgroups = 4 xps rows of every slice
+    const unsigned g = (unsigned)(8 * ((nrows + 4 * xps - 1) / (4 * xps)));
+#define GNET_ROWS(C_) roi_pool_fwd_rows<C_><<<g, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax)
+    if (C == 256) GNET_ROWS(256); else if (C == 512) GNET_ROWS(512); else if (C == 1024) GNET_ROWS(1024); else GNET_ROWS(2048);
+#undef GNET_ROWS
   }
   else if ((C & 3) == 0)
     roi_pool_fwd<true><<<grid, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, C, bottom_rois, nbins, pooled_h, pooled_w, spatial_scale, top_data, argmax);

@@ -14,7 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 d = "cuda:0"
 t0 = time.time()
 for case in range(cases):
-    C = int(rng.choice([1, 3, 4, 7, 16, 64, 100, 256, 260, 512, 768, 1024, 1280]))
+    C = int(rng.choice([1, 3, 4, 7, 16, 64, 100, 256, 260, 512, 768, 1024, 1280, 2048]))
     B = int(rng.integers(1, 4))
     H, W = int(rng.integers(1, 30)), int(rng.integers(1, 30))
     if C >= 512:
