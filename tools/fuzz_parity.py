@@ -14,11 +14,11 @@ from gossipnet_amd.synthetic import make_image
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 # configuration (argv[3]): 0 = 80 classes, 2 blocks, class weights; 1 = one class, 3 blocks, normalised loss; 2 = 80 classes, one
-# block, biases 0.5, pw_feat_multiplyer 0.7; 3 = neighbor_feats (a second reduce FC per block), 2 blocks
+# block, biases 0.5, pw_feat_multiplyer 0.7; 3 = neighbor_feats (a second reduce FC per block), 2 blocks; 4 = as 0 with 16 blocks
 CONF = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 NF = CONF == 3
-if CONF == 0:
-    NC, NB = 80, 2
+if CONF in (0, 4):
+    NC, NB = 80, (2 if CONF == 0 else 16)                # (4 = the real depth, 16 blocks)
     net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32))
 elif CONF == 1:
     NC, NB = 1, 3
