@@ -8,6 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgossipnet_hip.so")
 GNET_MAX_BLOCKS = 64
+ABI_VERSION = 5          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 _ERR = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported configuration",
@@ -59,12 +60,38 @@ EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_grap
            "gnet_forward", "gnet_loss", "gnet_match_prepare", "gnet_backward", "gnet_backward_prepare", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
            "gnet_profiler_destroy", "gnet_profiler_set_stride", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
-           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou"]
+           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou", "gnet_abi_version", "gnet_abi_sizes"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
             "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials", "edge_geometry"]
 
 _lib = None
+
+
+def abi_mirror():
+    """What gnet_abi_sizes must report for the ctypes mirrors above (sizes, four field offsets of gnet_buffers)."""
+    b = gnet_buffers
+    return [C.sizeof(gnet_config), C.sizeof(gnet_shape), C.sizeof(gnet_inputs), C.sizeof(b),
+            b.head1.offset, b.d_g1.offset, b.match_ws_bytes.offset, b.start_feat.offset]
+
+
+def check_abi(lib):
+    """Refuse a library whose struct layout differs from this binding's mirror -- whatever the source-hash record says
+    (a shifted gnet_buffers hands the kernels wrong device pointers without any error)."""
+    if not hasattr(lib, "gnet_abi_version") or not hasattr(lib, "gnet_abi_sizes"):
+        raise GnetError("libgossipnet_hip.so predates the ABI guard (no gnet_abi_version): rebuild it with "
+                        "`python -m gossipnet_amd.build`")
+    lib.gnet_abi_version.restype = C.c_int
+    lib.gnet_abi_version.argtypes = []
+    lib.gnet_abi_sizes.restype = C.c_int
+    lib.gnet_abi_sizes.argtypes = [C.POINTER(C.c_size_t)]
+    got_v = lib.gnet_abi_version()
+    sizes = (C.c_size_t * 8)()
+    n_classes = lib.gnet_abi_sizes(sizes)
+    if got_v != ABI_VERSION or list(sizes) != abi_mirror() or n_classes != len(KCLASSES):
+        raise GnetError("libgossipnet_hip.so has ABI version %d, layout %s, %d kernel classes; this binding expects version "
+                        "%d, layout %s, %d classes: rebuild the library (`python -m gossipnet_amd.build`) or update "
+                        "gossipnet_amd/_lib.py" % (got_v, list(sizes), n_classes, ABI_VERSION, abi_mirror(), len(KCLASSES)))
 
 
 def load():
@@ -95,6 +122,7 @@ def load():
     # same libamdhip64 as the streams/allocations it is handed (loading /opt/rocm's copy first breaks launches)
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    check_abi(lib)
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     P = C.POINTER
     lib.gnet_param_count.restype = i64

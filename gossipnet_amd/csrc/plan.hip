@@ -175,4 +175,19 @@ extern "C" int gnet_profiler_destroy(void* profiler) {
   return GNET_OK;
 }
 
-extern "C" const char* gnet_version(void) { return "gossipnet_hip 0.1 (gfx950, fp32 MFMA)"; }
+extern "C" const char* gnet_version(void) { return "gossipnet_hip 0.4 (gfx950, fp32 MFMA)"; }
+
+extern "C" int gnet_abi_version(void) { return GNET_ABI_VERSION; }
+
+extern "C" int gnet_abi_sizes(size_t out[8]) {
+  if (!out) return GNET_ERR_INVALID;
+  out[0] = sizeof(gnet_config);
+  out[1] = sizeof(gnet_shape);
+  out[2] = sizeof(gnet_inputs);
+  out[3] = sizeof(gnet_buffers);
+  out[4] = offsetof(gnet_buffers, head1);
+  out[5] = offsetof(gnet_buffers, d_g1);
+  out[6] = offsetof(gnet_buffers, match_ws_bytes);
+  out[7] = offsetof(gnet_buffers, start_feat);
+  return GNET_KCLASS_COUNT;
+}

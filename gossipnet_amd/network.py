@@ -76,7 +76,8 @@ class DeviceBatch(object):
     def __init__(self, images, device):
         if isinstance(images, dict):
             images = [images]
-        if len(images) == 0:
+        self.empty = len(images) == 0
+        if self.empty:
             # a data-parallel rank without an image in this step (fewer images than ranks): one image without detections --
             # zero gradients into the all-reduce, no loss terms
             images = [{"dets": np.zeros((0, 4), np.float32), "det_scores": np.zeros(0, np.float32), "det_classes": np.zeros(0, np.int32),
@@ -454,7 +455,14 @@ class Gnet(object):
         inp = db.c_inputs()
         self._inputs = inp
         if self._imfeats:
-            buf.start_feat = _vp(self._imfeat_forward(db))
+            if db.empty:
+                # a rank without an image in this step: no detections, so no start features to compute (the placeholder image
+                # carries no feature map) -- and the reduce_imfeats gradients below are exactly zero
+                self.roifeats = self.det_imfeats = None
+                self._imfeat_acts = []
+                buf.start_feat = _vp(self.params)          # [0,128]: never read
+            else:
+                buf.start_feat = _vp(self._imfeat_forward(db))
         if training:
             self._prepare_matching(shape, inp, buf, backward)
         _lib.check(lib.gnet_forward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
@@ -471,7 +479,13 @@ class Gnet(object):
                                              C.byref(buf), _vp(self.grads), 1, C.c_void_p(self._bprep_done.cuda_event), s),
                            "gnet_backward")
                 if self._imfeats:
-                    self._imfeat_backward(db)
+                    if db.empty:
+                        for nm, _ in self._spec:
+                            if nm.startswith("gnet/reduce_imfeats/"):
+                                self.gradients[nm].zero_()
+                        self.imfeats_grad = [] if self.imfeats_need_grad else None
+                    else:
+                        self._imfeat_backward(db)
                 if self.weight_reg:
                     # slim get_total_loss adds sum(l2_regularizer(scale)(w)) -> d/dw = scale * w (train.py:231-238),
                     # ONCE per optimisation step whatever the number of images in it: not scaled by grad_scale.

@@ -42,7 +42,9 @@ typedef void* gnet_stream_t; /* hipStream_t */
  * (nms_net/config.py:46-79, experiments/<exp>/conf.yaml).  Only the configuration of the two
  * shipped experiments is compiled: shortcut 128, reduced 32, pairfeat 64,
  * pwfeat 256, pwfeat_narrow 32, num_pwfeat_fc 3, predict_fc 128, num_predict_fc 3,
- * num_block_pw_fc 2, num_block_fc 2, neighbor_feats False, imfeats False. */
+ * num_block_pw_fc 2, num_block_fc 2 (anything else: GNET_ERR_UNSUPPORTED).  num_classes, num_blocks,
+ * neighbor_thresh, neighbor_feats, pw_feat_multiplyer and the loss flags are run-time values; the image-feature
+ * variant (cfg.gnet.imfeats) is selected per call through gnet_buffers.start_feat. */
 typedef struct gnet_config {
   int32_t num_classes;     /* C; multiclass = C > 1 (network.py:151)            */
   int32_t num_blocks;      /* cfg.gnet.num_blocks                                */
@@ -139,7 +141,7 @@ typedef struct gnet_buffers {
   float* w1_t;        /* [n_det,256] sum of d_h1 over the reversed pairs (neighbour role)          */
   float* packed_t;    /* [param_count] transposed copies of the weight matrices */
   float* arena;       /* per-workgroup partial weight gradients */
-  int32_t* scratch_i; /* [n_det + 1024] per detection: 1 = its segment-max records start from zero in every block (no edge, or its edges are split between two waves' ranges of the forward edge kernel), written once per step by gnet_forward; [n_det], [n_det + 1]: tile counters of the pairwise-feature kernels (reset and used inside gnet_forward / gnet_backward) */
+  int32_t* scratch_i; /* [n_det + 1024] per detection: 1 = its segment-max records start from zero in every block (no edge, or its edges are split between two waves' ranges of the forward edge kernel), written once per step by gnet_forward; [n_det]: the tile-claim counter of pw_fwd (reset and used inside gnet_forward only; no backward kernel touches scratch_i).  Because of this counter and the flags, two gnet_forward calls in flight at the same time must not share one planned workspace. */
   void* match_ws;     /* det_matching_workspace_bytes(n_det, n_gt) */
   size_t match_ws_bytes;
   size_t arena_floats;
@@ -300,6 +302,19 @@ int gnet_profiler_destroy(void* profiler);
 
 /* Version / build info string (static storage). */
 const char* gnet_version(void);
+
+/* ---- ABI guard ---------------------------------------------------------------------------------
+ * The structs above cross the boundary by value layout (a foreign-function binding mirrors them field by field:
+ * gossipnet_amd/_lib.py).  GNET_ABI_VERSION changes whenever a struct field, an enum value or an
+ * entry point's signature changes; gnet_abi_version() returns the value the LIBRARY was compiled with.
+ * gnet_abi_sizes fills out[0..7] = sizeof(gnet_config), sizeof(gnet_shape), sizeof(gnet_inputs),
+ * sizeof(gnet_buffers), offsetof(gnet_buffers, head1), offsetof(gnet_buffers, d_g1),
+ * offsetof(gnet_buffers, match_ws_bytes), offsetof(gnet_buffers, start_feat) and returns GNET_KCLASS_COUNT.
+ * A binding compares both with its own mirror before the first call and refuses to go on when they differ
+ * (a shifted gnet_buffers would hand the kernels wrong device pointers without any error). */
+#define GNET_ABI_VERSION 5
+int gnet_abi_version(void);
+int gnet_abi_sizes(size_t out[8]);
 
 #ifdef __cplusplus
 }

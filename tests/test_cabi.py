@@ -28,6 +28,43 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.gnet_version()
 
 
+def test_abi_guard_sizes_and_version():
+    """The ctypes mirrors of the four structs have the library's sizes and field offsets, the header's version is the
+    binding's, and load() refuses a library that reports anything else."""
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "gossipnet_hip.h")).read()
+    assert int(re.search(r"#define GNET_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION == lib.gnet_abi_version()
+    sizes = (C.c_size_t * 8)()
+    assert lib.gnet_abi_sizes(sizes) == len(_lib.KCLASSES)
+    assert list(sizes) == _lib.abi_mirror()
+    assert sizes[3] == C.sizeof(_lib.gnet_buffers) > 5000 and sizes[0] == 17 * 4
+    assert lib.gnet_abi_sizes(None) == _lib.ERR_INVALID
+
+    class Fn(object):                          # stands in for a ctypes function object (check_abi sets restype / argtypes)
+        def __init__(self, f):
+            self.f = f
+
+        def __call__(self, *a):
+            return self.f(*a)
+
+    def sizes_shifted(out):                    # a library built from a header with one more pointer in gnet_buffers
+        for i, v in enumerate(_lib.abi_mirror()):
+            out[i] = v + (8 if i >= 3 else 0)
+        return len(_lib.KCLASSES)
+
+    class Fake(object):
+        pass
+    fake = Fake()
+    fake.gnet_abi_version, fake.gnet_abi_sizes = Fn(lambda: _lib.ABI_VERSION), Fn(sizes_shifted)
+    with pytest.raises(_lib.GnetError, match="layout"):
+        _lib.check_abi(fake)
+    fake.gnet_abi_version, fake.gnet_abi_sizes = Fn(lambda: _lib.ABI_VERSION - 1), Fn(lambda out: lib.gnet_abi_sizes(out))
+    with pytest.raises(_lib.GnetError, match="ABI version"):
+        _lib.check_abi(fake)
+    with pytest.raises(_lib.GnetError, match="predates"):
+        _lib.check_abi(Fake())
+
+
 def test_param_count_and_unsupported_config():
     lib = _lib.load()
     ok = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0, 0)

@@ -224,17 +224,21 @@ def test_headline_config_single_image():
     assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
 
 
-def test_headline_bench_batch_8_images():
+@pytest.mark.parametrize("preset", ["dense", "coco_like"])
+def test_headline_bench_batch_8_images(preset):
     """The batch bench.py times: 8 images x N = 2000, C = 80, B = 16 as one block-diagonal graph
-    (E ~ 1.44 M: the XCD-aware range mapping and the 32-bit byte offsets are live at this size).
-    Per image: edges / det_anno_iou / assignments bit-exact, activations and logits <= 1e-5; the batch
-    gradient <= 1e-5 against the sum of the per-image oracle gradients on the pinned piece."""
+    (dense preset: E ~ 1.44 M, the XCD-aware range mapping and the 32-bit byte offsets are live at this size;
+    coco_like preset, bench.py's other_configs line: E/N ~ 34 -- fewer tiles per wave, the equal (not layered)
+    edge_fwd_w ranges, a different winner fraction; reference experiments/coco_multiclass/conf.yaml, 16 stacked
+    blocks network.py:344-409).  Per image: edges / det_anno_iou / assignments bit-exact, activations and logits
+    <= 1e-5; the batch gradient <= 1e-5 against the sum of the per-image oracle gradients on the pinned piece."""
     n, c, b, k_img = 2000, 80, 16, 8
     net, orc = make_pair(c, b)
     net.keep_edge_activations = True
-    imgs = [make_image(n, c, seed=i) for i in range(k_img)]
+    imgs = [make_image(n, c, seed=i, preset=preset) for i in range(k_img)]
     net.run(imgs)
     torch.cuda.synchronize()
+    print("%s preset: 8 x N=2000, E = %d (E/N %.1f)" % (preset, net.num_edges, net.num_edges / (n * k_img)))
     pairs_all = net.neighbor_pair_idxs.cpu().numpy()
     rp = net.row_ptr.cpu().numpy()
     pred = net.prediction.cpu().numpy(); assign = net.det_gt_matching.cpu().numpy(); labels = net.labels.cpu().numpy()
@@ -496,6 +500,30 @@ def test_imfeats_start_features(imfeat_dim):
     errs = grad_errors(net, gpin, c, b, imfeat=imf)
     assert any(k.startswith("gnet/reduce_imfeats/") for k in errs)
     assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
+    reset_cfg()
+
+
+def test_imfeats_rank_without_images_contributes_zero():
+    """The image-feature variant on a data-parallel rank whose shard is empty: the placeholder image has no feature map; the
+    step runs, the loss is 0 and every gradient -- the reduce_imfeats tensors included, right after a step that left them
+    non-zero -- is exactly 0 (the other ranks would otherwise wait in the all-reduce for a rank that raised)."""
+    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.network import Gnet
+    c, b, ch = 80, 2, 32
+    reset_cfg()
+    cfg.gnet.num_blocks = b
+    cfg.gnet.imfeats = True
+    cfg.gnet.imfeat_dim = 64
+    net = Gnet(c, imfeat_channels=ch, imfeat_stride=16)
+    batch = make_image(60, c, seed=3)
+    batch["imfeats"] = np.random.default_rng(1).normal(size=(1, 30, 40, ch)).astype(np.float32)
+    net.run(batch); torch.cuda.synchronize()
+    g_full = net.grads.clone()
+    assert net.gradients["gnet/reduce_imfeats/fully_connected/weights"].abs().max().item() > 0
+    net.run([]); torch.cuda.synchronize()
+    assert float(net.loss) == 0.0 and net.grads.abs().max().item() == 0.0
+    net.run(batch); torch.cuda.synchronize()
+    assert torch.equal(net.grads, g_full)
     reset_cfg()
 
 

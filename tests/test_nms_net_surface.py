@@ -13,6 +13,10 @@ def test_every_name_a_caller_of_the_reference_imports():
     from nms_net.config import cfg_from_file                         # train.py:21
     from nms_net.roi_pooling_layer import roi_pooling_op, roi_pooling_op_grad      # nms_net/network.py:13
     from nms_net import matching_module                              # nms_net/network.py:14
+    from nms_net.dataset import ShuffledDataset, load_roi            # train.py:22, test.py:22
+    from nms_net.class_weights import class_equal_weights            # train.py:23
+    from nms_net import tools                                        # test.py:20
+    assert callable(load_roi) and callable(class_equal_weights) and callable(tools.Timer) and ShuffledDataset.next_batch
     assert cfg is gossipnet_amd.config.cfg and cfg_from_file is gossipnet_amd.config.cfg_from_file
     assert Gnet is gossipnet_amd.network.Gnet
     assert callable(matching_module.detection_matching)
@@ -24,6 +28,51 @@ def test_every_name_a_caller_of_the_reference_imports():
     # the Gnet surface of SURVEY 8b
     assert Gnet.name == 'gnet' and set(Gnet.get_batch_spec(80)) >= {'dets', 'det_scores', 'det_classes', 'gt_boxes', 'gt_crowd', 'gt_classes'}
     assert set(Gnet.get_batch_spec(80, is_training=False)) == {'dets', 'det_scores', 'det_classes'}
+
+
+def test_class_equal_weights_known_answer():
+    """nms_net/class_weights.py:12-22 + imdb/tools.py:113-124 traced by hand: C = 2, pos_weight 0.1; one image with
+    gt classes [1, 1, 2] and 10 detections, one image with gt [2] and no detections: counts start at 1 ->
+    [1 + 7, 1 + 2, 1 + 2] = [8, 3, 3], 14 samples; expected [0.9, 0.05, 0.05] -> 14 * e / counts."""
+    from gossipnet_amd.config import reset_cfg
+    from nms_net.class_weights import class_equal_weights, get_class_counts
+    reset_cfg()
+    imdb = {"num_classes": 2, "roidb": [{"gt_classes": np.array([1, 1, 2]), "det_classes": np.ones(10, np.int32)},
+                                        {"gt_classes": np.array([2])}]}
+    assert get_class_counts(imdb).tolist() == [8, 3, 3]
+    w = class_equal_weights(imdb)
+    assert np.allclose(w, [14 * 0.9 / 8, 14 * 0.05 / 3, 14 * 0.05 / 3], rtol=1e-6)
+
+
+def test_datasets_feed_rois_without_touching_the_imdb():
+    """nms_net/dataset.py:17-112: load_roi copies the record and scales boxes by im_scale only with images; the shuffled
+    set redraws a permutation that cannot fill the next step; batch_size k returns k images (one per step in the reference)."""
+    from nms_net.dataset import ShuffledDataset, TestDataset, load_roi
+    roidb = [{"dets": np.full((2, 4), float(i), np.float32), "gt_boxes": np.ones((1, 4), np.float32), "id": i} for i in range(5)]
+    imdb = {"roidb": roidb, "num_classes": 1}
+    r = load_roi(False, roidb[2])
+    assert r["im_scale"] == 1.0 and r is not roidb[2] and "im_scale" not in roidb[2]
+    with pytest.raises(ValueError):
+        load_roi(True, roidb[2])
+    r = load_roi(True, dict(roidb[2], imfeats=np.zeros((1, 2, 2, 4), np.float32), im_scale=1.5))
+    assert np.array_equal(r["dets"], roidb[2]["dets"] * 1.5) and np.array_equal(roidb[2]["dets"], np.full((2, 4), 2.0, np.float32))
+    ts = TestDataset(imdb, 1, False)
+    assert len(ts) == 5 and [ts.next_batch()["id"] for _ in range(5)] == [0, 1, 2, 3, 4]
+    sd = ShuffledDataset(imdb, 1, False, rng=np.random.default_rng(0))
+    first = [sd.next_batch()["id"] for _ in range(5)]
+    assert sorted(first) == [0, 1, 2, 3, 4]
+    sd = ShuffledDataset(imdb, 2, False, rng=np.random.default_rng(0))
+    seen = [tuple(r["id"] for r in sd.next_batch()) for _ in range(4)]
+    assert all(len(s) == 2 and s[0] != s[1] for s in seen) and len({i for s in seen[:2] for i in s}) == 4
+
+
+def test_timer_running_average():
+    from nms_net.tools import Timer
+    calls = []
+    t = Timer(sync=lambda: calls.append(1))
+    t.tic(); d = t.toc(average=False)
+    t.tic(); avg = t.toc()
+    assert t.calls == 2 and len(calls) == 4 and d >= 0 and abs(avg - t.total_time / 2) < 1e-12
 
 
 def test_learning_rate_table_semantics():
