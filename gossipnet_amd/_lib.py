@@ -47,7 +47,7 @@ _PB = C.c_void_p * (GNET_MAX_BLOCKS + 1)
 
 
 class gnet_buffers(C.Structure):
-    _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "edge_t", "edge_nz", "geo", "einfo", "pw_h1", "pw_h2",
+    _fields_ = ([(n, C.c_void_p) for n in ("row_ptr", "edge_c", "edge_n", "edge_iou", "edge_t", "edge_nz", "geo", "pw_tc", "pw_tn", "pw_h1", "pw_h2",
                                            "pw_feats")] +
                 [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_rnb", "blk_h1", "blk_h2", "blk_parg")] +
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",

@@ -371,22 +371,21 @@ struct EdgeBwdWArgs {
   GNET_TRACE_FIELD
 };
 
-// Top of an edge_bwd_w tile: edge ids and the bias tile rc[c] + rn[n] (the forward kernel's operand order) into the wave's
-// LDS area, then h1 = relu(P . Wp + bias) with the forward kernel's operation sequence (same bits), in place.
-// x / y = the sixteen gathered bias-row chunks (lane = (row 4 i + q4, chunk f4)), pa = the lane's P row (A layout).
+// Top of an edge_bwd_w tile: h1 = relu(P . Wp + (rc[c] + rn[n])) with the forward kernel's operation sequence (same bits),
+// computed TRANSPOSED exactly as edge_fwd_w does (h1^T = Wp^T . P^T: lane = tile row, register r = feature 8 (r >> 2) + 4 half +
+// (r & 3) [+ 32]): the accumulators start from the lane's OWN bias-row pieces x = rc[c], y = rn[n] (eight 16-byte gathers each,
+// no cross-lane shuffles, no LDS staging of the bias tile) and go to the wave's LDS tile as whole 16-byte pieces of row-major
+// rows (the d W2 gathers read rows; g1 reads its ReLU mask back as the same pieces).  pa = the lane's P row (B operand).
 __device__ __forceinline__ void ebw_stage_h1(float* sH, int* sE, const float* sWpT, const float4 (&x)[8], const float4 (&y)[8],
                                              const f32x4 (&pa)[4], int my_e, int lane) {
-  const int col = lane & 31, half = lane >> 5, q4 = lane >> 4, f4 = lane & 15;
+  const int col = lane & 31, half = lane >> 5;
   if (half == 0) sE[col] = my_e;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    *reinterpret_cast<float4*>(sH + (4 * i + q4) * (D_P + 4) + 4 * f4) =
-        make_float4(x[i].x + y[i].x, x[i].y + y[i].y, x[i].z + y[i].z, x[i].w + y[i].w);
-  wave_lds_sync();
   f32x16 h1a, h1b;
-  float* hp = sH + (4 * half) * (D_P + 4) + col;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { h1a[r] = hp[crow(r, 0) * (D_P + 4)]; h1b[r] = hp[crow(r, 0) * (D_P + 4) + 32]; }
+  for (int g = 0; g < 4; ++g) {
+    h1a[4 * g + 0] = x[g].x + y[g].x; h1a[4 * g + 1] = x[g].y + y[g].y; h1a[4 * g + 2] = x[g].z + y[g].z; h1a[4 * g + 3] = x[g].w + y[g].w;
+    h1b[4 * g + 0] = x[4 + g].x + y[4 + g].x; h1b[4 * g + 1] = x[4 + g].y + y[4 + g].y; h1b[4 * g + 2] = x[4 + g].z + y[4 + g].z; h1b[4 * g + 3] = x[4 + g].w + y[4 + g].w;
+  }
   const float* b0 = sWpT + col * (D_E + 4) + 4 * half;
   const float* b1 = b0 + 32 * (D_E + 4);
 #pragma unroll
@@ -394,17 +393,23 @@ __device__ __forceinline__ void ebw_stage_h1(float* sH, int* sE, const float* sW
     const f32x4 av = pa[k];
     const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
     const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.x, av.x, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.x, av.x, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.y, av.y, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.y, av.y, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.z, av.z, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.z, av.z, h1b, 0, 0, 0);
+    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.w, av.w, h1a, 0, 0, 0);
+    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.w, av.w, h1b, 0, 0, 0);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { hp[crow(r, 0) * (D_P + 4)] = relu_bits(h1a[r]); hp[crow(r, 0) * (D_P + 4) + 32] = relu_bits(h1b[r]); }
+  for (int r = 0; r < 16; ++r) { h1a[r] = relu_bits(h1a[r]); h1b[r] = relu_bits(h1b[r]); }
+  float* hp = sH + col * (D_P + 4) + 4 * half;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *reinterpret_cast<float4*>(hp + 8 * g) = make_float4(h1a[4 * g], h1a[4 * g + 1], h1a[4 * g + 2], h1a[4 * g + 3]);
+    *reinterpret_cast<float4*>(hp + 32 + 8 * g) = make_float4(h1b[4 * g], h1b[4 * g + 1], h1b[4 * g + 2], h1b[4 * g + 3]);
+  }
 }
 
 constexpr int EBW_WAVES = 4;
@@ -480,17 +485,16 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     apB = a.apos[ob_]; dvB = a.d_pc[ob_];                                                               \
     apC = a.apos[oc_]; dvC = a.d_pc[oc_];                                                               \
   } while (0)
-  // bias rows (rc[c] | rn[n], lane = (row 4 i + q4, 16-byte chunk f4)) and P rows (A layout) of the tile whose records are
-  // in nx_e / nx_c / nx_nz: all sixteen row requests in flight together, one exposed latency
+  // bias rows rc[c], rn[n] as the lane's own sixteen 16-byte pieces (lane = row, features 8 g + 4 half .. + 3 and + 32) and its
+  // P row (B layout) of the tile whose records are in nx_e / nx_c / nx_nz: all twenty requests in flight together
 #define EBW_LOAD_TILE(bx, by, bpa)                                                                      \
   do {                                                                                                  \
     const float* ap_ = a.pw + (size_t)nx_e * D_E + 4 * half;                                            \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) bpa[k_] = *reinterpret_cast<const f32x4*>(ap_ + 8 * k_); \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
-      const int row_ = 4 * i_ + q4;                                                                     \
-      const int cr_ = max(__shfl(nx_c, row_), 0), nzr_ = __shfl(nx_nz, row_);                           \
-      bx[i_] = ldg4_b(a.rc, (unsigned)cr_ * (D_P * 4u) + 16u * f4);                                     \
-      by[i_] = ldg4_b(a.rn, (unsigned)nzr_ * (D_P * 4u) + 16u * f4);                                    \
+    const unsigned oc_ = (unsigned)max(nx_c, 0) * (D_P * 4u) + 16u * half, on_ = (unsigned)nx_nz * (D_P * 4u) + 16u * half; \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                  \
+      bx[g_] = ldg4_b(a.rc, oc_ + 32u * g_);                                                            \
+      by[g_] = ldg4_b(a.rn, on_ + 32u * g_);                                                            \
     }                                                                                                   \
   } while (0)
   // Kernel front: the first tile's chain of dependent requests -- list entries -> row records -> (bias rows, P rows,
@@ -667,31 +671,44 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       if (hleft) wave_lds_sync();                        // the slots are rewritten by the next chunk
     }
     if (t == t0) GSTAMP(a, 4);
-    // ---- g1 = (h1 > 0) * (d h2 . W2^T); overwrites h1 in place
+    // ---- g1 = (h1 > 0) * (d h2 . W2^T), computed transposed (g1^T = W2 . d h2^T: the operands swapped) so that its
+    // accumulators share h1^T's layout -- lane = row, register r = feature crow(r, half) [+ 32]: the mask is the lane's own
+    // eight 16-byte pieces of its h1 row (requested in front of the MFMAs), the masked values ARE the A operand of the d P
+    // product below (k pairing of mma_abt), and the rows go to LDS as 16-byte pieces (over h1) for the d Wp product and
+    // the row store
+    f32x16 g1a = zero16(), g1b = zero16();
     {
-      f32x16 g1a = zero16(), g1b = zero16();
+      float* hp = sH + col * LD64 + 4 * half;
+      float4 hm[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { hm[g] = *reinterpret_cast<const float4*>(hp + 8 * g); hm[4 + g] = *reinterpret_cast<const float4*>(hp + 32 + 8 * g); }
       const float* b0 = sW2 + col * LD64 + 4 * half;
       const float* b1 = b0 + 32 * LD64;
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * s8);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * s8);
-        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 0], bv0.x, g1a, 0, 0, 0);
-        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 0], bv1.x, g1b, 0, 0, 0);
-        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 1], bv0.y, g1a, 0, 0, 0);
-        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 1], bv1.y, g1b, 0, 0, 0);
-        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 2], bv0.z, g1a, 0, 0, 0);
-        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 2], bv1.z, g1b, 0, 0, 0);
-        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 3], bv0.w, g1a, 0, 0, 0);
-        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[4 * s8 + 3], bv1.w, g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.x, dA[4 * s8 + 0], g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.x, dA[4 * s8 + 0], g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.y, dA[4 * s8 + 1], g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.y, dA[4 * s8 + 1], g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.z, dA[4 * s8 + 2], g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.z, dA[4 * s8 + 2], g1b, 0, 0, 0);
+        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.w, dA[4 * s8 + 3], g1a, 0, 0, 0);
+        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.w, dA[4 * s8 + 3], g1b, 0, 0, 0);
       }
-      float* hp = sH + (4 * half) * LD64 + col;          // every lane rewrites the elements it reads
+      const bool live = col < nrows;                     // rows past the list (last tile): zero
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool live = crow(r, half) < nrows;         // rows past the list (last tile): zero
-        const float ha = hp[crow(r, 0) * LD64], hb = hp[crow(r, 0) * LD64 + 32];
-        hp[crow(r, 0) * LD64] = (live && ha > 0.f) ? g1a[r] : 0.f;
-        hp[crow(r, 0) * LD64 + 32] = (live && hb > 0.f) ? g1b[r] : 0.f;
+      for (int g = 0; g < 4; ++g) {
+        g1a[4 * g + 0] = (live && hm[g].x > 0.f) ? g1a[4 * g + 0] : 0.f; g1a[4 * g + 1] = (live && hm[g].y > 0.f) ? g1a[4 * g + 1] : 0.f;
+        g1a[4 * g + 2] = (live && hm[g].z > 0.f) ? g1a[4 * g + 2] : 0.f; g1a[4 * g + 3] = (live && hm[g].w > 0.f) ? g1a[4 * g + 3] : 0.f;
+        g1b[4 * g + 0] = (live && hm[4 + g].x > 0.f) ? g1b[4 * g + 0] : 0.f; g1b[4 * g + 1] = (live && hm[4 + g].y > 0.f) ? g1b[4 * g + 1] : 0.f;
+        g1b[4 * g + 2] = (live && hm[4 + g].z > 0.f) ? g1b[4 * g + 2] : 0.f; g1b[4 * g + 3] = (live && hm[4 + g].w > 0.f) ? g1b[4 * g + 3] : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(hp + 8 * g) = make_float4(g1a[4 * g], g1a[4 * g + 1], g1a[4 * g + 2], g1a[4 * g + 3]);
+        *reinterpret_cast<float4*>(hp + 32 + 8 * g) = make_float4(g1b[4 * g], g1b[4 * g + 1], g1b[4 * g + 2], g1b[4 * g + 3]);
       }
     }
     wave_lds_sync();
@@ -708,16 +725,22 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     // ---- d P = g1 . Wp^T;  d_pw[e] += d P
     {
       f32x16 acc = zero16();
-      const float* ap = sH + col * LD64 + 4 * half;
       const float* bp = sWpT + (4 * half) * LD32 + col;             // B[k = f][n = pf] = Wp[pf = col][f] = sWpT[f][pf]
 #pragma unroll
-      for (int k = 0; k < D_P; k += 8) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[(k + 0) * LD32], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[(k + 1) * LD32], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[(k + 2) * LD32], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[(k + 3) * LD32], acc, 0, 0, 0);
-        if ((k & 8) != 0) __builtin_amdgcn_sched_barrier(0);
+      for (int g = 0; g < 4; ++g) {                                  // k = f = 8 g + 4 half + q: the g1^T registers, in k order
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1a[4 * g + 0], bp[(8 * g + 0) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1a[4 * g + 1], bp[(8 * g + 1) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1a[4 * g + 2], bp[(8 * g + 2) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1a[4 * g + 3], bp[(8 * g + 3) * LD32], acc, 0, 0, 0);
+        if ((g & 1) != 0) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1b[4 * g + 0], bp[(32 + 8 * g + 0) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1b[4 * g + 1], bp[(32 + 8 * g + 1) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1b[4 * g + 2], bp[(32 + 8 * g + 2) * LD32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1b[4 * g + 3], bp[(32 + 8 * g + 3) * LD32], acc, 0, 0, 0);
+        if ((g & 1) != 0) __builtin_amdgcn_sched_barrier(0);
       }
       // rows past the list (last tile) go to the slack row E of d_pw: unconditional, no divergent branches
 #pragma unroll

@@ -52,6 +52,19 @@ __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ 
   long long off; int in, out;
   mat_info(blockIdx.y, dpw, nblocks, nf, &off, &in, &out);
   const int total = in * out;
+  if (blockIdx.y == 1) {
+    // pw_feats/fc2 (256 x 256) is streamed from L2 by pw_fwd as MFMA operand fragments: FRAGMENT-MAJOR, so that the 64
+    // lanes of one load instruction read one contiguous 1 KB block (8 cache lines) instead of 32 bytes of each of 32 rows
+    // (32 lines per instruction: the stream's tag look-ups, not its bytes, loaded the CU's texture path).  Wave w owns output
+    // columns [32 w, 32 w + 32); k-step s covers k = 8 s .. 8 s + 7; lane (r, h) holds W[k = 8 s + 4 h + t][o = 32 w + r], t = 0..3:
+    //   packed[(((w * 32 + s) * 64) + 32 h + r) * 4 + t]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+      const int t = i & 3, lane = (i >> 2) & 63, s_ = (i >> 8) & 31, w = i >> 13;
+      const int o = 32 * w + (lane & 31), k = 8 * s_ + 4 * (lane >> 5) + t;
+      packed[off + i] = params[off + (long long)k * out + o];
+    }
+    return;
+  }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int o = i / in, k = i - o * in;   // packed[o][k] = W[k][o]
     packed[off + i] = params[off + (long long)k * out + o];
@@ -68,7 +81,12 @@ struct GeoArgs {
   const float4* dets; const float* scores; const int* classes;
   int cprime, multiclass;
   float* geo;       // [E,8]  (iou, x_dist, y_dist, l2_dist, w_diff, h_diff, aspect_diff, 0)
-  int4* einfo;      // [E]    (fc1 row of c's score column, fc1 row of n's score column, score_c, score_n)
+  // The 2C one-hot x score columns of _geometry_feats (network.py:413-419) enter pw_feats/fc1 as ONE row of its weight matrix
+  // times the detection's score -- a per-DETECTION term, not a per-edge one: tc[i] = score_i W1[class_i - 1] + b1 (i as the
+  // centre of a pair), tn[i] = score_i W1[C + class_i - 1] (i as the neighbour).  Two [N,256] tables per step; fc1 of an
+  // edge (c, n) starts from tc[c] + tn[n] (pw_fwd).
+  const float* w1; const float* b1;   // pw_feats/fc1 natural [dpw,256], [256]
+  float* tc; float* tn;               // [N,256] each
   int* edge_nz;     // [E+64] n, or n_det for self pairs (their neighbour features are zeroed, network.py:371-374) and the tail
   int n_det;
   float mult;       // cfg.gnet.pw_feat_multiplyer (network.py:199-200: the whole feature row times it)
@@ -80,14 +98,29 @@ struct GeoArgs {
   int* pw_claim; int pw_claim0;   // pw_fwd's tile counter and its start value (the tiles behind every workgroup's first two)
 };
 
-// _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns are kept
-// as (row, score) pairs; the 7 geometry columns are evaluated in the reference's fp32 operation order.
+// _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns become the per-detection
+// tables tc / tn (16 bytes of each per thread, grid-stride); the 7 geometry columns are evaluated in the reference's fp32
+// operation order.
 __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e == 0) *a.pw_claim = a.pw_claim0;
   for (int i = e; i < a.n_det; i += gridDim.x * 256) {
     const int eb = a.row_ptr[i], ee = a.row_ptr[i + 1];
     a.straddle[i] = (ee == eb || efw_owner(eb >> 5, a.ef_tiles, a.ef_waves) != efw_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
+  }
+  for (int idx = e; idx < a.n_det * (D_H / 4); idx += gridDim.x * 256) {
+    const int i = idx >> 6, q = idx & 63;
+    float sc = a.scores[i] * a.mult, sn = sc;          // x * 1.0f is exact: the default multiplier changes no bit
+    int rc = 0, rn = 1;
+    if (a.multiclass) {                                // scatter_nd one-hot x score (network.py:413-419)
+      const int cl = a.classes[i] - 1;
+      if (cl >= 0 && cl < a.cprime) { rc = cl; rn = a.cprime + cl; } else { sc = 0.f; sn = 0.f; rn = a.cprime; }
+    }
+    const float4 wc = *reinterpret_cast<const float4*>(a.w1 + (size_t)rc * D_H + 4 * q);
+    const float4 wn = *reinterpret_cast<const float4*>(a.w1 + (size_t)rn * D_H + 4 * q);
+    const float4 bb = *reinterpret_cast<const float4*>(a.b1 + 4 * q);
+    *reinterpret_cast<float4*>(a.tc + (size_t)i * D_H + 4 * q) = make_float4(sc * wc.x + bb.x, sc * wc.y + bb.y, sc * wc.z + bb.z, sc * wc.w + bb.w);
+    *reinterpret_cast<float4*>(a.tn + (size_t)i * D_H + 4 * q) = make_float4(sn * wn.x, sn * wn.y, sn * wn.z, sn * wn.w);
   }
   if (e >= a.n_edge) {
     if (e < a.n_edge + 64) a.edge_nz[e] = a.n_det;
@@ -107,27 +140,21 @@ __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const float wd = logf(n_w / c_w) / log2f_;
   const float hd = logf(n_h / c_h) / log2f_;
   const float ad = (logf(n_w / n_h) - logf(c_w / c_h)) / log2f_;
-  float sc = a.scores[c], sn = a.scores[n];
-  int rc = 0, rn = 1;
-  if (a.multiclass) {                   // scatter_nd one-hot x score (network.py:413-419)
-    const int cc = a.classes[c] - 1, cn = a.classes[n] - 1;
-    if (cc >= 0 && cc < a.cprime) rc = cc; else sc = 0.f;
-    if (cn >= 0 && cn < a.cprime) rn = a.cprime + cn; else { sn = 0.f; rn = a.cprime; }
-  }
   float4* gp = reinterpret_cast<float4*>(a.geo + (size_t)e * 8);
   const float m = a.mult;                   // x * 1.0f is exact: the default changes no bit
   gp[0] = make_float4(a.edge_iou[e] * m, xd * m, yd * m, l2 * m);
   gp[1] = make_float4(wd * m, hd * m, ad * m, 0.f);
-  a.einfo[e] = make_int4(rc, rn, __float_as_int(sc * m), __float_as_int(sn * m));
   a.edge_nz[e] = c == n ? a.n_det : n;
 }
 
 struct PwFwdArgs {
   int n_edge;
   int cprime;
-  const float* geo; const int4* einfo;
-  const float* w1; const float* b1;     // natural [dpw,256]
-  const float* w2t; const float* b2;    // transposed [256,256]
+  const float* geo;
+  const int* edge_c; const int* edge_n;
+  const float* tc; const float* tn;     // [N,256] per-detection score terms of fc1 (edge_geometry): tc includes the bias
+  const float* w1;                      // natural [dpw,256]: the 7 geometry rows are read here
+  const float* w2t; const float* b2;    // fc2 as operand fragments (pack_transpose: fragment-major), [256]
   const float* w3t; const float* b3;    // transposed [32,256]
   float* h1; float* h2; float* pw;
   int training;
@@ -144,22 +171,27 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                          // [64][260]
   float* sR = sH;                            // [4][64][32] fc3 partials, aliased over sH (2 workgroups / CU)
-  float* sStage = sH + PW_T * PW_LD;         // 2 x { geo [64][8], (row, score) records [64] }: this tile / the next
+  float* sStage = sH + PW_T * PW_LD;         // 2 x { geo [64][8], centre index [64], neighbour index [64] }: this tile / the next
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int f = tid & 255, eh = wave >> 2;   // eh (scalar): which of the two interleaved edge sets
   const int col = lane & 31, half = lane >> 5;
+  // fc1's geometry rows as the A operand of a TRANSPOSED product (h1^T = Wg^T . geo^T, as edge_fwd_w's first layer): the
+  // wave owns output features [32 wave, 32 wave + 32); lane (feature col, half) supplies Wg[4 half + s][32 wave + col] at
+  // k-step s -- the k pairing (s, 4 + s) lets the B operand, the lane's edge's geometry columns 4 half .. 4 half + 3, be ONE
+  // 16-byte LDS read.  Row 7 of the geometry block does not exist (the eighth column is zero padding).
   const int geo_row0 = 2 * a.cprime;
-  float wg[7];
+  float wgA[4];
 #pragma unroll
-  for (int g = 0; g < 7; ++g) wg[g] = a.w1[(size_t)(geo_row0 + g) * D_H + f];
-  const float bias1 = a.b1[f];
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int k = 4 * half + s_;
+    wgA[s_] = k < 7 ? a.w1[(size_t)(geo_row0 + k) * D_H + 32 * wave + col] : 0.f;
+  }
   const float bias2 = a.b2[32 * wave + col];
   const float bias3 = a.b3[tid & 31];
   // fc3: wave = (row tile mt, K quarter kq)
   const int mt = wave & 1, kq = wave >> 1;
-  // The geometry columns [64][8] and (row, score) records [64] of a tile reach LDS by DMA (global_load_lds: 1 KB per
-  // wave-instruction, lane i -> 16 bytes at base + 16 i; waves 0 / 1 the two halves of the geometry, wave 2 the records),
-  // one tile ahead, into the staging buffer the previous tile has finished with.  No staging registers: at 128
+  // The geometry columns [64][8] and the centre / neighbour indices [64] + [64] of a tile reach LDS by DMA (global_load_lds:
+  // lane i -> its 16 (waves 0 / 1: the two halves of the geometry) or 4 bytes (wave 2: edge_c, wave 3: edge_n) at base +
+  // size * i), one tile ahead, into the staging buffer the previous tile has finished with.  No staging registers: at 128
   // registers per wave they were spilled, and a spill reload behind the tile's h1 / h2 stores made the in-order memory
   // counter wait for those stores.
   const int last = a.n_edge - 1;
@@ -169,9 +201,10 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
       const int e_ = min((tile_) * PW_T + (tid >> 1), last);                                            \
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.geo + (size_t)e_ * 8 + 4 * (tid & 1)), \
                                        (__attribute__((address_space(3))) void*)((dst_) + 256 * wave), 16, 0, 0);          \
-    } else if (wave == 2) {                                                                             \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.einfo + min((tile_) * PW_T + lane, last)), \
-                                       (__attribute__((address_space(3))) void*)((dst_) + PW_T * 8), 16, 0, 0);             \
+    } else if (wave < 4) {                                                                              \
+      const int* src_ = wave == 2 ? a.edge_c : a.edge_n;                                                \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + min((tile_) * PW_T + lane, last)), \
+                                       (__attribute__((address_space(3))) void*)((dst_) + PW_T * 8 + PW_T * (wave - 2)), 4, 0, 0); \
     }                                                                                                   \
   } while (0)
   if ((int)blockIdx.x * PW_T < a.n_edge) {
@@ -189,57 +222,64 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
 
   for (; tile * PW_T < a.n_edge; ++it) {
     const int e0 = tile * PW_T;
-    // ---- phase 0: the tile's geometry columns and (row, score) pairs were staged during the previous tile
+    // ---- phase 0: the tile's geometry columns and pair indices were staged during the previous tile
     const float* sGeo = sStage + (it & 1) * (PW_T * 12);
-    const int4* sInf = reinterpret_cast<const int4*>(sGeo + PW_T * 8);
+    const int* sIdx = reinterpret_cast<const int*>(sGeo + PW_T * 8);
     float* nGeo = sStage + ((it & 1) ^ 1) * (PW_T * 12);
     // this tile's staging DMA was issued a tile ago, in front of at least the four pw stores of every wave: "all but
     // the four youngest operations" covers it without waiting for those stores
-    if (wave < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (it == 10) GSTAMP(a, 0);
     __syncthreads();
     if (it == 10) GSTAMP(a, 1);
-    // ---- phase 1: fc1 + ReLU, structured (2 row lookups + 7 geometry terms per output).  Edges are
-    // sorted by centre, so the centre's row of W1 is re-read only when it changes (scalar branch: the
-    // pair index is wave-uniform).
-    // the centre rows of the thread's first and last edge are requested up front, beside the first batch of neighbour
-    // rows: a tile rarely spans more than two centres, and a row fetched at the edge where the centre changes cost a
-    // full round trip with every other request of the batch drained behind it
-    const int rxA = __builtin_amdgcn_readfirstlane(sInf[eh].x), rxB = __builtin_amdgcn_readfirstlane(sInf[2 * (PW_T / 2 - 1) + eh].x);
-    const float wcA = a.w1[(size_t)rxA * D_H + f], wcB = a.w1[(size_t)rxB * D_H + f];
-    int rc_prev = -1; float wc = 0.f;
+    // ---- phase 1: fc1 + ReLU.  h1[e] = relu(tc[c] + tn[n] + geo[e] . Wg): the accumulators of the transposed product
+    // (lane = edge col of row tile 0 / 1, register r = feature 32 wave + 8 (r >> 2) + 4 half + (r & 3)) START from the two
+    // table rows, gathered as the lane's own 16-byte pieces; 4 MFMAs per row tile add the geometry term (K = 8); one
+    // integer max rectifies; the rows go to LDS as 16-byte stores in the [edge][feature] layout fc2 reads.  ~100 vector
+    // instructions per wave and tile; the per-edge loop it replaces (two row look-ups, 7 FMAs on broadcast LDS reads and a
+    // store PER EDGE AND THREAD: ~640) took 18 of a tile's 46 us waiting for issue slots between the other workgroup's MFMAs.
+    f32x16 acc0, acc1;
+    {
+      const unsigned fo = (unsigned)(32 * wave + 4 * half) * 4u;
+      const unsigned ocA = (unsigned)sIdx[col] * (D_H * 4u) + fo, onA = (unsigned)sIdx[PW_T + col] * (D_H * 4u) + fo;
+      const unsigned ocB = (unsigned)sIdx[32 + col] * (D_H * 4u) + fo, onB = (unsigned)sIdx[PW_T + 32 + col] * (D_H * 4u) + fo;
+      float4 tcA[4], tnA[4], tcB[4], tnB[4];
 #pragma unroll
-    for (int kb = 0; kb < PW_T / 2; kb += 16) {        // neighbour rows in two batches of 16 requests
-      float wn[16];
+      for (int g = 0; g < 4; ++g) { tcA[g] = ldg4_b(a.tc, ocA + 32u * g); tnA[g] = ldg4_b(a.tn, onA + 32u * g); }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int ry = __builtin_amdgcn_readfirstlane(sInf[2 * (kb + k) + eh].y);
-        wn[k] = a.w1[(size_t)ry * D_H + f];
+      for (int g = 0; g < 4; ++g) { tcB[g] = ldg4_b(a.tc, ocB + 32u * g); tnB[g] = ldg4_b(a.tn, onB + 32u * g); }
+      const f32x4 gA = *reinterpret_cast<const f32x4*>(sGeo + col * 8 + 4 * half);
+      const f32x4 gB = *reinterpret_cast<const f32x4*>(sGeo + (32 + col) * 8 + 4 * half);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        acc0[4 * g + 0] = tcA[g].x + tnA[g].x; acc0[4 * g + 1] = tcA[g].y + tnA[g].y; acc0[4 * g + 2] = tcA[g].z + tnA[g].z; acc0[4 * g + 3] = tcA[g].w + tnA[g].w;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[0], gA.x, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[1], gA.y, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gA.z, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gA.w, acc0, 0, 0, 0);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int el = 2 * (kb + k) + eh;
-        const int4 inf = sInf[el];
-        const int rx = __builtin_amdgcn_readfirstlane(inf.x);
-        if (rx != rc_prev) {
-          if (rx == rxA) wc = wcA; else if (rx == rxB) wc = wcB; else wc = a.w1[(size_t)rx * D_H + f];
-          rc_prev = rx;
-        }
-        float v = __int_as_float(inf.z) * wc;
-        v = fmaf(__int_as_float(inf.w), wn[k], v);
+      for (int g = 0; g < 4; ++g) {
+        acc1[4 * g + 0] = tcB[g].x + tnB[g].x; acc1[4 * g + 1] = tcB[g].y + tnB[g].y; acc1[4 * g + 2] = tcB[g].z + tnB[g].z; acc1[4 * g + 3] = tcB[g].w + tnB[g].w;
+      }
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[0], gB.x, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[1], gB.y, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gB.z, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gB.w, acc1, 0, 0, 0);
+      float* dA = sH + col * PW_LD + 32 * wave + 4 * half;
+      float* dB = dA + 32 * PW_LD;
 #pragma unroll
-        for (int g = 0; g < 7; ++g) v = fmaf(sGeo[el * 8 + g], wg[g], v);
-        sH[el * PW_LD + f] = fmaxf(v + bias1, 0.f);
-        __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting every edge's LDS reads (spills)
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(dA + 8 * g) = make_float4(relu_bits(acc0[4 * g]), relu_bits(acc0[4 * g + 1]), relu_bits(acc0[4 * g + 2]), relu_bits(acc0[4 * g + 3]));
+        *reinterpret_cast<float4*>(dB + 8 * g) = make_float4(relu_bits(acc1[4 * g]), relu_bits(acc1[4 * g + 1]), relu_bits(acc1[4 * g + 2]), relu_bits(acc1[4 * g + 3]));
       }
     }
     if (it == 10) GSTAMP(a, 2);
     __syncthreads();
     if (it == 10) GSTAMP(a, 3);
     // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
-    f32x16 acc0 = zero16(), acc1 = zero16();
-    mma_abt2_gB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)(32 * wave) * D_H, D_H, lane);
+    acc0 = zero16(); acc1 = zero16();
+    mma_abt2_fB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)wave * (32 * 256), lane);
     // requested before this tile's stores: the next tile's geometry and records, straight into the other staging buffer
     if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
     if (a.training) {      // fc1 activations: rows [8 wave, 8 wave + 8) of the tile (rows past E land in the slack)
@@ -252,11 +292,17 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     if (it == 10) GSTAMP(a, 4);
     __syncthreads();   // every wave has finished reading fc1 activations
     if (it == 10) GSTAMP(a, 5);
+    {
+      // one base register + constant offsets (hoisted out of the tile loop the sixteen row addresses were kept in registers
+      // of their own -- and spilled: their reloads sat behind the tile's global stores)
+      unsigned hb = (unsigned)((4 * half) * PW_LD + 32 * wave + col) * 4u;
+      asm volatile("" : "+v"(hb));
+      float* hp2 = reinterpret_cast<float*>(reinterpret_cast<char*>(sH) + hb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      sH[row * PW_LD + 32 * wave + col] = fmaxf(acc0[r] + bias2, 0.f);
-      sH[(32 + row) * PW_LD + 32 * wave + col] = fmaxf(acc1[r] + bias2, 0.f);
+      for (int r = 0; r < 16; ++r) {
+        hp2[crow(r, 0) * PW_LD] = fmaxf(acc0[r] + bias2, 0.f);
+        hp2[(32 + crow(r, 0)) * PW_LD] = fmaxf(acc1[r] + bias2, 0.f);
+      }
     }
     // fc3 operand of this wave (its wait sits two barriers behind the h1 stores, which are long acknowledged)
     f32x4 w3f[8];
@@ -289,8 +335,11 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
       if (it == 10) GSTAMP(a, 8);
       __syncthreads();   // every wave is done with the fc2 outputs: the partials may overwrite them
       if (it == 10) GSTAMP(a, 9);
+      unsigned rb = (unsigned)((kq * PW_T + mt * 32 + 4 * half) * D_E + col) * 4u;
+      asm volatile("" : "+v"(rb));                       // (one base register + constant offsets, as above)
+      float* rp2 = reinterpret_cast<float*>(reinterpret_cast<char*>(sR) + rb);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sR[(kq * PW_T + mt * 32 + crow(r, half)) * D_E + col] = acc[r];
+      for (int r = 0; r < 16; ++r) rp2[crow(r, 0) * D_E] = acc[r];
     }
     if (tid == 0) sClaim = claimed;
     __syncthreads();
@@ -311,7 +360,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
 #undef PW_STAGE_DMA
 }
 
-constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 2 * (PW_T * 8 + 4 * PW_T)) * sizeof(float);   // records = 4 ints per edge
+constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 2 * (PW_T * 12)) * sizeof(float);   // staging: 8 floats + 2 indices per edge (+ 2 spare)
 
 // ------------------------------------------------------------------------------------------
 // edge_fwd: one wave = one 32-edge tile at a time, 4 independent waves per workgroup sharing the
@@ -965,15 +1014,16 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.n_edge = E; g.edge_c = buf->edge_c; g.edge_n = buf->edge_n; g.edge_iou = buf->edge_iou;
     g.dets = (const float4*)in->dets; g.scores = in->det_scores; g.classes = in->det_classes;
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
-    g.geo = buf->geo; g.einfo = (int4*)buf->einfo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
+    g.geo = buf->geo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
+    g.w1 = params + L.pw1; g.b1 = params + L.pb1; g.tc = buf->pw_tc; g.tn = buf->pw_tn;
     g.row_ptr = buf->row_ptr; g.straddle = buf->scratch_i;
     const int pw_tiles = (E + PW_T - 1) / PW_T, pw_grid = min(pw_tiles, 512);
     g.pw_claim = buf->scratch_i + N; g.pw_claim0 = 2 * pw_grid;
     g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
     GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
     PwFwdArgs a;
-    a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.einfo = (const int4*)buf->einfo;
-    a.w1 = params + L.pw1; a.b1 = params + L.pb1;
+    a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.edge_c = buf->edge_c; a.edge_n = buf->edge_n;
+    a.tc = buf->pw_tc; a.tn = buf->pw_tn; a.w1 = params + L.pw1;
     a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
     a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
     a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training; a.claim = buf->scratch_i + N;

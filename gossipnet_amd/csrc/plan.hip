@@ -43,7 +43,8 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
   b.prediction = c.take<float>(Np);
   b.scratch_i = c.take<int32_t>(N + 1024);
   b.geo = c.take<float>(Ep * 8);
-  b.einfo = c.take<int32_t>(Ep * 4);
+  b.pw_tc = c.take<float>(Np * D_H);
+  b.pw_tn = c.take<float>(Np * D_H);
   if (training) {
     b.pw_h1 = c.take<float>(Ep * D_H);
     b.pw_h2 = c.take<float>(Ep * D_H);

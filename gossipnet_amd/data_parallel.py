@@ -27,6 +27,41 @@ def shard_images(images, rank, world, costs=None, per_rank=None):
     return [images[i] for i in sorted(mine)]
 
 
+class GradientExchange(object):
+    """The one collective of a data-parallel step, issued on a side stream behind the backward pass: the stream the
+    step's kernels run on only waits for it where the summed gradient is consumed (the optimizer update, or the next
+    step's backward which overwrites the buffer).  `timed=True` brackets every all-reduce with events on the side stream
+    (they see the collective itself, not the step); read_us() returns (mean microseconds per all-reduce, count) and resets.
+    Used by train_step(..., dist=...) and by bench.py --gpus N: the same code path."""
+
+    def __init__(self, dist, device, group=None, timed=False):
+        self.dist, self.group, self.device = dist, group, torch.device(device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.timed, self._events = timed, []
+
+    def __call__(self, flat_grads):
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)                       # behind reduce_partials
+        with torch.cuda.stream(self.side):
+            if self.timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
+            self.dist.all_reduce(flat_grads, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.timed:
+                e1.record(self.side)
+                self._events.append((e0, e1))
+        cur.wait_stream(self.side)
+        return flat_grads
+
+    def read_us(self):
+        if not self._events:
+            return None, 0
+        self._events[-1][1].synchronize()
+        us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in self._events]
+        self._events = []
+        return sum(us) / len(us), len(us)
+
+
 def allreduce_gradients(flat_grads, dist, group=None):
     """One collective per step on the flat gradient buffer (in place, sum)."""
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)

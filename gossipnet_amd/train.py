@@ -94,13 +94,17 @@ class Optimizer(object):
 def train_step(net, opt, batch, lr, dist=None):
     """One iteration of train.py:316-320: forward + loss (+ l2) + backward [+ all-reduce] + update.
     Under data parallelism (dist) the caller sets net.grad_scale = 1 / (images of the global step); the l2
-    regulariser is added once per step: every rank contributes 1 / world of it to the SUM all-reduce."""
+    regulariser is added once per step: every rank contributes 1 / world of it to the SUM all-reduce, which is the
+    one flat-buffer collective of data_parallel.GradientExchange (side stream; bench.py --gpus N uses the same object)."""
     if dist is not None:
         net.reg_scale = 1.0 / dist.get_world_size()
     net.run(batch)
     if dist is not None:
-        from .data_parallel import allreduce_gradients
-        allreduce_gradients(net.grads, dist)
+        ex = getattr(net, "_grad_exchange", None)
+        if ex is None or ex.dist is not dist:
+            from .data_parallel import GradientExchange
+            ex = net._grad_exchange = GradientExchange(dist, net.device)
+        ex(net.grads)
     with torch.cuda.device(net.device):
         opt.apply_gradients(lr)
     return net.loss

@@ -94,7 +94,8 @@ typedef struct gnet_buffers {
   int32_t* edge_t;    /* [n_edge] index of the reversed pair (n,c); the graph is symmetric */
   int32_t* edge_nz;   /* [n_edge+64] neighbour index for the rn gathers: n_det (a zero row) for self pairs and the tail */
   float* geo;         /* [n_edge,8] 7 geometry columns of _geometry_feats (+pad) */
-  int32_t* einfo;     /* [n_edge,4] fc1 rows of the centre/neighbour score columns + the two scores (bits) */
+  float* pw_tc;       /* [n_det,256] per detection: score x (pw_feats/fc1 row of its class's CENTRE score column) + bias -- the one-hot x score columns of _geometry_feats (network.py:413-419) contribute one row of fc1 per detection, not per edge */
+  float* pw_tn;       /* [n_det,256] per detection: score x (fc1 row of its class's NEIGHBOUR score column) */
   float* pw_h1;       /* [n_edge,256]  pw_feats/fc1 output (training)            */
   float* pw_h2;       /* [n_edge,256]  pw_feats/fc2 output (training)            */
   float* pw_feats;    /* [n_edge,32]   Gnet.pw_feats                             */

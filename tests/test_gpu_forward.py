@@ -36,7 +36,7 @@ def test_forward_parity(n, c, b, seed):
 def test_geometry_and_score_columns_vs_oracle(c):
     """SURVEY 8a F1 (`_geometry_feats`, network.py:411-454) on its own: the 7 geometry columns the pw-MLP reads
     (within a few ulp: logf / sqrtf / IEEE division on the device vs numpy) and the one-hot x score columns in the
-    factored form the kernels use -- (row, score) of the centre and of the neighbour -- bit-exact."""
+    factored form the kernels use -- per-detection tables of score x fc1 row for the centre and the neighbour role -- bit-exact."""
     net, orc = make_pair(c, 1)
     batch = make_image(300, c, seed=9)
     ref = orc.forward(batch)
@@ -47,12 +47,22 @@ def test_geometry_and_score_columns_vs_oracle(c):
     geo = net.debug_view("geo", E * 8).cpu().numpy().reshape(E, 8)
     assert rel_err(geo[:, :7], raw[:, 2 * cp:]) < 2e-6
     assert np.array_equal(geo[:, 0], raw[:, 2 * cp])                       # the IoU column is the graph's: bit-exact
-    info = net.debug_view("einfo", E * 4, dtype=torch.int32).cpu().numpy().reshape(E, 4)
-    dense = np.zeros((E, 2 * cp), np.float32)
-    dense[np.arange(E), info[:, 0]] = info[:, 2].view(np.float32)
-    dense[np.arange(E), info[:, 1]] += info[:, 3].view(np.float32)
-    assert (info[:, 0] < cp).all() and (info[:, 1] >= cp).all()
-    assert np.array_equal(dense, raw[:, :2 * cp])
+    # the score columns enter fc1 as one weight row per detection: tc[i] = score_i W1[class_i - 1] + b1 (centre role),
+    # tn[i] = score_i W1[C + class_i - 1] (neighbour role) -- plain fp32 multiply / add, bit-exact against numpy
+    n = batch["dets"].shape[0]
+    tc = net.debug_view("pw_tc", n * 256).cpu().numpy().reshape(n, 256)
+    tn = net.debug_view("pw_tn", n * 256).cpu().numpy().reshape(n, 256)
+    w1 = net.variables["gnet/pw_feats/fc1/weights"].cpu().numpy()
+    b1 = net.variables["gnet/pw_feats/fc1/biases"].cpu().numpy()
+    sc = batch["det_scores"].astype(np.float32)[:, None]
+    cls = (batch["det_classes"] - 1) if c > 1 else np.zeros(n, np.int64)
+    assert np.array_equal(tc, sc * w1[cls] + b1[None, :])
+    assert np.array_equal(tn, sc * w1[cp + cls])
+    # and the dense one-hot x score block of the oracle's raw features times the same rows gives the same sums
+    pairs = ref["neighbor_pair_idxs"]
+    want = raw[:, :2 * cp].astype(np.float64) @ w1[:2 * cp].astype(np.float64) + b1
+    got = tc[pairs[:, 0]].astype(np.float64) + tn[pairs[:, 1]]
+    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
 
 
 def test_forward_inference_mode_matches_training_mode():

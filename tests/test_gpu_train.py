@@ -103,8 +103,20 @@ if use_dist: dist.destroy_process_group()
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
 
 
+def test_two_ranks_rccl_two_gpus_equal_the_single_process_step(tmp_path):
+    """The same comparison as the next test, over RCCL: two ranks on two GPUs under the `nccl` backend (one process per
+    GPU, device = rank).  Needs two GPUs: on the one-GPU boxes of this pool it is SKIPPED and says so."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs for a 2-rank RCCL group; this box has %d" % torch.cuda.device_count())
+    _two_ranks_equal_single_process(tmp_path, 5, "nccl")
+
+
 @pytest.mark.parametrize("n_images", [5, 1])
 def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, n_images):
+    _two_ranks_equal_single_process(tmp_path, n_images, "gloo")
+
+
+def _two_ranks_equal_single_process(tmp_path, n_images, backend):
     """N > 1 on the PRODUCT path before an 8-GPU node ever runs it: two processes share cuda:0 under a `gloo` group
     (it accepts device tensors); each runs train_step(net, opt, shard, lr, dist=dist) on its LPT-by-edge-count shard of
     a 5-image global step -- HIP gradients into the flat buffer, ONE all-reduce, grad_scale = 1 / images of the step,
@@ -121,22 +133,26 @@ from gossipnet_amd.network import Gnet
 from gossipnet_amd.synthetic import make_image
 from gossipnet_amd.train import Optimizer, train_step
 from gossipnet_amd.data_parallel import broadcast_parameters, shard_images
-out, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+out, rank, world, port, backend = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
 dist = None
-torch.cuda.set_device(0)
+dev = rank if backend == "nccl" else 0
+torch.cuda.set_device(dev)
 if world > 1:
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 reset_cfg(); cfg.gnet.num_blocks = 3
 cfg.train.optimizer = "sgd"                     # momentum update: linear in the gradient (Adam's g / sqrt(v) turns a
                                                 # 1e-7 reduction-order difference of a cancelling sum into a visible step)
 cfg.random_seed = 42 + rank                     # replicas start DIFFERENT: the broadcast must make them equal
-net = Gnet(80, weight_reg=0.0005)
+net = Gnet(80, weight_reg=0.0005, device="cuda:%%d" %% dev)
 if world > 1: broadcast_parameters(net.params, dist, src=0)
 opt = Optimizer(net)
 imgs = [make_image(n, 80, seed=s) for n, s in ((150, 0), (90, 1), (200, 2), (60, 3), (120, 4))][:%d]
-costs = [float(Gnet.count_edges(im["dets"], "cuda:0")) for im in imgs]
+costs = [float(Gnet.count_edges(im["dets"], "cuda:%%d" %% dev)) for im in imgs]
 mine = shard_images(imgs, rank, world, costs=costs)
 assert 1 <= len(mine) < len(imgs) or world == 1 or len(imgs) == 1
 net.grad_scale = 1.0 / len(imgs)
@@ -149,9 +165,9 @@ if world > 1:
 """ % (root, n_images)
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = str(s_.getsockname()[1]); s_.close()
     single = str(tmp_path / "single.npy")
-    subprocess.run([sys.executable, "-c", script, single, "0", "1", port], check=True, cwd=root, timeout=600)
+    subprocess.run([sys.executable, "-c", script, single, "0", "1", port, backend], check=True, cwd=root, timeout=600)
     files = [str(tmp_path / ("r%d.npy" % r)) for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, "-c", script, files[r], str(r), "2", port], cwd=root) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", script, files[r], str(r), "2", port, backend], cwd=root) for r in range(2)]
     for p_ in procs:
         assert p_.wait(timeout=600) == 0
     want = np.load(single)
@@ -181,6 +197,9 @@ def test_bench_two_ranks_functional(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3 and line["unit"] == "detections/sec"
     assert line["config"]["parallelism"] == "dp2" and line["config"]["image_assignment"].startswith("longest-processing-time")
     assert len(line["per_rank"]) == 2 and all(r["dets"] == 1000 and r["edges"] > 0 and r["ms_per_step"] > 0 for r in line["per_rank"])
+    d = line["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["cuda_device_count"] >= 1 and d["distinct_devices"] == 1
+    assert d["allreduce_samples"] == 3 and d["allreduce_us_rank0"] > 0 and all(r["device_index"] == 0 for r in line["per_rank"])
     assert sum(r["edges"] for r in line["per_rank"]) == line["config"]["edges_per_step_all_gpus"]
     assert abs(line["value"] - 2000 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-3 * line["value"]
     assert line["cpu_baseline"] is None and line["roofline"] is None          # rank 0 at N = 1 only / kernel timing off

@@ -4,7 +4,7 @@
 #   bench.json                default bench.py line (with other_configs and cpu_baseline)
 #   kernel_stats.csv          rocprofv3 --kernel-trace --stats of the same command
 #   pmc_fetch.txt / pmc_write.txt / pmc_sq.txt   separate --pmc passes, per-kernel per-launch averages
-#   traffic.json              HBM bytes + MFMA-busy fraction per launch and kernel (bench.py reads profiles/r03_traffic.json)
+#   traffic.json              HBM bytes + MFMA-busy fraction per launch and kernel (bench.py reads profiles/r04_traffic.json)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=gpurun_out/prof; mkdir -p $R
 python bench.py > $R/bench.log 2>&1; tail -1 $R/bench.log > $R/bench.json
