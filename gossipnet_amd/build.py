@@ -9,6 +9,8 @@ LIB = os.path.join(HERE, "libgossipnet_hip.so")
 SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "fc.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
+if os.environ.get("GNET_EXTRA_FLAGS"):    # measurement builds only (probe variants of a kernel: tools/); never shipped
+    FLAGS = FLAGS + os.environ["GNET_EXTRA_FLAGS"].split()
 if os.environ.get("GNET_TRACE"):          # measurement build with per-workgroup time stamps (tools/wg_trace.py); never shipped
     FLAGS = FLAGS + ["-DGNET_TRACE"]
 
@@ -79,7 +81,9 @@ def _build_locked(force, verbose, objdir):
         failed |= p.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
-    if procs or force or not os.path.exists(LIB):
+    # (reached only when the library's recorded hash differs from this source / flag set: always link -- the objects of
+    # this flag set may all be current while the library was linked from another set's)
+    if True:
         tmp = LIB + ".tmp.%d" % os.getpid()
         subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
         os.replace(tmp, LIB)                 # a process that has the old library mapped keeps its inode
