@@ -44,10 +44,10 @@ KINK = 2e-6       # a mask may differ from the oracle's own only where the oracl
 
 
 # kink-free seeds (of 6) measured on MI355X per case, minus one (a change of a kernel's summation order may move a unit
-# across its kink); the count is deterministic for fixed kernels.  Filled from the run recorded in profiles/r03_kinks.txt.
+# across its kink); the count is deterministic for fixed kernels.  Filled from the run recorded in profiles/r04_kinks.txt.
 KINK_FREE_MIN = {(6, 1, 1, 0.01): 5, (6, 1, 1, 0.5): 5, (20, 1, 1, 0.01): 5, (20, 1, 1, 0.5): 5, (33, 1, 2, 0.01): 4, (33, 1, 2, 0.5): 5,
-                 (64, 1, 2, 0.01): 5, (64, 1, 2, 0.5): 4, (64, 80, 1, 0.01): 3, (64, 80, 1, 0.5): 4, (64, 80, 2, 0.01): 1,
-                 (64, 80, 2, 0.5): 3, (200, 1, 1, 0.01): 4, (200, 1, 1, 0.5): 4, (150, 80, 3, 0.01): 4, (150, 80, 3, 0.5): 5}
+                 (64, 1, 2, 0.01): 5, (64, 1, 2, 0.5): 4, (64, 80, 1, 0.01): 3, (64, 80, 1, 0.5): 5, (64, 80, 2, 0.01): 2,
+                 (64, 80, 2, 0.5): 5, (200, 1, 1, 0.01): 2, (200, 1, 1, 0.5): 4, (150, 80, 3, 0.01): 3, (150, 80, 3, 0.5): 5}
 
 
 def kink_report(net, ref, image=None):
@@ -89,7 +89,7 @@ def test_backward_parity_small(n, c, b, bias):
         assert max(pinned.values()) <= PINNED, (seed, max(pinned.items(), key=lambda kv: kv[1]))
     print("kink-free seeds: %d / 6, worst distance from a kink at a differing mask entry %.2e  (n=%d c=%d b=%d bias=%g)"
           % (n_free, worst_all, n, c, b, bias))
-    assert n_free >= KINK_FREE_MIN.get((n, c, b, bias), 0)
+    assert n_free >= KINK_FREE_MIN.get((n, c, b, bias), 0), "kink-free seeds %d" % n_free
 
 
 def first_winner_only(sel, c_idx):
