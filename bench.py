@@ -460,6 +460,32 @@ def main():
                    "worst": worst,
                    "whole_step_gb_per_s": round((8712.0 * E + 45156.0 * N_local) / step_s / 1e9, 1)}
 
+    side = None
+    if not args.no_kernel_timing and E > 0:
+        # The zeroing half of the backward preparation (hipMemsetAsync of d_pw = E x 128 B and of the winner maps: rocclr fill
+        # kernels, not in the per-class table) runs on the Gnet's side stream beside pw_fwd.  Timed here ALONE on the idle
+        # device = its unobstructed cost; in the step its workgroups wait for slots pw_fwd's persistent workgroups free (the
+        # fills then last as long as pw_fwd, rocprof shows ~2 ms of them per step) without costing the main stream anything
+        # measurable: issued after the forward pass instead (A/B on one box) the step is the same
+        # 11.48 ms, pw_fwd 2.11 vs 2.12 ms.
+        import ctypes as C
+        from gossipnet_amd import _lib as L_
+        s_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            L_.check(net._lib.gnet_backward_prepare(C.byref(net._cfg), C.byref(net._shape), C.byref(net._inputs), C.c_void_p(net.params.data_ptr()),
+                                                    C.byref(net._buf), 1, s_), "gnet_backward_prepare")
+        e1.record(); e1.synchronize()
+        fill_ms = e0.elapsed_time(e1) / 5
+        fill_bytes = E * 32 * 4 + (args.blocks + 1) * ((E + 63) // 64 + 256) * 8
+        side = {"zeroing_ms_alone": round(fill_ms, 4), "zeroing_bytes": fill_bytes, "gb_per_s_alone": round(fill_bytes / fill_ms / 1e6, 1),
+                "note": "hipMemsetAsync of d_pw and the winner maps on the side stream beside pw_fwd; alone on the device it takes this "
+                        "long; inside the step it overlaps pw_fwd (same step time whether issued there or after the forward pass)",
+                "winner_lists_ms_per_step": round(table.get("winner_lists", 0.0), 4),
+                "winner_lists_note": "side stream, beside matching / loss / head backward; ~0.085 ms of it exposed in front of the first edge_bwd_w"}
+
     if rank == 0:
         out = {
             "metric": "detections/sec Gnet fwd+bwd, N=%d/%d-class" % (args.dets, args.classes),
@@ -483,6 +509,7 @@ def main():
             "hbm": hbm,
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(table.items(), key=lambda kv: -kv[1])},
             "kernel_launches_per_step": counts,
+            "side_stream": side,
         }
         if world == 1 and not args.no_other_configs:
             del batch
