@@ -139,7 +139,7 @@ def cpu_baseline(make, num_classes, num_blocks, budget_s):
         orc.forward_backward(make(1, 300))
         spent += time.perf_counter() - t0
         for nt in (min(16, all_threads), 1, all_threads):        # the usually fastest first: it always gets its two runs
-            if any(r["threads"] == nt for r in runs):
+            if any(r["threads"] == nt for r in runs) or (runs and spent > budget_s):
                 continue
             torch.set_num_threads(nt)
             reps = []
@@ -402,8 +402,9 @@ def main():
                 roofline = {"bound": "mfma", "kernel": cls, "achieved": round(ex_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ex_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                             "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
-                            "launches_note": "every %s launch of the class inside the timed region is bracketed by HIP events on the launch stream%s"
-                                             % ("5th" if dom_stride == 5 else "", " (5 is coprime with the 16 launches per step: all blocks sampled equally)" if dom_stride == 5 else ""),
+                            "launches_note": ("every 5th launch of the class inside the timed region is bracketed by HIP events on the launch stream "
+                                              "(5 is coprime with the 16 launches per step: all blocks sampled equally)") if dom_stride == 5 else
+                                             "every launch of the class inside the timed region is bracketed by HIP events on the launch stream",
                             "within_3pct": near,
                             "flops_per_launch": ex if ex else fl,
                             "flops": "MFMA FLOPs issued per launch = FLOPs of the algorithm as formulated here (DESIGN.md 4)",

@@ -26,7 +26,9 @@ for k in fetch:
                            "active_inst_any": q.get("ACTIVE_INST_ANY"), "wave_cycles": q.get("WAVE_CYCLES"), "gui_active_cycles": gui,
                            "mfma_busy": round(busy / (N_SIMD * gui), 4) if (busy and gui) else (0.0 if gui else None),
                            "effective_clock_ghz": round(gui / (q["avg_us"] * 1e3), 3) if gui else None,
-                           "valu_per_mfma": round(va / mf, 2) if mf else None})
+                           # SQ_INSTS_VALU counts the MFMAs too (pw_fwd: 541 per wave and tile against 296 MFMAs + ~245 other
+                           # vector instructions in the ISA): the ratio is of the OTHER vector instructions
+                           "valu_per_mfma": round((va - mf) / mf, 2) if mf else None})
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* GRBM_GUI_ACTIVE (three separate passes) -- python bench.py --steps 2 "
                   "--warmup 1 --cpu-seconds 0 --no-kernel-timing --no-other-configs",
        "workload": [2000, 8, 80, 16, "dense"],
@@ -34,7 +36,8 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* GRBM_GUI_ACTIV
        "units": "per launch; hbm_bytes = (2 x FETCH_SIZE[KB] + WRITE_SIZE[KB]) x 1024 -- MI355X_MICROARCH.md (HBM): on gfx950 "
                 "FETCH_SIZE reports half of the bytes of wide coalesced reads (double it); other access widths and WRITE_SIZE "
                 "are uncalibrated; Infinity-Cache hits are counted, not excluded.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES (64 per "
-                "v_mfma_f32_32x32x2_f32, summed over the SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE of the launch)",
+                "v_mfma_f32_32x32x2_f32, summed over the SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE of the launch); valu_per_mfma = "
+                "(SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA (INSTS_VALU includes the MFMAs: rounds 1-3 printed the ratio one too high)",
        "kernels": kernels}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps({k: [round(v["hbm_bytes"] / 1e6, 1), v.get("mfma_busy")] for k, v in kernels.items()}))
