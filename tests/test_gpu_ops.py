@@ -261,12 +261,13 @@ def test_config4_dense_10000_forward_backward_runs():
 CONFIG4_HOST_GB = {5000: 48, 10000: 190}
 
 
-@pytest.mark.parametrize("n,b", [(10000, 2), (5000, 16), (10000, 16)])
+@pytest.mark.parametrize("n,b", [(5000, 16), (10000, 16)])
 def test_config4_dense_backward_against_the_oracle(n, b):
-    """BASELINE config 4 through loss and backward on one synthetic dense image, C = 80, ground truth present:
-    N = 10 000 with B = 2 (E ~ 3.4 M), N = 5 000 at the full depth B = 16 (E ~ 0.9 M), N = 10 000 at the full depth
-    (reference network.py:344-409: 16 stacked blocks).  The size is a test parameter: a case the host cannot hold is SKIPPED
-    with the reason in the report, never silently shrunk.
+    """BASELINE config 4 through loss and backward on one synthetic dense image, C = 80, ground truth present, at the full
+    depth B = 16 (reference network.py:344-409: 16 stacked blocks): N = 10 000 (E ~ 3.4 M) where the host can hold the
+    oracle's autograd (~190 GB; the GPU boxes of this pool have 3 TB), N = 5 000 (E ~ 1.0 M) where it cannot.  The size is a
+    test parameter and exactly one of the two cases runs: the other one is SKIPPED with the reason in the report -- never a
+    silently shrunk input.
     Neighbour indices, det_anno_iou, matching assignments and labels bit-exact; logits and losses <= 1e-5; the device's
     ReLU masks / SegmentMax winner sets equal the oracle's own except within 2e-6 of a kink, the winner records of
     the first, a middle and the last block exact against the kernel's own pre-activations; every parameter gradient
@@ -274,10 +275,12 @@ def test_config4_dense_backward_against_the_oracle(n, b):
     import psutil
     from oracle.pins import gpu_pins, grad_errors, mask_disagreements, winner_records_exact
     from tests.util import make_pair, make_image, rel_err
-    need = CONFIG4_HOST_GB[n] * (b / 16.0 if b < 16 else 1.0) + 16
+    need = CONFIG4_HOST_GB[n] + 16
     free = psutil.virtual_memory().available / 2 ** 30
     if free < need:
         pytest.skip("config 4 at N = %d, B = %d needs ~%d GB of host memory for the oracle's autograd, %.0f GB free" % (n, b, need, free))
+    if n < 10000 and free >= CONFIG4_HOST_GB[10000] + 16:
+        pytest.skip("subsumed by the N = 10 000 case, which this host can hold (%.0f GB free)" % free)
     c = 80
     net, orc = make_pair(c, b)
     net.keep_edge_activations = True
