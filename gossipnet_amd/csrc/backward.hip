@@ -720,7 +720,8 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       for (int w8 = 1; w8 < 8; ++w8) p += sG3[w8 * 32 + tid];
       gb3 += p;
     }
-    __syncthreads();      // every wave is done with the fc2 outputs (and with d3)
+    // (no barrier here: a wave reads -- mask above, A operand of d W3 -- and now overwrites only ITS OWN 32 columns of the fc2
+    // tile, and a wave's LDS operations execute in order; d3 and the per-wave sums are rewritten behind the next barrier)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sH2[crow(r, half) * LD256 + 32 * wave + col] = d2[r];
     __syncthreads();
