@@ -570,6 +570,7 @@ struct PwBwdArgs {
   float* d_h1;
   float* arena; long long stride;
   long long o_w2, o_b2, o_w3, o_b3;
+  GNET_TRACE_FIELD
 };
 
 // Asynchronous global -> LDS copy of a [32][256] fp32 tile (one 1 KB row per wave-instruction: the LDS
@@ -604,9 +605,13 @@ __device__ __forceinline__ void dma_rows32(float* sdst, const float* __restrict_
 // back.  (Fetching an index right in front of its copy made the in-order memory counter wait for the copies issued before
 // it -- a 1 KB HBM round trip each -- before the next one could start.)
 __device__ __forceinline__ void dma_rows32_ids(float* sdst, const float* __restrict__ g, const int (&er)[4], int wave, int lane) {
+  // the four row indices are wave-uniform: as scalars, the source address is a scalar base + the lane's constant 16-byte offset
+  // (no per-lane 64-bit address arithmetic; 10 registers less)
+  const unsigned lane_b = 16u * (unsigned)lane;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float* src = g + (size_t)er[q] * D_H + 4 * lane;
+    const int rq = __builtin_amdgcn_readfirstlane(er[q]);
+    const char* src = reinterpret_cast<const char*>(g + (size_t)rq * D_H) + lane_b;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sdst + (wave * 4 + q) * LD256), 16, 0, 0);
   }
@@ -627,6 +632,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   __shared__ float sG3[8 * 32];             // per-wave column sums of the d3 tile (d b3)
   const int n_rows = *a.n_rows;
   const int ntiles = (n_rows + 31) / 32;
+  const int G = (int)gridDim.x;
   // Everything a tile reads from HBM is requested one tile ahead and BEFORE the tile's 16 d_h1 stores: the
   // h1/h2 tiles by DMA into the other LDS buffer, the d_pw / pw values of the d3 tile into registers.  The
   // wait at the top of a tile is then vmcnt(16): "everything but the 16 youngest operations", i.e. it never
@@ -646,29 +652,35 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   do {                                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dr[q_] = PB_ROW(tile_, wave * 4 + q_);             \
     ra = PB_ROW(tile_, tid >> 5); rb = PB_ROW(tile_, (tid >> 5) + 16);                                  \
-    rs = (tile_) * 32 + (tid & 31) < n_rows ? a.rows[(tile_) * 32 + (tid & 31)] : a.n_edge;   /* slack row */ \
+    /* an UNCONDITIONAL load (clamped index; the slack row is selected where the value is used): a load under an exec mask whose    \
+       result merges with the other side's value made the compiler wait for it -- vmcnt(0): for the tile copies and every load just \
+       issued in front of it, a full HBM round trip (2.3 us of every 21.9 us tile, tools/wg_trace.py) -- right here */             \
+    rs = PB_ROW(tile_, tid & 31);                                                                       \
   } while (0)
-#define PB_PREFETCH_D3()                                                                                \
+#define PB_PREFETCH_D3(tile_)    /* tile_ = the tile whose row ids are in ra / rb / rs */                \
   do {                                                                                                  \
-    pq0 = a.pw[(size_t)ra * D_E + (tid & 31)]; dq0 = a.d_pw[(size_t)ra * D_E + (tid & 31)];             \
-    pq1 = a.pw[(size_t)rb * D_E + (tid & 31)]; dq1 = a.d_pw[(size_t)rb * D_E + (tid & 31)];             \
-    rs_tile = rs;                                                                                       \
+    const unsigned oa_ = (unsigned)ra * (D_E * 4u) + 4u * (tid & 31), ob_ = (unsigned)rb * (D_E * 4u) + 4u * (tid & 31);   /* [E,32] fp32: 32-bit byte offsets up to the edge limit */ \
+    pq0 = ldg_b(a.pw, oa_); dq0 = ldg_b(a.d_pw, oa_);                                                   \
+    pq1 = ldg_b(a.pw, ob_); dq1 = ldg_b(a.d_pw, ob_);                                                   \
+    rs_tile = (tile_) * 32 + (tid & 31) < n_rows ? rs : a.n_edge;   /* rows past the list: the slack row */ \
   } while (0)
   if ((int)blockIdx.x < ntiles) {
     PB_LOAD_ROWIDS((int)blockIdx.x);
     dma_rows32(smem, a.h1, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
     dma_rows32(smem + 32 * LD256, a.h2, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
-    PB_PREFETCH_D3();
-    if ((int)(blockIdx.x + gridDim.x) < ntiles) PB_LOAD_ROWIDS((int)(blockIdx.x + gridDim.x));
+    PB_PREFETCH_D3((int)blockIdx.x);
+    if (((int)blockIdx.x + G) < ntiles) PB_LOAD_ROWIDS(((int)blockIdx.x + G));
   }
   drain_vmem_before_loop();
   int it = 0;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+  for (int t = blockIdx.x; t < ntiles; t += G, ++it) {
     const int e0 = t * 32;                 // first list position of the tile
     float* sH1 = smem + (it & 1) * (2 * 32 * LD256);
     float* sH2 = sH1 + 32 * LD256;        // fc2 output, then d(fc2 pre-activation)
     float* nH1 = smem + ((it & 1) ^ 1) * (2 * 32 * LD256);
+    if (it == 5) GSTAMP(a, 0);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this tile's DMA and d3 sources (issued one tile ago) have landed
+    if (it == 5) GSTAMP(a, 1);
     if (tid < 32) sRows[it & 1][tid] = rs_tile;
     {
       const int row0 = tid >> 5, j = tid & 31;            // rows past the list: zero gradient
@@ -680,7 +692,9 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       unsigned lo, hi; half_bcast(__float_as_uint(va + vb), lo, hi);
       if (lane < 32) sG3[wave * 32 + lane] = __uint_as_float(lo) + __uint_as_float(hi);
     }
+    if (it == 5) GSTAMP(a, 2);
     __syncthreads();
+    if (it == 5) GSTAMP(a, 3);
     // d(fc2 pre) tile w = (d3 . W3^T) * (h2 > 0)
     f32x16 d2 = zero16();
     {
@@ -694,6 +708,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
         d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w3f[k].w, d2, 0, 0, 0);
       }
     }
+    if (it == 5) GSTAMP(a, 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) d2[r] = sH2[crow(r, half) * LD256 + 32 * wave + col] > 0.f ? d2[r] : 0.f;
     // d b2[32 w + col] += sum over the tile's rows of d2: the lane's sixteen rows, then the other half-wave's (a 32-read LDS
@@ -705,6 +720,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       unsigned lo, hi; half_bcast(__float_as_uint(p), lo, hi);
       gb2 += __uint_as_float(lo) + __uint_as_float(hi);
     }
+    if (it == 5) GSTAMP(a, 5);
     // d W3 += h2^T . d3 (rows [32w, 32w+32) of W3)
     {
       const int r = lane & 31, h = lane >> 5;
@@ -722,23 +738,33 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     }
     // (no barrier here: a wave reads -- mask above, A operand of d W3 -- and now overwrites only ITS OWN 32 columns of the fc2
     // tile, and a wave's LDS operations execute in order; d3 and the per-wave sums are rewritten behind the next barrier)
+    if (it == 5) GSTAMP(a, 6);
 #pragma unroll
     for (int r = 0; r < 16; ++r) sH2[crow(r, half) * LD256 + 32 * wave + col] = d2[r];
+    if (it == 5) GSTAMP(a, 7);
     __syncthreads();
+    if (it == 5) GSTAMP(a, 8);
     // next tile's h1/h2 -> the other buffer (last read during the previous tile).  Issued here: the
     // d W2 phase below touches only LDS, so the in-order vmcnt never waits on this copy.
-    if (t + (int)gridDim.x < ntiles) {
+    if (t + G < ntiles) {
       dma_rows32_ids(nH1, a.h1, dr, wave, lane);
       dma_rows32_ids(nH1 + 32 * LD256, a.h2, dr, wave, lane);
-      PB_PREFETCH_D3();
-      if (t + 2 * (int)gridDim.x < ntiles) PB_LOAD_ROWIDS(t + 2 * (int)gridDim.x);
+      PB_PREFETCH_D3(t + G);
+      // (the row ids of the tile after the next one: UNCONDITIONAL -- past the list PB_ROW re-reads its last entry -- and pinned
+      // behind the uses of the old ids: a conditional or re-ordered load of a loop-carried value goes through a temporary
+      // register, and the copy out of it made the compiler wait for every request just issued: vmcnt(0), 2.3 of a tile's 21.9 us)
+      __builtin_amdgcn_sched_barrier(0);
+      PB_LOAD_ROWIDS(t + 2 * G);
     }
+    if (it == 5) GSTAMP(a, 9);
     // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
     mma_xty_pipelined<8>(aW2, sH1 + 32 * wave, LD256, sH2, LD256, lane);
+    if (it == 5) GSTAMP(a, 10);
     // d(fc1 pre) tile w = (d2 . W2^T) * (h1 > 0)
     {
       f32x16 acc = zero16();
       mma_abt_gB<D_H, 6>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
+      if (it == 5) GSTAMP(a, 11);
       // d_h1 rows go back to their edge positions (rows past the list: the slack row E); exactly 16 stores
       const int* rp = sRows[it & 1] + 4 * half;
       const float* hp = sH1 + (4 * half) * LD256 + 32 * wave + col;
@@ -746,7 +772,9 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       for (int r = 0; r < 16; ++r)
         a.d_h1[(size_t)rp[crow(r, 0)] * D_H + 32 * wave + col] = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
     }
+    if (it == 5) GSTAMP(a, 12);
   }
+  GSTAMP(a, 15);
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
 #pragma unroll
   for (int j = 0; j < 8; ++j) store_acc(ar + a.o_w2 + (size_t)(32 * wave) * D_H + 32 * j, D_H, aW2[0][j], lane);
@@ -1106,6 +1134,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     p.n_edge = E; p.pw = buf->pw_feats; p.d_pw = buf->d_pw; p.h1 = buf->pw_h1; p.h2 = buf->pw_h2;
     p.w2 = params + L.pw2; p.w3 = params + L.pw3; p.d_h1 = buf->d_h1;
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
+    GNET_TRACE_SET(p, "PW_BWD", true);
     GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<<<g_pw, 512, kPwBwdSmem, s>>>(p));
     PwW1Args w;
     w.n_det = N; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-KERNELS = ["PW_FWD", "EDGE_FWD", "NODE_FWD", "EDGE_BWD", "GATHER", "NODE_BWD"]
+KERNELS = ["PW_FWD", "EDGE_FWD", "NODE_FWD", "EDGE_BWD", "GATHER", "NODE_BWD", "PW_BWD"]
 MAXWG = 8192
 bufs = {}
 for k in KERNELS:
