@@ -677,6 +677,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     // product below (k pairing of mma_abt), and the rows go to LDS as 16-byte pieces (over h1) for the d Wp product and
     // the row store
     f32x16 g1a = zero16(), g1b = zero16();
+    __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note at the atomics below)
     {
       float* hp = sH + col * LD64 + 4 * half;
       float4 hm[8];
@@ -742,6 +743,10 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1b[4 * g + 3], bp[(32 + 8 * g + 3) * LD32], acc, 0, 0, 0);
         if ((g & 1) != 0) __builtin_amdgcn_sched_barrier(0);
       }
+      // Everything outside the g1 / d P MFMA section runs at a raised wave priority: a wave in its bookkeeping (atomics, row
+      // stores, the next tile's slot logic and gathers) gets its issue slots ahead of the other workgroup's MFMA stream and is
+      // back in its own MFMA section sooner (-1 %; raising the MFMA section instead: +-0).
+      __builtin_amdgcn_s_setprio(1);
       // rows past the list (last tile) go to the slack row E of d_pw: unconditional, no divergent branches
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -277,9 +277,15 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     if (it == 10) GSTAMP(a, 2);
     __syncthreads();
     if (it == 10) GSTAMP(a, 3);
-    // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles
+    // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles.  At a raised wave priority:
+    // the CU's other workgroup is, more often than not, in one of its light phases (fc1, the h2 / partial-sum round trips, the
+    // stores), and its vector instructions no longer cut into this MFMA stream (the fp32 MFMA and the vector ALU share lanes):
+    // 2.13 -> 2.06 ms.  (A per-CU token that keeps the two workgroups' fc2 phases apart altogether -- CU id from HW_ID /
+    // XCC_ID, compare-and-swap on a global word -- gives the same 3 %, and 4 % together with this; not worth its machinery.)
     acc0 = zero16(); acc1 = zero16();
+    __builtin_amdgcn_s_setprio(2);
     mma_abt2_fB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)wave * (32 * 256), lane);
+    __builtin_amdgcn_s_setprio(0);
     // requested before this tile's stores: the next tile's geometry and records, straight into the other staging buffer
     if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
     if (a.training) {      // fc1 activations: rows [8 wave, 8 wave + 8) of the tile (rows past E land in the slack)
@@ -316,6 +322,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     // ---- phase 3: fc3 (256 -> 32): wave = (row tile, K quarter), partial sums through LDS
     {
       f32x16 acc = zero16();
+
       const float* ap = sH + (mt * 32 + col) * PW_LD + 64 * kq + 4 * half;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -536,6 +543,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         h1b[4 * g + 0] = cb.x + rnv[4 + g].x; h1b[4 * g + 1] = cb.y + rnv[4 + g].y; h1b[4 * g + 2] = cb.z + rnv[4 + g].z; h1b[4 * g + 3] = cb.w + rnv[4 + g].w;
       }
     }
+    __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note behind layer 2)
     {
       const float* b0 = sWp + col * E_LD1 + 4 * half;
       const float* b1 = b0 + 32 * E_LD1;
@@ -611,6 +619,10 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 3], bv1.w, h2b, 0, 0, 0);
       }
     }
+    // The segment bookkeeping (and the top of the next tile, up to its first MFMA) runs at a raised wave priority: the three
+    // waves of a SIMD are at unrelated points of their tiles, and a wave in its vector section that gets its issue slots
+    // ahead of the others' MFMA streams is back in its own MFMA section sooner (-1 %; raising the MFMA section instead: +-0).
+    __builtin_amdgcn_s_setprio(1);
     // pre-activations; relu is monotone, so max(relu(v)) = relu(max(v)): rectify once per segment.  The
     // tie count is the number of rows equal to the maximum (when the maximum is <= 0 every gradient through
     // it is zero and only count >= 1 matters).
