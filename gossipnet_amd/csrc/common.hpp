@@ -395,9 +395,12 @@ __device__ __forceinline__ void mma_abt2_gB(f32x16& acc0, f32x16& acc1, const fl
   }
 }
 
-// The same pipeline with the B operand stored FRAGMENT-MAJOR (forward.hip pack_transpose): Bf + (s * 64 + lane) * 4 is the
-// lane's 16-byte fragment of k-step s -- one contiguous 1 KB block per load instruction.
-#define GNET_MMA16(acc0, acc1, p0, p1, q0, q1, bP, bQ)                                  \
+// Two row tiles against a B operand stored FRAGMENT-MAJOR (forward.hip pack_transpose): Bf + (s * 64 + lane) * 4 is the lane's
+// 16-byte fragment of k-step group s -- one contiguous 1 KB block per load instruction.
+// The two operand streams are pipelined at DIFFERENT depths, in units of one fragment (8 MFMAs: four k-steps
+// of both row tiles): the B fragments come from L2 (~1 us under load) and are requested three units ahead, the A rows come from
+// LDS and are requested one unit ahead.  32 operand registers instead of 48, the same k order (bit-identical sums).
+#define GNET_MMA8(acc0, acc1, p0, p1, bP)                                               \
   do {                                                                                 \
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.x, bP.x, acc0, 0, 0, 0);            \
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.x, bP.x, acc1, 0, 0, 0);            \
@@ -407,46 +410,37 @@ __device__ __forceinline__ void mma_abt2_gB(f32x16& acc0, f32x16& acc1, const fl
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.z, bP.z, acc1, 0, 0, 0);            \
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.w, bP.w, acc0, 0, 0, 0);            \
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.w, bP.w, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.x, bQ.x, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.x, bQ.x, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.y, bQ.y, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.y, bQ.y, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.z, bQ.z, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, bQ.z, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.w, bQ.w, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, bQ.w, acc1, 0, 0, 0);            \
   } while (0)
-
-// Two row tiles against a fragment-major B: a rolled pipeline over QUADS of k-steps with two register sets in ping-pong
-// (no copies at the loop's end): while the 16 MFMAs of one pair of k-steps issue, the B fragments (L2) AND the A rows
-// (LDS) of the next pair are already requested -- neither an L2 nor an LDS latency sits in front of an MFMA block.
-template <int K>
-__device__ __forceinline__ void mma_abt2_fB(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1, int lda,
-                                            const float* __restrict__ Bf, int lane) {
+template <int K, int DB = 4>
+__device__ __forceinline__ void mma_abt2_fB_deep(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1, int lda,
+                                                 const float* __restrict__ Bf, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const float* a0p = A0 + r * lda + 4 * h;
   const float* a1p = A1 + r * lda + 4 * h;
   const float* bp = Bf + 4 * lane;
-  static_assert(K % 32 == 0, "quads of k-steps");
-  f32x4 bA = *reinterpret_cast<const f32x4*>(bp), bB = *reinterpret_cast<const f32x4*>(bp + 256);
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p), a1 = *reinterpret_cast<const f32x4*>(a1p);
-  f32x4 c0 = *reinterpret_cast<const f32x4*>(a0p + 8), c1 = *reinterpret_cast<const f32x4*>(a1p + 8);
+  constexpr int NF = K / 8;
+  static_assert(NF % DB == 0 && NF >= 2 * DB && DB % 2 == 0, "rings of DB fragments");
+#define GNET_BF(f_) (*reinterpret_cast<const f32x4*>(bp + (f_) * 256))
+#define GNET_A0(f_) (*reinterpret_cast<const f32x4*>(a0p + (f_) * 8))
+#define GNET_A1(f_) (*reinterpret_cast<const f32x4*>(a1p + (f_) * 8))
+  f32x4 b[DB], x[2], y[2];
+#pragma unroll
+  for (int i = 0; i < DB - 1; ++i) b[i] = GNET_BF(i);
+  x[0] = GNET_A0(0); y[0] = GNET_A1(0);
 #pragma unroll 1
-  for (int k = 0; k < K; k += 32) {
-    const int k1 = k + 16, k2 = min(k + 32, K - 16);      // (the last quad re-reads its own second pair)
-    const f32x4 nA = *reinterpret_cast<const f32x4*>(bp + k1 * 32), nB = *reinterpret_cast<const f32x4*>(bp + k1 * 32 + 256);
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(a0p + k1), d1 = *reinterpret_cast<const f32x4*>(a1p + k1);
-    const f32x4 e0 = *reinterpret_cast<const f32x4*>(a0p + k1 + 8), e1 = *reinterpret_cast<const f32x4*>(a1p + k1 + 8);
-    __builtin_amdgcn_sched_barrier(0);
-    GNET_MMA16(acc0, acc1, a0, a1, c0, c1, bA, bB);
-    __builtin_amdgcn_sched_barrier(0);
-    bA = *reinterpret_cast<const f32x4*>(bp + k2 * 32); bB = *reinterpret_cast<const f32x4*>(bp + k2 * 32 + 256);
-    a0 = *reinterpret_cast<const f32x4*>(a0p + k2); a1 = *reinterpret_cast<const f32x4*>(a1p + k2);
-    c0 = *reinterpret_cast<const f32x4*>(a0p + k2 + 8); c1 = *reinterpret_cast<const f32x4*>(a1p + k2 + 8);
-    __builtin_amdgcn_sched_barrier(0);
-    GNET_MMA16(acc0, acc1, d0, d1, e0, e1, nA, nB);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int f = 0; f < NF; f += DB) {
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+      b[(i + DB - 1) % DB] = GNET_BF(min(f + i + DB - 1, NF - 1));           // (the tail re-reads the last fragment)
+      x[(i + 1) & 1] = GNET_A0(min(f + i + 1, NF - 1)); y[(i + 1) & 1] = GNET_A1(min(f + i + 1, NF - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      GNET_MMA8(acc0, acc1, x[i & 1], y[i & 1], b[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+#undef GNET_BF
+#undef GNET_A0
+#undef GNET_A1
 }
 
 // acc[m][n] += X[32 rows x (32*MI)]^T * Y[32 rows x (32*NJ)] (weight-gradient shape: the

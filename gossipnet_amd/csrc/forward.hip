@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     // XCC_ID, compare-and-swap on a global word -- gives the same 3 %, and 4 % together with this; not worth its machinery.)
     acc0 = zero16(); acc1 = zero16();
     __builtin_amdgcn_s_setprio(2);
-    mma_abt2_fB<D_H>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)wave * (32 * 256), lane);
+    mma_abt2_fB_deep<D_H, 4>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)wave * (32 * 256), lane);
     __builtin_amdgcn_s_setprio(0);
     // requested before this tile's stores: the next tile's geometry and records, straight into the other staging buffer
     if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
