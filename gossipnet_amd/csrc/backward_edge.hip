@@ -526,6 +526,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   GSTAMP(a, 1);
   if (have_tiles) ebw_stage_h1(sH, sE, sWpT, fx, fy, fpa, first_e, lane);
   GSTAMP(a, 2);
+  const bool young = blockIdx.x >= gridDim.x / 2;      // the second workgroup dispatched to its CU (wave priorities below)
   for (int t = t0; t < t1; ++t) {
     const int p0 = t * 32;
     const int nrows = min(32, W - p0);
@@ -677,7 +678,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     // product below (k pairing of mma_abt), and the rows go to LDS as 16-byte pieces (over h1) for the d Wp product and
     // the row store
     f32x16 g1a = zero16(), g1b = zero16();
-    __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note at the atomics below)
+    if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note at the atomics below)
     {
       float* hp = sH + col * LD64 + 4 * half;
       float4 hm[8];
@@ -745,8 +746,9 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       }
       // Everything outside the g1 / d P MFMA section runs at a raised wave priority: a wave in its bookkeeping (atomics, row
       // stores, the next tile's slot logic and gathers) gets its issue slots ahead of the other workgroup's MFMA stream and is
-      // back in its own MFMA section sooner (-1 %; raising the MFMA section instead: +-0).
-      __builtin_amdgcn_s_setprio(1);
+      // back in its own MFMA section sooner (-1 %; raising the MFMA section instead: +-0).  The CU's second-dispatched workgroup
+      // (the loser of every age-based arbitration) runs one level above the first in both sections: another -2.7 %.
+      if (young) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
       // rows past the list (last tile) go to the slack row E of d_pw: unconditional, no divergent branches
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
