@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     // instructions per wave and tile; the per-edge loop it replaces (two row look-ups, 7 FMAs on broadcast LDS reads and a
     // store PER EDGE AND THREAD: ~640) took 18 of a tile's 46 us waiting for issue slots between the other workgroup's MFMAs.
     f32x16 acc0, acc1;
+    int claimed = 0;
     {
       const unsigned fo = (unsigned)(32 * wave + 4 * half) * 4u;
       const unsigned ocA = (unsigned)sIdx[col] * (D_H * 4u) + fo, onA = (unsigned)sIdx[PW_T + col] * (D_H * 4u) + fo;
@@ -248,6 +249,11 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
       for (int g = 0; g < 4; ++g) { tcA[g] = ldg4_b(a.tc, ocA + 32u * g); tnA[g] = ldg4_b(a.tn, onA + 32u * g); }
 #pragma unroll
       for (int g = 0; g < 4; ++g) { tcB[g] = ldg4_b(a.tc, ocB + 32u * g); tnB[g] = ldg4_b(a.tn, onB + 32u * g); }
+      // the claim of the tile after the next one, HERE: the compiler waits for an atomic's result on the spot (vmcnt(0): the result
+      // merges with the other lanes' value), and behind the gathers that wait is the one this wave is about to make anyway.
+      // In front of fc3, where it used to sit, it made wave 0 wait for the acknowledgement of its eight h1 stores and the
+      // atomic's round trip in front of a workgroup barrier -- every wave of the tile waited with it.
+      if (tid == 0) claimed = atomicAdd(a.claim, 1);
       const f32x4 gA = *reinterpret_cast<const f32x4*>(sGeo + col * 8 + 4 * half);
       const f32x4 gB = *reinterpret_cast<const f32x4*>(sGeo + (32 + col) * 8 + 4 * half);
 #pragma unroll
@@ -314,8 +320,6 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
     f32x4 w3f[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3t + (size_t)col * D_H + 64 * kq + 4 * half + 8 * k);
-    int claimed = 0;
-    if (tid == 0) claimed = atomicAdd(a.claim, 1);            // (beside the W3 loads; read behind the fc3 MFMAs)
     if (it == 10) GSTAMP(a, 6);
     __syncthreads();
     if (it == 10) GSTAMP(a, 7);
