@@ -804,6 +804,10 @@ struct PwW1Args {
 };
 
 __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
+  // rows in flight per wave.  The grid is bounded by the arena's partial slots (512 workgroups = two waves per SIMD), so the
+  // bytes in flight are waves x NQ KB: 8 rows = 16 MB on the device = 4.7 TB/s at ~3 us per round trip (0.465 ms); 16: 0.417;
+  // 24: 0.408; 32: 0.420 (173 registers at 24: still two waves per SIMD).  Same order of additions, same bits.
+  constexpr int NQ = 24;
   __shared__ float red[4 * 8 * D_H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 g[7], gb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -824,8 +828,8 @@ __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
       const int tt = in ? a.edge_t[el] : 0;
       unsigned long long mo = __ballot(in && W1_BIT(el));
       unsigned long long mr = __ballot(in && W1_BIT(tt));
-      // eight rows in flight per wave (the sums are latency-bound: 2 rows per round trip kept the kernel at 2.5 TB/s,
-      // 4 at 3.9); rows are taken in ascending edge order, missing slots re-read the last row and are skipped.
+      // NQ rows in flight per wave (the sums are latency-bound: 2 rows per round trip kept the kernel at 2.5 TB/s,
+      // 4 at 3.9, 8 at 4.7); rows are taken in ascending edge order, missing slots re-read the last row and are skipped.
       // The geometry columns of the 64 edges of this pass sit in two registers per lane (one coalesced load) and
       // reach the sums through v_readlane.
       float4 geA = make_float4(0.f, 0.f, 0.f, 0.f), geB = geA;
@@ -834,18 +838,18 @@ __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
         geB = *reinterpret_cast<const float4*>(a.geo + (size_t)el * 8 + 4);
       }
       while (mo) {
-        int j[8]; bool hv[8];
+        int j[NQ]; bool hv[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           hv[q] = mo != 0ull;
           j[q] = hv[q] ? __builtin_ctzll(mo) : (q ? j[q - 1] : 0);
           if (hv[q]) mo &= mo - 1;
         }
-        float4 d[8];
+        float4 d[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)(base + j[q]) * D_H + 4 * lane);
+        for (int q = 0; q < NQ; ++q) d[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)(base + j[q]) * D_H + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           if (hv[q]) {                                      // wave-uniform
             const float4 dq = d[q];
             const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geA.x), j[q])), g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geA.y), j[q]));
@@ -859,19 +863,19 @@ __global__ void __launch_bounds__(256) pw_w1_nodesums(const PwW1Args a) {
         }
       }
       while (mr) {
-        int r[8]; bool hv[8];
+        int r[NQ]; bool hv[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           hv[q] = mr != 0ull;
           const int jj = hv[q] ? __builtin_ctzll(mr) : 0;
           if (hv[q]) mr &= mr - 1;
           r[q] = hv[q] ? __builtin_amdgcn_readlane(tt, jj) : (q ? r[q - 1] : 0);
         }
-        float4 tq[8];
+        float4 tq[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) tq[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r[q] * D_H + 4 * lane);
+        for (int q = 0; q < NQ; ++q) tq[q] = *reinterpret_cast<const float4*>(a.d_h1 + (size_t)r[q] * D_H + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < NQ; ++q)
           if (hv[q]) { T.x += tq[q].x; T.y += tq[q].y; T.z += tq[q].z; T.w += tq[q].w; }
       }
     }
