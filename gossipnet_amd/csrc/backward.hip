@@ -331,8 +331,12 @@ __device__ __forceinline__ void load_node_mid(NodeTileMid& m, const BlkNodeArgs&
 // the weight slices each wave multiplies by are loaded into registers once, before the first tile, and all seven
 // input tiles of a detection tile (x, d_x, r, [r_n,] d_rc, d_rn, q, segment-max records) are requested together
 // at its top.  The weight-gradient accumulators stay in registers across the tiles of the workgroup.
-template <bool NF>
-__global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
+// ONE: one tile per workgroup at 256 registers, so that TWO workgroups share a CU (2 x 80 KB of LDS) and their barrier-separated
+// chains interleave on its SIMDs -- the node_fwd arrangement.  The weight slices are then requested a stage ahead of their use
+// instead of once for all tiles (they cost 96 of the 492 registers), and there is no next tile to prefetch.  Used while there is
+// at most one tile per CU (N <= 8192 detections per step: see gnet_backward); the looping form covers larger steps.
+template <bool NF, bool ONE>
+__global__ void __launch_bounds__(256, ONE ? 2 : 1) blk_bwd_node(const BlkNodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   GSTAMP(a, 0);
   const int tid = threadIdx.x, lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,15 +356,13 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
   // waves are folded once, after the last tile
   float gb1 = 0.f, gbr = 0.f, gbrn = 0.f, gb4 = 0.f, gb4b = 0.f, gb3 = 0.f;
   BtRegs<32> gW1, gWr, gWrn, gW3; BtRegs<64> gW4;
-  if (a.do_pre) {
-    load_bt<32>(gW1, a.w1 + (size_t)(32 + 32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane);   // role = (term, K half)
-    load_bt<D_R>(gWr, a.wr + (size_t)(32 * cw) * D_R, D_R, lane);
-    if (NF) load_bt<D_R>(gWrn, a.wrn + (size_t)(32 * cw) * D_R, D_R, lane);
-  }
-  if (a.do_post) {
-    load_bt<64>(gW4, a.w4 + (size_t)(32 * (cw & 1)) * D_S + 64 * (cw >> 1), D_S, lane);        // role = (column tile, K half)
-    load_bt<32>(gW3, a.w3 + (size_t)(32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane);
-  }
+#define BN_LOAD_W1() load_bt<32>(gW1, a.w1 + (size_t)(32 + 32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane)   /* role = (term, K half) */
+#define BN_LOAD_WR() do { load_bt<D_R>(gWr, a.wr + (size_t)(32 * cw) * D_R, D_R, lane); if (NF) load_bt<D_R>(gWrn, a.wrn + (size_t)(32 * cw) * D_R, D_R, lane); } while (0)
+#define BN_LOAD_W4() load_bt<64>(gW4, a.w4 + (size_t)(32 * (cw & 1)) * D_S + 64 * (cw >> 1), D_S, lane)        /* role = (column tile, K half) */
+#define BN_LOAD_W3() load_bt<32>(gW3, a.w3 + (size_t)(32 * (cw & 1)) * D_P + 32 * (cw >> 1), D_P, lane)
+  if (a.do_pre) { BN_LOAD_W1(); if (!ONE) BN_LOAD_WR(); }
+  if (a.do_post && !ONE) { BN_LOAD_W4(); BN_LOAD_W3(); }
+  if (ONE && !a.do_pre && a.do_post) BN_LOAD_W4();
   const int ntiles = (a.n_det + 31) / 32;
   NodeTileIn in;
   if ((int)blockIdx.x < ntiles) load_node_tile<NF>(in, a, blockIdx.x * 32, tid);
@@ -390,7 +392,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
     NodeTileMid mid;
     load_node_mid(mid, a, row0, tid);
     // the next tile of this workgroup is requested now and lands while this one is computed
-    if (t + (int)gridDim.x < ntiles) load_node_tile<NF>(in, a, (t + gridDim.x) * 32, tid);
+    if (!ONE && t + (int)gridDim.x < ntiles) load_node_tile<NF>(in, a, (t + gridDim.x) * 32, tid);
     __syncthreads();
     GSTAMP(a, 1);
     if (a.do_pre) {
@@ -402,6 +404,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sPart[(cw * 32 + crow(r, half)) * 32 + col] = acc[r];
       }
+      if (ONE && (a.do_post || a.want_dx0)) BN_LOAD_WR();      // (used two barriers further down)
       // d Wc += r^T . drc ; d Wn += r_n^T . drn (r_n = r without neighbor_feats) : role = (term, column tile)
       {
         const int term = cw >> 1, nj = cw & 1;
@@ -439,6 +442,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         f32x16 acc = zero16();
         mma_abt_r<D_R>(acc, sDr, LD32, gWr, lane);
         if (NF) mma_abt_r<D_R>(acc, sDrn, LD32, gWrn, lane);
+        if (ONE && a.do_post) BN_LOAD_W4();                    // (used behind the next two barriers)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
@@ -491,6 +495,7 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
         const int nt = cw & 1, kh = cw >> 1;
         f32x16 acc = zero16();
         mma_abt_r<64>(acc, sDZ + 64 * kh, LD128, gW4, lane);
+        if (ONE) BN_LOAD_W3();                                 // (used behind the next two barriers)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sR[(kh * 32 + crow(r, half)) * D_P + 32 * nt + col] = acc[r];
       }
@@ -527,7 +532,12 @@ __global__ void __launch_bounds__(256, 1) blk_bwd_node(const BlkNodeArgs a) {
       }
     }
     GSTAMP(a, 3);
+    if (ONE) break;
   }
+#undef BN_LOAD_W1
+#undef BN_LOAD_WR
+#undef BN_LOAD_W4
+#undef BN_LOAD_W3
   // ---- partial weight gradients of this workgroup
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
   __syncthreads();
@@ -1058,7 +1068,17 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into the [E,64] fp32 arrays
   void* prof = buf->profiler;
   const long long stride = arena_stride(L.total);
-  const int g_node = min((N + 31) / 32, 256);                                           // node-kernel workgroups (32-detection tiles, one workgroup per CU)
+#ifdef BN_NO_ONE
+  const bool node_one = false;
+#else
+  // one tile per workgroup (blk_bwd_node<.., true>) while the tiles fit the CUs.  Measured at 500 tiles (8 x 2000 detections):
+  // two co-resident workgroups per CU finish in 23.2 us instead of 25.8 (their chains overlap except for the MFMA pipe, which is 40 %
+  // of a chain) -- and reduce_partials then reads 500 instead of 256 partial copies of the node parameters: 0.05 ms gained, 0.05 ms
+  // lost.  At up to 256 tiles (the reference's one-image step: 63) the partial count is the same and the shorter front is a gain
+  // (19 -> 17 us per launch).
+  const bool node_one = (N + 31) / 32 <= 256;
+#endif
+  const int g_node = node_one ? (N + 31) / 32 : min((N + 31) / 32, 256);                // node-kernel workgroups (32-detection tiles)
   const int g_head = min((N + 31) / 32, 256);
   const int etiles = (E + 31) / 32;
   const int g_edge = E > 0 ? 512 : 0;                                                  // edge_bwd_w workgroups (two per CU)
@@ -1084,8 +1104,10 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     GNET_LAUNCH(prof, GNET_K_HEAD_BWD, s, head_bwd<<<g_head, 256, 0, s>>>(h));
   }
   // backward chain: node(post B) -> edge(B) -> node(pre B + post B-1) -> edge(B-1) -> ... -> node(pre 1)
-  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
-  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)blk_bwd_node<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlkNodeSmem));
   for (int b = B + 1; b >= 1; --b) {
     // node stage: pre of block b (b <= B), post of block b-1 (b >= 2)
     BlkNodeArgs n;
@@ -1117,8 +1139,13 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     } else { n.q = nullptr; n.pm = nullptr; n.w4 = n.w3 = nullptr; n.o_w4 = n.o_b4 = n.o_w3 = n.o_b3 = 0; }
     n.d_x = buf->d_x; n.d_pc = buf->d_pc; n.arena = buf->arena; n.stride = stride;
     GNET_TRACE_SET(n, "NODE_BWD", b == B / 2);
-    if (cfg->neighbor_feats) { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<true><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
-    else { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<false><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
+    if (node_one) {
+      if (cfg->neighbor_feats) { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<true, true><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
+      else { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<false, true><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
+    } else {
+      if (cfg->neighbor_feats) { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<true, false><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
+      else { GNET_LAUNCH(prof, GNET_K_NODE_BWD, s, blk_bwd_node<false, false><<<g_node, 256, kBlkNodeSmem, s>>>(n)); }
+    }
     // edge stage of block b-1
     if (b >= 2 && E > 0) {
       if (b == B + 1 && prepared && prepared_event) {
