@@ -657,10 +657,12 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         for (int r = 1; r < 16; ++r) { s0 = fmaxf(s0, h2a[r]); s1 = fmaxf(s1, h2b[r]); }
         s0 = half_fmax(s0);
         s1 = half_fmax(s1);
+        if (TRAIN) {                                    // (forward only: nobody reads the tie count or the arg-max)
 #pragma unroll
-        for (int r = 15; r >= 0; --r) {
-          hit_bit(b0, h2a[r], s0);
-          hit_bit(b1, h2b[r], s1);
+          for (int r = 15; r >= 0; --r) {
+            hit_bit(b0, h2a[r], s0);
+            hit_bit(b1, h2b[r], s1);
+          }
         }
       } else {
         // rows [lo, hi) of the tile.  Accumulator slots come in groups of four consecutive rows (8 g + 4 half + q):
@@ -687,6 +689,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         }
         s0 = half_fmax(s0);
         s1 = half_fmax(s1);
+        if (TRAIN)
 #pragma unroll
         for (int g = 3; g >= 0; --g) {
           if (8 * g + 8 <= lo || 8 * g >= hi) { b0 <<= 4; b1 <<= 4; continue; }
@@ -706,7 +709,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
           }
         }
       }
-      unsigned q0 = __popc(b0), q1 = __popc(b1);
+      // (forward only: a count of one per half-wave -- the records' low word is then 2 and means nothing)
+      unsigned q0 = TRAIN ? __popc(b0) : 1u, q1 = TRAIN ? __popc(b1) : 1u;
       int a0 = 0x7fffffff, a1 = 0x7fffffff;          // first edge attaining the maximum (no hit in this half-wave: INT_MAX)
       if (TRAIN) {
         // lowest hit slot r -> row crow(r, half) = r + (r & 12) + 4 half of the tile (v_ffbl of 0 is -1: masked by the select)

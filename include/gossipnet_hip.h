@@ -103,7 +103,7 @@ typedef struct gnet_buffers {
   float* blk_r[GNET_MAX_BLOCKS + 1];       /* [n_det,32]  relu(reduce_dim)        */
   float* blk_rc[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[32:64] + b1        */
   float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[64:96]             */
-  uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count */
+  uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count (the count is formed by a training forward only; a forward-only pass leaves a meaningless low word) */
   float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
   float* blk_rnb[GNET_MAX_BLOCKS + 1];     /* [n_det,32]  relu(reduce_dim_neighbor) (neighbor_feats, training)   */
   float* blk_h1[GNET_MAX_BLOCKS + 1];      /* [n_edge+64,64] relu(pw_fc1) per edge -- only when planned with training == 2 (tests / debugging: the backward pass recomputes the rows it needs) */
