@@ -630,8 +630,12 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     // pre-activations; relu is monotone, so max(relu(v)) = relu(max(v)): rectify once per segment.  The
     // tie count is the number of rows equal to the maximum (when the maximum is <= 0 every gradient through
     // it is zero and only count >= 1 matters).
+    // (forward only: rounding is monotone, so max_r fl(h_r + b) = fl(max_r h_r + b) -- the bias is added to the segment's maximum;
+    //  a training pass counts ties on the biased values, which two different raw values can share)
+    if (TRAIN) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { h2a[r] += bias0; h2b[r] += bias1; }
+      for (int r = 0; r < 16; ++r) { h2a[r] += bias0; h2b[r] += bias1; }
+    }
     if (KEEP) {
       // tests: the exact bits the maxima, tie counts and arg-max edges below are derived from (rows past E: slack)
       float* dst = a.h2_out + (size_t)e0 * D_P + col;
@@ -721,6 +725,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         a0 = half_min(a0);
         a1 = half_min(a1);
       }
+      if (!TRAIN) { s0 += bias0; s1 += bias1; }
       s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
       q0 = half_add(q0);
       q1 = half_add(q1);
