@@ -215,7 +215,13 @@ __global__ void __launch_bounds__(256) gather_winners(const float* __restrict__ 
   const struct { unsigned long long* trace; } tr = {trace_ptr};
 #endif
   GSTAMP(tr, 0);
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD-aware: workgroups go round-robin to the 8 XCDs; XCD x takes the x-th contiguous eighth of the detections (one image's
+  // worth when the batch has 8), whose own rows AND reversed pairs' rows -- neighbours are detections of the same image -- lie in
+  // the eighth of the list that edge_bwd_w's XCD x has just written: one L2 sees both reads of a row
+  // (-1.6 %: probe builds put 0.30 of the kernel's 0.58 ms on the reversed rows -- random 256-byte gathers at 4.6 TB/s -- 0.13 on
+  // the own rows, which stream at 10 TB/s out of the caches edge_bwd_w left them in, and 0.15 on the launches' fixed part)
+  const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int node = lb * 4 + (threadIdx.x >> 6);
   if (node >= n_det) return;
   const int lane = threadIdx.x & 63, sub = lane >> 4, f4 = lane & 15;
   const int eb = row_ptr[node], ee = row_ptr[node + 1];
