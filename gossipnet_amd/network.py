@@ -578,7 +578,7 @@ class Gnet(object):
         totals = off[:, n_wg]
         cp = self.num_classes if self.num_classes > 1 else 1
         n = int(self.params.numel())
-        g_w1c = max(1, min(128, 256 // (2 * cp))); g_w1 = max(1, min(512, (N + 3) // 4)); g_pw = min((E + 31) // 32, 256)
+        g_w1c = max(1, min(128, 2048 // (2 * cp))); g_w1 = max(1, min(512, (N + 3) // 4)); g_pw = min((E + 31) // 32, 256)
         tiles = (N + 31) // 32
         g_edge, g_node, g_head = 512, min(tiles, 256), min(tiles, 256)                        # the grids of gnet_backward
         w1c = 2 * cp * 256; pw1 = (2 * cp + 7) * 256 + 256; pw = pw1 + 256 * 256 + 256 + 256 * 32 + 32
