@@ -47,6 +47,9 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, l
   *off = o; *in = D_HEAD; *out = D_HEAD;
 }
 
+#ifndef PACK_X
+#define PACK_X 32        // workgroups per matrix: the 256 x 256 one is 32 strided 4-byte gathers per thread at 8 (20 us), 8 at 32
+#endif
 __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ params, float* __restrict__ packed,
                                                       int dpw, int nblocks, int nf) {
   long long off; int in, out;
@@ -1031,7 +1034,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   float* pt = buf->packed_t;
 
   void* prof = buf->profiler;
-  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(8, 3 + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats));
+  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(PACK_X, 3 + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats));
 
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
