@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(256) winner_positions(const PosArgs a) {
 // their rn row is the zero row), wrow[i] = list position of the first winner at or after detection i's first edge.
 // gather_winners reads these instead of chasing edge_t -> bitmap word -> prefix count per edge.  All blocks in one launch.
 struct TposArgs {
-  int n_det, n_edge;
+  int n_det, n_edge, n_wg;
+  const int* wlist; const int* wg_off;    // the blocks' winner lists and their lengths (list_scan's totals)
   long long bm_stride, wl_stride, tf_stride;
   const unsigned long long* ewin; const int* wprefix;
   const int* row_ptr; const int* edge_c; const int* edge_n; const int* edge_t;
@@ -361,11 +362,16 @@ __global__ void __launch_bounds__(256) winner_tpos(const TposArgs a) {
   int* tpos = a.tpos + (size_t)blk * a.wl_stride;
   int* wrow = a.wrow + (size_t)blk * a.tf_stride;
   const int stride = gridDim.x * 256;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < a.n_edge; e += stride) {
-    const int t = a.edge_t[e];
-    int tp = -1;
-    if (a.edge_c[e] != a.edge_n[e] && ((ewin[t >> 6] >> (t & 63)) & 1ull)) tp = winner_pos(ewin, wprefix, t);
-    tpos[e] = tp;
+  // SCATTER over the winners (a quarter of the edges): winner t at list position p is the reversed pair of edge edge_t[t]
+  // (edge_t is an involution; a self pair is its own reverse and has no neighbour row).  tpos was filled with -1 beside the
+  // forward pass.  The gather it replaces -- every edge looks its reversed pair up in the bitmap -- made 28 M random L2 requests
+  // per step for the 16 blocks (96 us; the CU's address path takes one lane-address per clock); this makes 11 M.
+  const int* wl = a.wlist + (size_t)blk * a.wl_stride;
+  const int W = a.wg_off[(size_t)blk * (a.n_wg + 1) + a.n_wg];
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < W; p += stride) {
+    const int t = wl[p];
+    const int e = a.edge_t[t];
+    if (e != t) tpos[e] = p;          // (a self pair is the involution's fixed point)
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i <= a.n_det; i += stride) wrow[i] = winner_pos(ewin, wprefix, a.row_ptr[i]);
 }
@@ -854,6 +860,8 @@ int edge_stage_clear(const gnet_config* cfg, const gnet_shape* shape, gnet_buffe
   const EdgeGeom G = edge_geom(E, N);
   HIP_CHECK_RET(hipMemsetAsync(buf->ewin, 0, (size_t)(B + 1) * G.bm_stride * sizeof(unsigned long long), s));
   HIP_CHECK_RET(hipMemsetAsync(buf->rl_scratch + (size_t)(B + 1) * (2 * G.n_wg + 1), 0, (size_t)GNET_MAX_BLOCKS * sizeof(int), s));
+  // tpos = -1 everywhere: winner_tpos scatters the positions of the winners' reversed pairs over it
+  if (E > 0) HIP_CHECK_RET(hipMemsetAsync(buf->tpos, 0xff, (size_t)B * G.wl_stride * sizeof(int), s));
   return GNET_OK;
 }
 
@@ -898,7 +906,7 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   t.n_det = N; t.n_edge = E; t.bm_stride = (long long)G.bm_stride; t.wl_stride = (long long)G.wl_stride; t.tf_stride = (long long)G.tf_stride;
   t.ewin = (const unsigned long long*)buf->ewin; t.wprefix = buf->wprefix;
   t.row_ptr = buf->row_ptr; t.edge_c = buf->edge_c; t.edge_n = buf->edge_n; t.edge_t = buf->edge_t;   // (edge_t: gnet_graph_transpose, earlier on this stream)
-  t.tpos = buf->tpos; t.wrow = buf->wrow;
+  t.tpos = buf->tpos; t.wrow = buf->wrow; t.n_wg = (int)G.n_wg; t.wlist = buf->wlist; t.wg_off = l.wg_off;
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_tpos<<<dim3(min((E + 255) / 256, 1024), B), 256, 0, s>>>(t));
   return GNET_OK;
 }
