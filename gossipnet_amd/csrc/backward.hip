@@ -1074,16 +1074,12 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;   // 32-bit byte offsets into the [E,64] fp32 arrays
   void* prof = buf->profiler;
   const long long stride = arena_stride(L.total);
-#ifdef BN_NO_ONE
-  const bool node_one = false;
-#else
   // one tile per workgroup (blk_bwd_node<.., true>) while the tiles fit the CUs.  Measured at 500 tiles (8 x 2000 detections):
   // two co-resident workgroups per CU finish in 23.2 us instead of 25.8 (their chains overlap except for the MFMA pipe, which is 40 %
   // of a chain) -- and reduce_partials then reads 500 instead of 256 partial copies of the node parameters: 0.05 ms gained, 0.05 ms
   // lost.  At up to 256 tiles (the reference's one-image step: 63) the partial count is the same and the shorter front is a gain
   // (19 -> 17 us per launch).
   const bool node_one = (N + 31) / 32 <= 256;
-#endif
   const int g_node = node_one ? (N + 31) / 32 : min((N + 31) / 32, 256);                // node-kernel workgroups (32-detection tiles)
   const int g_head = min((N + 31) / 32, 256);
   const int etiles = (E + 31) / 32;
