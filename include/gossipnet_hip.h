@@ -232,8 +232,9 @@ int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_in
  * streams).  With prepared = 0 gnet_backward does this work itself. */
 int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                           const float* params, gnet_buffers* buf, int32_t phase, gnet_stream_t stream);
-/* phase 0 = everything (after gnet_forward); 1 = only the zeroing (d_pw, the winner maps: independent of the forward
- * pass, may run beside it); 2 = only the forward-dependent part (after gnet_forward and after phase 1). */
+/* phase 0 = everything (after gnet_forward); 1 = only the fills (d_pw and the winner maps zeroed, tpos set to -1:
+ * independent of the forward pass, may run beside it); 2 = only the forward-dependent part (after gnet_forward and
+ * after phase 1). */
 
 /* ---- training step around the path (train.py:64-77: slim create_train_op with Adam / Momentum) --------
  * All buffers are flat fp32 of n = gnet_param_count elements (device).  grad_scale multiplies the
