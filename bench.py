@@ -463,7 +463,7 @@ def main():
 
     side = None
     if not args.no_kernel_timing and E > 0:
-        # The zeroing half of the backward preparation (hipMemsetAsync of d_pw = E x 128 B and of the winner maps: rocclr fill
+        # The zeroing half of the backward preparation (hipMemsetAsync of d_pw = E x 128 B, of the winner maps and of tpos: rocclr fill
         # kernels, not in the per-class table) runs on the Gnet's side stream beside pw_fwd.  Timed here ALONE on the idle
         # device = its unobstructed cost; in the step its workgroups wait for slots pw_fwd's persistent workgroups free (the
         # fills then last as long as pw_fwd, rocprof shows ~2 ms of them per step) without costing the main stream anything
@@ -480,12 +480,12 @@ def main():
                                                     C.byref(net._buf), 1, s_), "gnet_backward_prepare")
         e1.record(); e1.synchronize()
         fill_ms = e0.elapsed_time(e1) / 5
-        fill_bytes = E * 32 * 4 + (args.blocks + 1) * ((E + 63) // 64 + 256) * 8
+        fill_bytes = E * 32 * 4 + (args.blocks + 1) * ((E + 63) // 64 + 256) * 8 + args.blocks * ((E + 64 + 63) // 64 * 64) * 4   # d_pw, winner maps, tpos
         side = {"zeroing_ms_alone": round(fill_ms, 4), "zeroing_bytes": fill_bytes, "gb_per_s_alone": round(fill_bytes / fill_ms / 1e6, 1),
-                "note": "hipMemsetAsync of d_pw and the winner maps on the side stream beside pw_fwd; alone on the device it takes this "
+                "note": "hipMemsetAsync of d_pw, the winner maps and tpos (-1) on the side stream beside pw_fwd; alone on the device it takes this "
                         "long; inside the step it overlaps pw_fwd (same step time whether issued there or after the forward pass)",
                 "winner_lists_ms_per_step": round(table.get("winner_lists", 0.0), 4),
-                "winner_lists_note": "side stream, beside matching / loss / head backward; ~0.085 ms of it exposed in front of the first edge_bwd_w"}
+                "winner_lists_note": "side stream, beside matching / loss / head backward; ~0.03 ms of it exposed in front of the first edge_bwd_w (probe build without the wait, DESIGN.md lesson 55)"}
 
     if rank == 0:
         out = {
