@@ -10,6 +10,7 @@
 //   node_fwd         per block: fc1, fc2, shortcut (:390-408) of block b and reduce_dim (:348-354)
 //                    + the per-node halves of pw_fc1 of block b+1; after the last block: head (:258-273)
 // All dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -157,6 +158,7 @@ struct PwFwdArgs {
   const float* w1;                      // natural [dpw,256]: the 7 geometry rows are read here
   const float* w2t; const float* b2;    // fc2 as operand fragments (pack_transpose: fragment-major), [256]
   const float* w3t; const float* b3;    // transposed [32,256]
+  const float* w3;                      // natural [256,32] (pw_fwd2's resident fc3 operand)
   float* h1; float* h2; float* pw;
   int training;
   int* claim;                           // tile counter (reset by edge_geometry, the launch in front of this one)
@@ -373,6 +375,207 @@ __global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
 }
 
 constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 2 * (PW_T * 12)) * sizeof(float);   // staging: 8 floats + 2 indices per edge (+ 2 spare)
+
+// ------------------------------------------------------------------------------------------
+// pw_fwd2: the same layer stack as pw_fwd with the WEIGHTS RESIDENT IN REGISTERS: one 8-wave workgroup per CU (two waves per
+// SIMD, 256 registers each), wave w owns output features [32 w, 32 w + 32) of fc2 for every tile the workgroup walks and keeps
+// its 256 x 32 slice of W2 (128 registers), its 32 x 32 slice of W3 (16) and its bias pieces (16) for the whole kernel -- fc2's
+// weight stream from L2 (the 11 % of round 4's probe, and 32 operand registers of pipeline) is gone.
+//   * fc2 is computed TRANSPOSED (h2^T = W2^T . h1^T: A = the resident weights, B = the h1 tile in LDS): the accumulators hold
+//     lane = edge, registers = features, which IS the A operand of fc3 (as edge_fwd_w's layers) -- no h2 round trip through
+//     LDS; fc3 is K-split over the eight waves (16 MFMAs each), the partial sums meet in LDS;
+//   * a tile is 32 edges; its h1 is produced one tile ahead, INSIDE the previous tile's fc2 stream (8 table gathers requested
+//     at the top of the stream, 4 MFMAs + 4 LDS stores in its middle), into the other of two h1 buffers; the partial sums of
+//     tile t are reduced and stored inside tile t + 1's stream (two partial buffers): ONE workgroup barrier per tile, and
+//     nothing but the fc3 tail (16 MFMAs, 16 LDS stores) runs without MFMAs of the same wave around it;
+//   * training: h1 leaves through LDS as whole 1 KB rows (four per wave); h2 leaves straight from the accumulators, 16 bytes
+//     per lane -- a store instruction covers 32 bytes of each of 32 rows, four of them complete a 128-byte line.
+// No conditional memory operation in the tile loop (the compiler's wait insertion merges control-flow joins conservatively):
+// the one-tile-ahead work of the last tile recomputes a clamped tile, the first tile's "previous" output row is a slack row.
+constexpr int PW2_T = 32;
+constexpr int PW2_LD = D_H + 4;                  // padded h1 row: conflict-free 16-byte reads at one column of 32 rows
+constexpr int PW2_HF = PW2_T * PW2_LD;           // floats of one h1 tile
+constexpr int PW2_PF = 8 * PW2_T * D_E;          // floats of one set of fc3 partial sums (8 waves x [32][32])
+constexpr size_t kPwFwd2Smem = (size_t)(2 * PW2_HF + 2 * PW2_PF) * sizeof(float);
+
+__device__ __forceinline__ void pw2_barrier() {
+  // LDS only: this wave's LDS stores are done, then the workgroup meets.  (__syncthreads() also drains vmcnt: the h1 / h2 / pw
+  // stores of a tile would be waited for at every barrier.)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool TRAINING>
+__global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sH = smem;                              // [2][32][260]
+  float* sP = smem + 2 * PW2_HF;                 // [2][8][32][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int nt = (a.n_edge + PW2_T - 1) / PW2_T, nwg = gridDim.x;
+  // XCD-aware contiguous ranges (as edge_fwd_w): XCD x walks the x-th eighth of the edge list, its table rows stay in its L2
+  const int lb = (nwg & 7) == 0 ? (int)((blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int t0 = range_begin(lb, nt, nwg), t1 = range_begin(lb + 1, nt, nwg);
+  if (t0 >= t1) return;
+  const int last = a.n_edge - 1;
+
+  // ---- resident operands
+  // W2 as the A operand of the transposed product: lane (feature col, half) supplies W2[8 s + 4 half + t][32 wave + col] at
+  // step (s, t) -- exactly the lane's 16-byte piece of the fragment-major copy (pack_transpose)
+  f32x4 w2r[32];
+  {
+    const float* bp = a.w2t + ((size_t)wave * (32 * 64) + lane) * 4;
+#pragma unroll
+    for (int s_ = 0; s_ < 32; ++s_) w2r[s_] = *reinterpret_cast<const f32x4*>(bp + s_ * 256);
+  }
+  // fc3: A = the rectified accumulators (lane = edge, register r = feature 32 wave + crow(r, half)), B = W3[that feature][col]
+  // (requested late in every tile's stream, when the registers of the next tile's gathers are free again: 32 registers
+  // that would not fit beside the 128 of W2 otherwise; L1-resident after the first tile)
+  float w3r[16];
+  float4 b2q[4];
+  const float* w3p = a.w3 + (size_t)(32 * wave + 4 * half) * D_E + col;
+  const float* b2p = a.b2 + 32 * wave + 4 * half;
+  const int geo_row0 = 2 * a.cprime;
+  float wgA[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int k = 4 * half + s_;
+    wgA[s_] = k < 7 ? a.w1[(size_t)(geo_row0 + k) * D_H + 32 * wave + col] : 0.f;
+  }
+  const int er = tid >> 4, j0 = (tid & 15) * 2;   // the (edge, output pair) of a tile this thread reduces
+  const float b3a = a.b3[j0], b3b = a.b3[j0 + 1];
+  const unsigned fo = (unsigned)(32 * wave + 4 * half) * 4u;   // the lane's first feature piece in a table row (bytes)
+
+#define PW2_EDGE(u_) min(min((u_), nt - 1) * PW2_T + col, last)
+#define PW2_REQUEST(c_, n_)                                                                        \
+  do {                                                                                             \
+    const unsigned oc_ = (unsigned)(c_) * (D_H * 4u) + fo, on_ = (unsigned)(n_) * (D_H * 4u) + fo; \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) { tcv[g] = ldg4_b(a.tc, oc_ + 32u * g); tnv[g] = ldg4_b(a.tn, on_ + 32u * g); } \
+  } while (0)
+  // h1^T piece of this wave: accumulators start from the two table rows, 4 MFMAs add the geometry term (K = 8), one integer
+  // max rectifies, the rows go to LDS in the [edge][feature] layout fc2 reads
+#define PW2_FC1(dstH_)                                                                             \
+  do {                                                                                             \
+    f32x16 h_;                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
+      h_[4 * g + 0] = tcv[g].x + tnv[g].x; h_[4 * g + 1] = tcv[g].y + tnv[g].y;                    \
+      h_[4 * g + 2] = tcv[g].z + tnv[g].z; h_[4 * g + 3] = tcv[g].w + tnv[g].w;                    \
+    }                                                                                              \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[0], gv.x, h_, 0, 0, 0);                          \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[1], gv.y, h_, 0, 0, 0);                          \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gv.z, h_, 0, 0, 0);                          \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gv.w, h_, 0, 0, 0);                          \
+    float* d_ = (dstH_) + col * PW2_LD + 32 * wave + 4 * half;                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                  \
+      *reinterpret_cast<float4*>(d_ + 8 * g) = make_float4(relu_bits(h_[4 * g]), relu_bits(h_[4 * g + 1]), relu_bits(h_[4 * g + 2]), relu_bits(h_[4 * g + 3])); \
+  } while (0)
+
+  // ---- front: the first tile's h1, the records of the second
+  float4 tcv[4], tnv[4];
+  f32x4 gv;
+  int c1, n1;
+  {
+    const int e = PW2_EDGE(t0);
+    const int c0 = a.edge_c[e], n0 = a.edge_n[e];
+    gv = *reinterpret_cast<const f32x4*>(a.geo + (size_t)e * 8 + 4 * half);
+    const int e1 = PW2_EDGE(t0 + 1);
+    c1 = a.edge_c[e1]; n1 = a.edge_n[e1];
+    PW2_REQUEST(c0, n0);
+    PW2_FC1(sH);
+  }
+  pw2_barrier();
+
+  for (int t = t0, it = 0; t < t1; ++t, ++it) {
+    const int e0 = t * PW2_T;
+    const float* Hc = sH + (it & 1) * PW2_HF;
+    float* Hn = sH + ((it & 1) ^ 1) * PW2_HF;
+    float* Pc = sP + (it & 1) * PW2_PF;
+    const float* Pp = sP + ((it & 1) ^ 1) * PW2_PF;
+    const float* hb = Hc + col * PW2_LD + 4 * half;
+#define PW2_HB(f_) (*reinterpret_cast<const f32x4*>(hb + 8 * (f_)))
+    f32x4 bq0 = PW2_HB(0), bq1 = PW2_HB(1), bq2;
+    // requests of the next tile (its h1 is formed in the middle of this tile's stream) and the records of the one after it
+    int c2, n2;
+    {
+      PW2_REQUEST(c1, n1);
+      const int e1 = PW2_EDGE(t + 1);
+      gv = *reinterpret_cast<const f32x4*>(a.geo + (size_t)e1 * 8 + 4 * half);
+      const int e2 = PW2_EDGE(t + 2);
+      c2 = a.edge_c[e2]; n2 = a.edge_n[e2];
+    }
+    f32x16 acc;
+    float4 hrow;
+#define PW2_MMA4(bq_, w_, first_)                                                                       \
+  do {                                                                                                  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((w_).x, (bq_).x, (first_) ? zero16() : acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((w_).y, (bq_).y, acc, 0, 0, 0);                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((w_).z, (bq_).z, acc, 0, 0, 0);                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((w_).w, (bq_).w, acc, 0, 0, 0);                          \
+  } while (0)
+    // ---- fc2: 32 fragments of 4 MFMAs; the h1 operand two fragments ahead; the rest of the tile's work in between
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+      if (f + 2 < 32) { if (f % 3 == 0) bq2 = PW2_HB(f + 2); else if (f % 3 == 1) bq0 = PW2_HB(f + 2); else bq1 = PW2_HB(f + 2); }
+      if (f == 3) {
+        // the previous tile's fc3: sum of the eight waves' partial sums, bias, ReLU, 8 bytes per thread (a tile's 4 KB in a row);
+        // the first tile of the range has no predecessor: a slack row takes the store
+        const float* pp = Pp + er * D_E + j0;
+        float2 s_ = *reinterpret_cast<const float2*>(pp);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); s_.x += v.x; s_.y += v.y; }
+        const int ep = it > 0 ? e0 - PW2_T : a.n_edge + 32;
+        *reinterpret_cast<float2*>(a.pw + (size_t)(ep + er) * D_E + j0) = make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f));
+      }
+      // training: four whole h1 rows per wave, read from LDS one fragment before they are stored
+      if (TRAINING && f >= 7 && f < 11) *reinterpret_cast<float4*>(a.h1 + (size_t)(e0 + 4 * wave + (f - 7)) * D_H + 4 * lane) = hrow;
+      if (TRAINING && f >= 6 && f < 10) hrow = *reinterpret_cast<const float4*>(Hc + (4 * wave + (f - 6)) * PW2_LD + 4 * lane);
+      if (f == 16) PW2_FC1(Hn);
+      if (f == 24) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w3r[r] = w3p[crow(r, 0) * D_E];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b2q[g] = *reinterpret_cast<const float4*>(b2p + 8 * g);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (f % 3 == 0) PW2_MMA4(bq0, w2r[f], f == 0); else if (f % 3 == 1) PW2_MMA4(bq1, w2r[f], false); else PW2_MMA4(bq2, w2r[f], false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- bias, ReLU, h2 rows, this wave's K = 32 slice of fc3
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc[4 * g + 0] = relu_bits(acc[4 * g + 0] + b2q[g].x); acc[4 * g + 1] = relu_bits(acc[4 * g + 1] + b2q[g].y);
+      acc[4 * g + 2] = relu_bits(acc[4 * g + 2] + b2q[g].z); acc[4 * g + 3] = relu_bits(acc[4 * g + 3] + b2q[g].w);
+    }
+    if (TRAINING) {
+      float* d_ = a.h2 + (size_t)(e0 + col) * D_H + 32 * wave + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(d_ + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    }
+    f32x16 pacc = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], w3r[r], pacc, 0, 0, 0);
+    {
+      float* d_ = Pc + (wave * PW2_T + 4 * half) * D_E + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
+    }
+    c1 = c2; n1 = n2;
+    pw2_barrier();
+  }
+  {
+    // the last tile's fc3
+    const int itl = t1 - t0 - 1;
+    const float* pp = sP + (itl & 1) * PW2_PF + er * D_E + j0;
+    float2 s_ = *reinterpret_cast<const float2*>(pp);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); s_.x += v.x; s_.y += v.y; }
+    *reinterpret_cast<float2*>(a.pw + (size_t)((t1 - 1) * PW2_T + er) * D_E + j0) = make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f));
+  }
+#undef PW2_EDGE
+#undef PW2_REQUEST
+#undef PW2_FC1
+#undef PW2_HB
+#undef PW2_MMA4
+}
 
 // ------------------------------------------------------------------------------------------
 // edge_fwd: one wave = one 32-edge tile at a time, 4 independent waves per workgroup sharing the
@@ -1055,8 +1258,20 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training; a.claim = buf->scratch_i + N;
     GNET_TRACE_SET(a, "PW_FWD", true);
     // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
-    GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<pw_grid, 512, kPwFwdSmem, s>>>(a));
+    a.w3 = params + L.pw3;
+    if (getenv("GNET_PW_FWD_OLD")) {       // (A/B during round 5)
+      HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
+      GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<pw_grid, 512, kPwFwdSmem, s>>>(a));
+    } else {
+      const int grid2 = min((E + PW2_T - 1) / PW2_T, 256);
+      if (training) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
+        GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd2<true><<<grid2, 512, kPwFwd2Smem, s>>>(a));
+      } else {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
+        GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd2<false><<<grid2, 512, kPwFwd2Smem, s>>>(a));
+      }
+    }
   }
 
   const int ntile_n = (N + 31) / 32;
