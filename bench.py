@@ -296,7 +296,9 @@ def main():
     def step():
         net.run(batch)
         if exchange is not None:
-            exchange(net.grads)
+            # nothing waits here: the next step's graph build, forward pass and loss run beside the collective, its backward
+            # pass (the next writer of the buffer) queues behind the event
+            net.defer_backward_until(exchange.launch(net.grads))
 
     for _ in range(args.warmup):
         step()

@@ -6,9 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgossipnet_hip.so")
+from .build import LIB as LIB_PATH     # libgossipnet_hip.so (a GNET_TRACE / GNET_EXTRA_FLAGS measurement process: its own probe library)
 GNET_MAX_BLOCKS = 64
-ABI_VERSION = 5          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
+ABI_VERSION = 6          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 _ERR = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported configuration",
@@ -59,7 +59,7 @@ class gnet_buffers(C.Structure):
 EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_graph_transpose", "gnet_workspace_bytes", "gnet_plan",
            "gnet_forward", "gnet_loss", "gnet_match_prepare", "gnet_backward", "gnet_backward_prepare", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
-           "gnet_profiler_destroy", "gnet_profiler_set_stride", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
+           "gnet_profiler_destroy", "gnet_profiler_set_stride", "gnet_profiler_begin", "gnet_profiler_end", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
            "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou", "gnet_abi_version", "gnet_abi_sizes"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
@@ -163,6 +163,10 @@ def load():
     lib.gnet_profiler_read.argtypes = [vp, P(C.c_double), P(i32)]
     lib.gnet_profiler_set_stride.restype = C.c_int
     lib.gnet_profiler_set_stride.argtypes = [vp, i32]
+    lib.gnet_profiler_begin.restype = C.c_int
+    lib.gnet_profiler_begin.argtypes = [vp, i32, vp]
+    lib.gnet_profiler_end.restype = C.c_int
+    lib.gnet_profiler_end.argtypes = [vp, i32, vp]
     lib.gnet_profiler_destroy.restype = C.c_int
     lib.gnet_profiler_destroy.argtypes = [vp]
     lib.gnet_adam_step.restype = C.c_int

@@ -5,7 +5,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libgossipnet_hip.so")
+# measurement builds (probe variants of a kernel, workgroup time stamps) never overwrite the shipped library: they are
+# written to -- and, by a process with the same environment, loaded from -- a library of their own
+PROBE_BUILD = bool(os.environ.get("GNET_EXTRA_FLAGS") or os.environ.get("GNET_TRACE"))
+LIB = os.path.join(HERE, "libgossipnet_hip_probe.so" if PROBE_BUILD else "libgossipnet_hip.so")
 SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "fc.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -83,10 +86,9 @@ def _build_locked(force, verbose, objdir):
         raise RuntimeError("hipcc failed")
     # (reached only when the library's recorded hash differs from this source / flag set: always link -- the objects of
     # this flag set may all be current while the library was linked from another set's)
-    if True:
-        tmp = LIB + ".tmp.%d" % os.getpid()
-        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
-        os.replace(tmp, LIB)                 # a process that has the old library mapped keeps its inode
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+    os.replace(tmp, LIB)                     # a process that has the old library mapped keeps its inode
     with open(LIB + ".srchash", "w") as f:
         f.write(source_hash())
     return LIB

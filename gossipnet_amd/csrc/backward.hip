@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     dma_rows32(smem, a.h1, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
     dma_rows32(smem + 32 * LD256, a.h2, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
     PB_PREFETCH_D3((int)blockIdx.x);
-    if (((int)blockIdx.x + G) < ntiles) PB_LOAD_ROWIDS(((int)blockIdx.x + G));
+    PB_LOAD_ROWIDS(min((int)blockIdx.x + G, ntiles - 1));
   }
   drain_vmem_before_loop();
   int it = 0;
@@ -760,21 +760,44 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     if (it == 5) GSTAMP(a, 7);
     __syncthreads();
     if (it == 5) GSTAMP(a, 8);
-    // next tile's h1/h2 -> the other buffer (last read during the previous tile).  Issued here: the
-    // d W2 phase below touches only LDS, so the in-order vmcnt never waits on this copy.
-    if (t + G < ntiles) {
-      dma_rows32_ids(nH1, a.h1, dr, wave, lane);
-      dma_rows32_ids(nH1 + 32 * LD256, a.h2, dr, wave, lane);
-      PB_PREFETCH_D3(t + G);
-      // (the row ids of the tile after the next one: UNCONDITIONAL -- past the list PB_ROW re-reads its last entry -- and pinned
-      // behind the uses of the old ids: a conditional or re-ordered load of a loop-carried value goes through a temporary
-      // register, and the copy out of it made the compiler wait for every request just issued: vmcnt(0), 2.3 of a tile's 21.9 us)
-      __builtin_amdgcn_sched_barrier(0);
-      PB_LOAD_ROWIDS(t + 2 * G);
+    // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns): 16 row pairs x 8 MFMAs, the operands of pair kk + 1
+    // requested in front of the MFMAs of pair kk (pinned).  Everything the NEXT tile reads from HBM is requested INSIDE this
+    // stream, one request per row pair: the eight h1 / h2 row copies into the other buffer (last read during the previous tile),
+    // the d3 sources, the row ids of the tile after the next.  (Issued as a block right behind the barrier above they cost
+    // every wave ~1.3 us -- 8 LDS-DMA issues with their scalar address set-up, ten loads -- with no MFMA in the pipe of any
+    // SIMD: all eight waves are there at the same time.)  Unconditional: past the last tile the clamped rows are copied into a
+    // buffer nobody reads; in-order vmcnt still never waits on them before the d_h1 stores of this tile are issued.
+    {
+      const int tn = min(t + G, ntiles - 1), tnn = min(t + 2 * G, ntiles - 1);
+      const float* X = sH1 + 32 * wave; const float* Y = sH2;
+      float xa = X[half * LD256 + col], yb[8];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) yb[n] = Y[half * LD256 + 32 * n + col];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * (kk + 1 < 16 ? kk + 1 : kk) + half;
+        const float xn = X[row * LD256 + col];
+        float yn[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) yn[n] = Y[row * LD256 + 32 * n + col];
+        if (kk < 8) {
+          const int q_ = kk & 3;
+          const int rq = __builtin_amdgcn_readfirstlane(dr[q_]);
+          const char* src = reinterpret_cast<const char*>((kk < 4 ? a.h1 : a.h2) + (size_t)rq * D_H) + 16u * (unsigned)lane;
+          float* dst = nH1 + (kk < 4 ? 0 : 32 * LD256) + (wave * 4 + q_) * LD256;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        if (kk == 8) PB_PREFETCH_D3(tn);
+        if (kk == 9) PB_LOAD_ROWIDS(tnn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) aW2[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, yb[n], aW2[0][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        xa = xn;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) yb[n] = yn[n];
+      }
     }
-    if (it == 5) GSTAMP(a, 9);
-    // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
-    mma_xty_pipelined<8>(aW2, sH1 + 32 * wave, LD256, sH2, LD256, lane);
     if (it == 5) GSTAMP(a, 10);
     // d(fc1 pre) tile w = (d2 . W2^T) * (h1 > 0)
     {
@@ -791,6 +814,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
     if (it == 5) GSTAMP(a, 12);
   }
   GSTAMP(a, 15);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the last tile's look-ahead copies: nothing may be in flight into LDS at exit)
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
 #pragma unroll
   for (int j = 0; j < 8; ++j) store_acc(ar + a.o_w2 + (size_t)(32 * wave) * D_H + 32 * j, D_H, aW2[0][j], lane);
@@ -1038,7 +1062,7 @@ extern "C" int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* s
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf) return GNET_ERR_INVALID;
-  if (!buf->d_pw || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows) return GNET_ERR_INVALID;   // plan(training >= 1)
+  if (!buf->d_pw || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows || !buf->tpos || !buf->wrow) return GNET_ERR_INVALID;   // plan(training >= 1)
   const int E = (int)shape->n_edge;
   if (shape->n_det == 0 || E == 0) return GNET_OK;
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;

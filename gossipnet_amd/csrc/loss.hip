@@ -299,7 +299,7 @@ MatchWs carve_match(void* ws, int n_det) {
 
 int run_matching(const float* iou, const long long* anno_off, const int* det_off, const int* gt_off,
                  const unsigned char* ignore, const float* score, int n_det, int n_gt, int n_img, void* ws, float* labels,
-                 float* weights, int* assign, bool have_cand, hipStream_t s) {
+                 float* weights, int* assign, bool have_cand, hipStream_t s, void* prof = nullptr) {
   if (n_gt > kMaxGt) return GNET_ERR_UNSUPPORTED;
   const int cap = (max(n_gt, 1) + 63) & ~63;
   const size_t lds = (size_t)cap * 5;
@@ -308,9 +308,9 @@ int run_matching(const float* iou, const long long* anno_off, const int* det_off
   if (!have_cand)
     anno_rows<false, true><<<(n_det + 3) / 4, 256, 0, s>>>(nullptr, nullptr, det_off, nullptr, ignore, nullptr, gt_off, anno_off, n_det, n_img, 0,
                                                             const_cast<float*>(iou), w.k1, w.k2, w.ncand, w.cfirst);
-  match_rank<<<(n_det + RANK_DETS - 1) / RANK_DETS, 256, 0, s>>>(score, det_off, n_det, n_img, w.order);
-  match_greedy<<<n_img, 64, lds, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
-                                      labels, weights, assign, cap);
+  GNET_LAUNCH(prof, GNET_K_LOSS, s, match_rank<<<(n_det + RANK_DETS - 1) / RANK_DETS, 256, 0, s>>>(score, det_off, n_det, n_img, w.order));
+  GNET_LAUNCH(prof, GNET_K_LOSS, s, match_greedy<<<n_img, 64, lds, s>>>(iou, anno_off, det_off, gt_off, ignore, w.order, w.k1, w.k2, w.ncand, w.cfirst,
+                                                                        labels, weights, assign, cap));
   return launch_status();
 }
 
@@ -369,9 +369,10 @@ extern "C" int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shap
   const MatchWs w = carve_match((char*)buf->match_ws + 1024, N);
   // det_anno_iou and the candidate records in ONE pass (one wave per detection; an image without ground truth has
   // empty rows and gets the "no candidate" records)
-  anno_rows<true, true><<<(N + 3) / 4, 256, 0, s>>>((const float4*)in->dets, in->det_classes, in->det_off, (const float4*)in->gt_boxes,
-                                                    in->gt_crowd, in->gt_classes, in->gt_off, (const long long*)in->anno_off, N,
-                                                    shape->n_img, cfg->num_classes > 1, buf->det_anno_iou, w.k1, w.k2, w.ncand, w.cfirst);
+  GNET_LAUNCH(buf->profiler, GNET_K_LOSS, s,
+              (anno_rows<true, true><<<(N + 3) / 4, 256, 0, s>>>((const float4*)in->dets, in->det_classes, in->det_off, (const float4*)in->gt_boxes,
+                                                                 in->gt_crowd, in->gt_classes, in->gt_off, (const long long*)in->anno_off, N,
+                                                                 shape->n_img, cfg->num_classes > 1, buf->det_anno_iou, w.k1, w.k2, w.ncand, w.cfirst)));
   return launch_status();
 }
 
@@ -393,12 +394,13 @@ extern "C" int gnet_loss(const gnet_config* cfg, const gnet_shape* shape, const 
   }
   st = run_matching(buf->det_anno_iou, (const long long*)in->anno_off, in->det_off, in->gt_off, in->gt_crowd,
                     buf->prediction, N, shape->n_gt, shape->n_img, (char*)buf->match_ws + 1024, buf->labels, buf->weights,
-                    buf->det_gt_matching, true, s);
+                    buf->det_gt_matching, true, s, buf->profiler);
   if (st != GNET_OK) return st;
-  loss_kernel<<<shape->n_img, LOSS_THREADS, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,
-                                           in->det_off, in->gt_off, in->gt_crowd, in->gt_classes, class_weights,
-                                           cfg->num_classes, cfg->normalize_loss, cfg->loss_multiplyer, grad_scale,
-                                           buf->loss, buf->d_logits);
+  GNET_LAUNCH(buf->profiler, GNET_K_LOSS, s,
+              loss_kernel<<<shape->n_img, LOSS_THREADS, 0, s>>>(buf->prediction, buf->labels, buf->weights, buf->det_gt_matching,
+                                                                in->det_off, in->gt_off, in->gt_crowd, in->gt_classes, class_weights,
+                                                                cfg->num_classes, cfg->normalize_loss, cfg->loss_multiplyer, grad_scale,
+                                                                buf->loss, buf->d_logits));
   return launch_status();
 }
 

@@ -160,6 +160,24 @@ extern "C" int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count
   return GNET_OK;
 }
 
+// Brackets for launches whose entry points carry no gnet_buffers (the graph build: gnet_graph_count / _fill / _transpose take
+// plain pointers): the caller opens a scope in front of the call and closes it behind it, on the stream it passes to the call.
+extern "C" int gnet_profiler_begin(void* profiler, int32_t cls, gnet_stream_t stream) {
+  GnetProfiler* p = (GnetProfiler*)profiler;
+  if (!p || cls < 0 || cls >= GNET_KCLASS_COUNT) return -1;
+  if (!((p->mask >> cls) & 1u) || (p->seen[cls]++ % p->stride) != 0 || p->n >= p->cap) return -1;
+  const int idx = p->n++;
+  p->cls[idx] = cls;
+  (void)hipEventRecord(p->ev0[idx], (hipStream_t)stream);
+  return idx;
+}
+
+extern "C" int gnet_profiler_end(void* profiler, int32_t idx, gnet_stream_t stream) {
+  GnetProfiler* p = (GnetProfiler*)profiler;
+  if (!p || idx < 0 || idx >= p->n) return GNET_OK;
+  return hipEventRecord(p->ev1[idx], (hipStream_t)stream) == hipSuccess ? GNET_OK : GNET_ERR_HIP;
+}
+
 extern "C" int gnet_profiler_set_stride(void* profiler, int32_t stride) {
   GnetProfiler* p = (GnetProfiler*)profiler;
   if (!p || stride < 1) return GNET_ERR_INVALID;

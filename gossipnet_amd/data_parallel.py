@@ -28,18 +28,24 @@ def shard_images(images, rank, world, costs=None, per_rank=None):
 
 
 class GradientExchange(object):
-    """The one collective of a data-parallel step, issued on a side stream behind the backward pass: the stream the
-    step's kernels run on only waits for it where the summed gradient is consumed (the optimizer update, or the next
-    step's backward which overwrites the buffer).  `timed=True` brackets every all-reduce with events on the side stream
-    (they see the collective itself, not the step); read_us() returns (mean microseconds per all-reduce, count) and resets.
+    """The one collective of a data-parallel step, issued on a side stream behind the backward pass.
+
+    launch(flat_grads) queues the all-reduce behind everything the compute stream has issued so far (reduce_partials wrote the
+    buffer) and records `done` behind it; NOTHING is made to wait there.  wait() makes the current stream wait for `done`: call
+    it where the summed gradient is consumed -- train_step() does, in front of the optimizer update; bench.py hands `done` to
+    Gnet.defer_backward_until(), so that step i + 1's graph build, forward pass and loss (which do not touch the gradient
+    buffer) run beside step i's all-reduce and only its backward pass (which overwrites the buffer) queues behind it.
+    `timed=True` brackets every all-reduce with events on the side stream (they see the collective itself, not the step);
+    read_us() returns (mean microseconds per all-reduce, count) and resets; at most `keep` samples are held.
     Used by train_step(..., dist=...) and by bench.py --gpus N: the same code path."""
 
-    def __init__(self, dist, device, group=None, timed=False):
+    def __init__(self, dist, device, group=None, timed=False, keep=1024):
         self.dist, self.group, self.device = dist, group, torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
-        self.timed, self._events = timed, []
+        self.timed, self._events, self._keep = timed, [], int(keep)
+        self.done = None
 
-    def __call__(self, flat_grads):
+    def launch(self, flat_grads):
         cur = torch.cuda.current_stream(self.device)
         self.side.wait_stream(cur)                       # behind reduce_partials
         with torch.cuda.stream(self.side):
@@ -50,7 +56,22 @@ class GradientExchange(object):
             if self.timed:
                 e1.record(self.side)
                 self._events.append((e0, e1))
-        cur.wait_stream(self.side)
+                if len(self._events) > self._keep:
+                    del self._events[:len(self._events) - self._keep]
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+        return self.done
+
+    def wait(self):
+        """The current stream waits for the last launched all-reduce (no-op when none is pending)."""
+        if self.done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done)
+            self.done = None
+
+    def __call__(self, flat_grads):
+        """launch + wait: the summed gradient is usable by whatever the current stream queues next."""
+        self.launch(flat_grads)
+        self.wait()
         return flat_grads
 
     def read_us(self):

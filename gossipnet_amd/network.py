@@ -424,6 +424,11 @@ class Gnet(object):
         """`training` argument of the C ABI: 0 inference, 1 training, 2 training + per-block pw_fc1 activations kept."""
         return 0 if not training else (2 if self.keep_edge_activations else 1)
 
+    def defer_backward_until(self, event):
+        """The next backward pass (the next writer of `grads`) waits for `event` on its stream -- the graph build, the forward
+        pass and the loss of that step do not.  bench.py --gpus N hands the all-reduce's completion event here."""
+        self._grads_busy = event
+
     def begin(self, batch=None):
         """First, asynchronous half of run(): feed + neighbour counting.  Several Gnets (sharing variables
         through reuse=True, each on its own stream) can be begun before any of them is finished, so that the
@@ -474,6 +479,11 @@ class Gnet(object):
             _lib.check(lib.gnet_loss(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.class_weights),
                                      float(self.grad_scale), C.byref(buf), 1, s), "gnet_loss")
             if backward:
+                if getattr(self, "_grads_busy", None) is not None:
+                    # a collective launched on another stream still reads the gradient buffer of the previous step
+                    # (data_parallel.GradientExchange.launch): everything up to here ran beside it
+                    torch.cuda.current_stream(self.device).wait_event(self._grads_busy)
+                    self._grads_busy = None
                 # (the main stream waits for the winner lists inside gnet_backward, where they are first needed)
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                              C.byref(buf), _vp(self.grads), 1, C.c_void_p(self._bprep_done.cuda_event), s),

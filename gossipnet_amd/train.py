@@ -104,7 +104,9 @@ def train_step(net, opt, batch, lr, dist=None):
         if ex is None or ex.dist is not dist:
             from .data_parallel import GradientExchange
             ex = net._grad_exchange = GradientExchange(dist, net.device)
-        ex(net.grads)
+        ex.launch(net.grads)
     with torch.cuda.device(net.device):
+        if dist is not None:
+            ex.wait()                    # where the summed gradient is consumed
         opt.apply_gradients(lr)
     return net.loss

@@ -301,6 +301,11 @@ int gnet_profiler_read(void* profiler, double* ms_sum, int32_t* count);
  * stream's time, so a timed region that wants a kernel's average duration samples its launches instead of bracketing all. */
 int gnet_profiler_set_stride(void* profiler, int32_t stride);
 int gnet_profiler_destroy(void* profiler);
+/* Scopes for the entry points that take no gnet_buffers (gnet_graph_count / _fill / _transpose): gnet_profiler_begin records the
+ * opening event of a launch of class `cls` on `stream` and returns a scope index (-1: class not selected / not sampled / pool
+ * full), gnet_profiler_end(index) records the closing event on the same stream (index -1: no-op). */
+int gnet_profiler_begin(void* profiler, int32_t cls, gnet_stream_t stream);
+int gnet_profiler_end(void* profiler, int32_t idx, gnet_stream_t stream);
 
 /* Version / build info string (static storage). */
 const char* gnet_version(void);
@@ -314,7 +319,7 @@ const char* gnet_version(void);
  * offsetof(gnet_buffers, match_ws_bytes), offsetof(gnet_buffers, start_feat) and returns GNET_KCLASS_COUNT.
  * A binding compares both with its own mirror before the first call and refuses to go on when they differ
  * (a shifted gnet_buffers would hand the kernels wrong device pointers without any error). */
-#define GNET_ABI_VERSION 5
+#define GNET_ABI_VERSION 6
 int gnet_abi_version(void);
 int gnet_abi_sizes(size_t out[8]);
 
