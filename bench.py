@@ -18,7 +18,7 @@ The JSON line also carries
                 against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) = `frac`; `reference_formulation`
                 = the same with the FLOPs of the reference's dense per-edge formulation, which a kernel can
                 exceed 1.0 on by not executing them; `traffic` = HBM bytes per launch from the separate rocprofv3
-                --pmc passes (profiles/r04_traffic.json), reported only while that file was collected from the same
+                --pmc passes (profiles/r05_traffic.json), reported only while that file was collected from the same
                 kernel sources (hash), else null; `mfma_busy` (per MFMA kernel, same file and gate) =
                 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the launch's GRBM_GUI_ACTIVE cycles) of the --pmc pass
   roi_pool      the RoiPool / RoiPoolGrad ops at the reference's shape (R=2000 rois, 38x63x1024 map, 7x7 bins):
@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 
 
 def kernel_source_hash():
@@ -77,11 +77,11 @@ def nominal_flops(cls, E, N, C):
 def executed_mfma_flops(cls, E, N, winners_per_block, pw_rows):
     """MFMA FLOPs one launch really issues (4096 per v_mfma_f32_32x32x2_f32), from the kernels' tile loops:
     edge_fwd_w 96 MFMAs per 32 edges (pw_fc1 split P.Wp + rc[c] + rn[n]); edge_bwd_w 160 MFMAs per 32 winner rows;
-    pw_fwd fc2 + fc3 (fc1 runs on the vector ALU through its one-hot structure); pw_bwd_main 4 GEMMs per listed row."""
+    pw_fwd2 fc2 + fc3 + fc1's K = 8 geometry product (the 2C score columns are two table rows per edge); pw_bwd_main 4 GEMMs per listed row."""
     table = {
         "edge_fwd": 96 * 4096.0 * E / 32,
         "edge_bwd": 160 * 4096.0 * winners_per_block / 32,
-        "pw_fwd": 2.0 * E * (256 * 256 + 256 * 32),
+        "pw_fwd": 2.0 * E * (8 * 256 + 256 * 256 + 256 * 32),      # fc1's geometry term (K = 8 incl. the zero pad) + fc2 + fc3
         "pw_bwd_main": 2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32),
         "node_fwd": 2.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128),
         "node_bwd": 4.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128),
@@ -138,12 +138,14 @@ def cpu_baseline(make, num_classes, num_blocks, budget_s):
         t0 = time.perf_counter()
         orc.forward_backward(make(1, 300))
         spent += time.perf_counter() - t0
-        for nt in (min(16, all_threads), 1, all_threads):        # the usually fastest first: it always gets its two runs
+        # the usually fastest first (it always gets its two repetitions), then ALL hardware threads torch offers (SURVEY 8d asks for
+        # it; one repetition: ~15 s on 2 x EPYC 9575F), then one thread
+        for nt in (min(16, all_threads), all_threads, 1):
             if any(r["threads"] == nt for r in runs) or (runs and spent > budget_s):
                 continue
             torch.set_num_threads(nt)
             reps = []
-            for _ in range(2):
+            for _ in range(1 if nt == all_threads and nt > 16 else 2):
                 if spent > 2.0 * budget_s and reps:
                     break
                 t0 = time.perf_counter()
@@ -159,18 +161,50 @@ def cpu_baseline(make, num_classes, num_blocks, budget_s):
     runs.sort(key=lambda r: r["threads"])
     best = max(runs, key=lambda r: r["value"])
     n, e = im["dets"].shape[0], len(out["neighbor_pair_idxs"])
-    return {"value": best["value"], "unit": "detections/sec", "cores": best["threads"], "kind": "port",
+    cpu = lscpu_model()
+    try:
+        host_cores = int(cpu["sockets"]) * int(cpu["cores_per_socket"])
+    except Exception:      # noqa: BLE001
+        host_cores = None
+    return {"value": best["value"], "unit": "detections/sec", "cores": best["threads"], "host_cores": host_cores,
+            "host_threads": os.cpu_count(), "torch_threads_default": all_threads, "kind": "port",
             "sample": "1 image of the bench workload (N=%d, E/N=%.1f), fwd+bwd, torch-CPU fp32 oracle; one warm-up on a 300-detection "
                       "image, then per thread count the faster of up to 2 repetitions; %.1f s in total" % (n, e / n, spent),
-            "runs": runs, "cpu": lscpu_model()}
+            "cores_note": "`cores` = the thread count of the fastest run (`value`); `runs` lists every count tried, the host's physical cores "
+                          "are `host_cores` (the op mix -- gathers, segment reductions, small GEMMs -- does not scale with torch's intra-op pool)",
+            "runs": runs, "cpu": cpu}
+
+
+def rccl_evidence(log_pattern):
+    """What RCCL itself logged about this rank's communicator (NCCL_DEBUG=INFO, INIT / GRAPH subsystems, written to
+    NCCL_DEBUG_FILE): the rank / world size / device / bus id it reports, the library version line, the ring or tree lines."""
+    import glob
+    import re
+    if not log_pattern:
+        return {"note": "backend is not nccl: no RCCL log"}
+    files = glob.glob(log_pattern.replace("%p", "*").replace("%h", "*"))
+    text = ""
+    for f in files:
+        try:
+            text += open(f, errors="replace").read()
+        except OSError:
+            pass
+    if not text:
+        return {"note": "no RCCL log found", "pattern": log_pattern}
+    ranks = sorted({(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"rank (\d+) nranks (\d+)", text)})
+    version = re.search(r"(RCCL version[^\n]*|NCCL version[^\n]*)", text)
+    rings = [l.split("NCCL INFO", 1)[-1].strip() for l in text.splitlines() if re.search(r"(Ring \d+ :|Channel \d+/\d+ :|Trees \[)", l)][:8]
+    devs = sorted({m.group(0) for m in re.finditer(r"busId [0-9a-fx]+", text)})
+    return {"version": version.group(1).strip() if version else None, "rccl_ranks_seen": [{"rank": r, "nranks": n} for r, n in ranks],
+            "bus_ids": devs[:16], "rings": rings, "init_complete": "Init COMPLETE" in text, "log_lines": len(text.splitlines())}
 
 
 def time_config(dev, classes, blocks, dets, images, preset, steps, warmup, inference=False):
     """detections/s of one configuration on one GPU (no kernel timing)."""
-    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.network import Gnet, DeviceBatch
     from gossipnet_amd.synthetic import make_image
-    reset_cfg()
+    experiment_cfg()
     cfg.gnet.num_blocks = blocks
     net = Gnet(classes, device=dev)
     imgs = [make_image(dets, classes, seed=1000 + i, preset=preset) for i in range(images)]
@@ -242,7 +276,7 @@ def main():
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--blocks", type=int, default=16)
     ap.add_argument("--preset", default="dense", choices=["dense", "coco_like"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
@@ -259,20 +293,28 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    rccl_log = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            # self-evidencing N > 1 runs: RCCL's own INIT log of this rank (ranks / devices / rings it set up) goes to a file that
+            # rank 0 parses into `distributed.rccl_*` below
+            import tempfile
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            rccl_log = os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(tempfile.gettempdir(), "gnet_rccl_%d.%%p.log" % os.getpid()))
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=dev)
         else:
             dist_mod.init_process_group(backend)
         dist = dist_mod
 
-    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.network import Gnet, DeviceBatch
     from gossipnet_amd.synthetic import make_image
     from gossipnet_amd.data_parallel import GradientExchange, broadcast_parameters, shard_images
-    reset_cfg()
+    experiment_cfg()
     cfg.gnet.num_blocks = args.blocks
     net = Gnet(args.classes, device=dev)
     if dist is not None:
@@ -395,7 +437,7 @@ def main():
                         traffic = tf["kernels"].get(cls, {}).get("hbm_bytes")
                         pmc = tf["kernels"]
                     else:
-                        note = "profiles/r04_traffic.json was collected from other kernel sources / another workload: not reported"
+                        note = "profiles/r05_traffic.json was collected from other kernel sources / another workload: not reported"
                 # `achieved` counts the FLOPs the algorithm needs in this kernel's formulation (= the MFMA FLOPs it issues:
                 # e.g. edge_fwd computes P.Wp + rc[c] + rn[n] per edge, the per-node products r.Wc / r.Wn live in
                 # node_fwd); the reference's dense per-edge formulation is reported beside it -- a kernel
@@ -432,7 +474,7 @@ def main():
             roofline["mfma_kernels"] = mfma_kernels
             roofline["mfma_busy"] = pmc.get(roofline["kernel"], {}).get("mfma_busy")
             roofline["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per launch, from the separate rocprofv3 "
-                                          "--pmc pass (profiles/r04_traffic.json, same kernel sources); null = no current counters")
+                                          "--pmc pass (profiles/r05_traffic.json, same kernel sources); null = no current counters")
         # whole-step executed MFMA FLOPs
         ex_total = 0.0
         for k_, c_ in counts.items():
@@ -483,7 +525,37 @@ def main():
         e1.record(); e1.synchronize()
         fill_ms = e0.elapsed_time(e1) / 5
         fill_bytes = E * 32 * 4 + (args.blocks + 1) * ((E + 63) // 64 + 256) * 8 + args.blocks * ((E + 64 + 63) // 64 * 64) * 4   # d_pw, winner maps, tpos
-        side = {"zeroing_ms_alone": round(fill_ms, 4), "zeroing_bytes": fill_bytes, "gb_per_s_alone": round(fill_bytes / fill_ms / 1e6, 1),
+        # graph_transpose (the reversed-pair permutation, a per-edge binary search): alone on the device, and the step with it issued
+        # beside pw_fwd (default) against behind the forward pass (Gnet.transpose_after_forward): the A/B of its placement
+        e0.record()
+        for _ in range(5):
+            L_.check(net._lib.gnet_graph_transpose(net._buf.row_ptr, net._buf.edge_c, net._buf.edge_n, net._shape.n_edge, net._buf.edge_t, s_), "gnet_graph_transpose")
+        e1.record(); e1.synchronize()
+        transpose_ms = e0.elapsed_time(e1) / 5
+
+        def steps_ms(n_):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(n_):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / n_ * 1e3
+        net.enable_kernel_timing(classes=[], capacity=8)         # (no events inside these steps)
+        ab = {}
+        for rep in range(2):
+            for late in (False, True):
+                net.transpose_after_forward = late
+                steps_ms(2)
+                v_ = steps_ms(max(5, min(args.steps, 10)))
+                k_ = "after_forward" if late else "beside_pw_fwd"
+                ab[k_] = min(ab.get(k_, 1e9), v_)
+        net.transpose_after_forward = False
+        side = {"graph_transpose_ms_alone": round(transpose_ms, 4),
+                "graph_transpose_placement_ms_per_step": {k_: round(v_, 4) for k_, v_ in ab.items()},
+                "graph_transpose_note": "alone on the idle device / whole step (best of 2 x %d steps each) with the transposition issued on the side stream beside pw_fwd "
+                                        "(shipped) or behind the forward pass; its side-stream wall time beside pw_fwd is in kernel_ms_per_step['graph'] together "
+                                        "with graph_count (side stream, one step ahead) and graph_fill (main stream)" % max(5, min(args.steps, 10)),
+                "zeroing_ms_alone": round(fill_ms, 4), "zeroing_bytes": fill_bytes, "gb_per_s_alone": round(fill_bytes / fill_ms / 1e6, 1),
                 "note": "hipMemsetAsync of d_pw, the winner maps and tpos (-1) on the side stream beside pw_fwd; alone on the device it takes this "
                         "long; inside the step it overlaps pw_fwd (same step time whether issued there or after the forward pass)",
                 "winner_lists_ms_per_step": round(table.get("winner_lists", 0.0), 4),
@@ -537,7 +609,7 @@ def main():
                                                 % (net.params.numel(), net.params.numel() * 4 / 1e6),
                                   "allreduce_us_rank0": round(ar_us, 1) if ar_us is not None else None, "allreduce_samples": ar_n,
                                   "allreduce_us_max_over_ranks": max(r_["allreduce_us"] for r_ in per_rank),
-                                  "rccl": os.environ.get("NCCL_DEBUG") or "set NCCL_DEBUG=INFO to log the rings",
+                                  "rccl": rccl_evidence(rccl_log),
                                   "hsa_ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(gen, args.classes, args.blocks, args.cpu_seconds)

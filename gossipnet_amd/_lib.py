@@ -52,7 +52,7 @@ class gnet_buffers(C.Structure):
                 [(n, _PB) for n in ("block_feats", "blk_r", "blk_rc", "blk_rn", "blk_pm", "blk_q", "blk_rnb", "blk_h1", "blk_h2", "blk_parg")] +
                 [(n, C.c_void_p) for n in ("head1", "head2", "prediction", "det_anno_iou", "labels", "weights",
                                            "det_gt_matching", "loss", "d_logits", "d_x", "d_pc", "d_rc", "d_rn",
-                                           "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "tpos", "wrow", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +
+                                           "d_pw", "d_h1", "d_g1", "ewin", "wprefix", "wlist", "xmask", "tflag", "apos", "tpos", "wrow", "spos", "rl_scratch", "pw_rows", "w1_s", "w1_t", "packed_t", "arena", "scratch_i", "match_ws")] +
                 [("match_ws_bytes", C.c_size_t), ("arena_floats", C.c_size_t), ("profiler", C.c_void_p), ("start_feat", C.c_void_p)])
 
 

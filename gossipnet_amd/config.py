@@ -51,13 +51,13 @@ def _defaults():
     g.load_imfeats = False
     g.imfeat_dim = -1
     g.neighbor_feats = False
-    # the reference default is num_pwfeat_fc = 0 / pwfeat_narrow_dim = 64 (config.py:73,75); both shipped
-    # experiments override them (experiments/*/conf.yaml) and only that configuration is compiled.
-    g.num_pwfeat_fc = 3
+    # the reference's own defaults (config.py:73-77): no pairwise-feature MLP.  Both shipped experiments override them
+    # (experiments/*/conf.yaml: num_pwfeat_fc 3, pwfeat_narrow_dim 32, bias_const_init 0.01 / 0.1) -- see experiment_cfg().
+    g.num_pwfeat_fc = 0
     g.pwfeat_dim = 256
-    g.pwfeat_narrow_dim = 32
+    g.pwfeat_narrow_dim = 64
     g.weight_init = "xavier"
-    g.bias_const_init = 0.01
+    g.bias_const_init = 0.0
     g.pw_feat_multiplyer = 1.0
     return cfg
 
@@ -106,6 +106,32 @@ def cfg_from_file(filename, strict=False):
 
 
 def reset_cfg():
+    """Back to the reference's defaults (nms_net/config.py:10-79)."""
     d = _defaults()
     cfg.clear()
     cfg.update(d)
+
+
+# the Gnet hyper-parameters the two shipped experiments set in their conf.yaml (experiments/coco_multiclass/conf.yaml:18-24,
+# experiments/coco_person/conf.yaml:1-6) -- what a run started with `cfg_from_file(experiments/<name>/conf.yaml)` sees
+EXPERIMENTS = {
+    "coco_multiclass": {"gnet": {"num_pwfeat_fc": 3, "pwfeat_narrow_dim": 32, "bias_const_init": 0.01, "imfeat_dim": 1024,
+                                 "imfeats": False, "neighbor_feats": False},
+                        "train": {"pos_weight": 0.3, "max_num_detections": 600}},
+    "coco_person": {"gnet": {"num_pwfeat_fc": 3, "pwfeat_narrow_dim": 32, "bias_const_init": 0.1, "num_blocks": 1,
+                             "neighbor_feats": False},
+                    "train": {"pos_weight": 0.1, "max_num_detections": 600}},
+}
+
+
+def experiment_cfg(name="coco_multiclass", **gnet_overrides):
+    """reset_cfg() + the overrides of a shipped experiment's conf.yaml (+ cfg.gnet overrides of the caller): the configuration
+    BASELINE.json's numbers are quoted on.  Tests, bench.py and the tools start from here; `cfg` itself starts from the
+    reference's defaults, as `from nms_net import cfg` does."""
+    reset_cfg()
+    _merge_a_into_b(EXPERIMENTS[name], cfg)
+    for k, v in gnet_overrides.items():
+        if k not in cfg.gnet:
+            raise KeyError("{} is not a valid cfg.gnet key".format(k))
+        cfg.gnet[k] = v
+    return cfg

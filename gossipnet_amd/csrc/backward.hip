@@ -993,6 +993,47 @@ __global__ void __launch_bounds__(256) pw_w1_classrows(const PwW1Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// num_pwfeat_fc = 0: the 2C' score rows of a block's pw_fc1 (network.py:413-419 one-hot x score columns of the raw pairwise
+// features, read by pw_fc1 directly).  The gradient of row k (centre column of class k) is sum_{i : class_i = k} s_i *
+// (sum over i's own pairs of g1) = s_i d_rc[i]; of row C' + k: s_i * (sum over the pairs whose NEIGHBOUR is i of g1) =
+// s_i (d_rn[i] + g1[self pair of i]) -- gather_winners leaves the self pair out of d_rn (the neighbour FEATURES of a self pair
+// are zeroed, its score column is not).  Launched per block behind gather_winners; grid (2 C', chunks), one wave per workgroup,
+// lane = output column; members of the class are picked by a ballot over 64 detections at a time and added in index order.
+struct RawW1Args {
+  int n_det, cprime, multiclass, nchunks;
+  const float* d_rc; const float* d_rn; const float* g1c; const int* spos;
+  const float* scores; const int* classes; float mult;
+  float* arena; long long stride, o_w1;
+};
+
+__global__ void __launch_bounds__(64) raw_w1_classrows(const RawW1Args a) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const bool nb = r >= a.cprime;
+  const int k = nb ? r - a.cprime : r;
+  const int per = (a.n_det + a.nchunks - 1) / a.nchunks;
+  const int c0 = blockIdx.y * per, c1 = min(a.n_det, c0 + per);
+  float acc = 0.f;
+  for (int base = c0; base < c1; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < c1;
+    const float sc = valid ? a.scores[i] * a.mult : 0.f;
+    const bool member = valid && (a.multiclass ? a.classes[i] - 1 == k : true);
+    const int sp = (valid && nb) ? a.spos[i] : -1;
+    unsigned long long mask = __ballot(member);
+    while (mask) {
+      const int j = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float s_ = __shfl(sc, j);
+      const int spj = __shfl(sp, j);
+      float v = (nb ? a.d_rn : a.d_rc)[(size_t)(base + j) * D_P + lane];
+      if (spj >= 0) v += a.g1c[(size_t)spj * D_P + lane];
+      acc = fmaf(s_, v, acc);
+    }
+  }
+  a.arena[(size_t)blockIdx.y * a.stride + a.o_w1 + (size_t)r * D_P + lane] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // grads[p] = sum over the n(p) partial copies arena[k][p], k ascending.
 struct ReduceArgs {
   const float* arena; long long stride; long long total;
@@ -1001,6 +1042,8 @@ struct ReduceArgs {
   long long pw_end;       // end of the pw-MLP parameters
   long long blk_sz; int nblocks;
   int n_w1c, n_w1, n_pw, n_edge, n_node, n_head;
+  int kp;                 // pairwise rows of a block's pw_fc1 (32; 2C'+7 with num_pwfeat_fc = 0)
+  int cls_rows, n_cls;    // of those, leading score rows written by raw_w1_classrows (n_cls partial copies); 0 with a pw-MLP
   float* grads;
 };
 
@@ -1021,9 +1064,9 @@ __global__ void __launch_bounds__(256) reduce_partials(const ReduceArgs a) {
     else if (p < a.pw_end + a.blk_sz * a.nblocks) {
       const long long q = (p - a.pw_end) % a.blk_sz;
       const long long w1 = D_S * D_R + D_R;                       // start of pw_fc1 weights
-      const long long w2 = w1 + (D_E + 2 * D_R) * D_P + D_P;      // start of pw_fc2 weights
-      const bool edge = (q >= w1 && q < w1 + D_E * D_P) || (q >= w2 && q < w2 + D_P * D_P + D_P);
-      n = edge ? a.n_edge : a.n_node;
+      const long long w2 = w1 + (long long)(a.kp + 2 * D_R) * D_P + D_P;      // start of pw_fc2 weights
+      const bool edge = (q >= w1 + (long long)a.cls_rows * D_P && q < w1 + (long long)a.kp * D_P) || (q >= w2 && q < w2 + D_P * D_P + D_P);
+      n = (q >= w1 && q < w1 + (long long)a.cls_rows * D_P) ? a.n_cls : edge ? a.n_edge : a.n_node;
     } else n = a.n_head;
     // the arena rows are padded to the stride: the 16-byte load of the last, partial group stays inside its row
     const float* src = a.arena + p;
@@ -1063,6 +1106,7 @@ extern "C" int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* s
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf) return GNET_ERR_INVALID;
   if (!buf->d_pw || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows || !buf->tpos || !buf->wrow) return GNET_ERR_INVALID;   // plan(training >= 1)
+  if (cfg->num_pwfeat_fc == 0 && !buf->spos) return GNET_ERR_INVALID;
   const int E = (int)shape->n_edge;
   if (shape->n_det == 0 || E == 0) return GNET_OK;
   if (E > (1 << 24) - 128) return GNET_ERR_UNSUPPORTED;
@@ -1084,7 +1128,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
-  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->pw_h1 || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows || !buf->tpos || !buf->wrow) return GNET_ERR_INVALID;   // plan(training >= 1)
+  if (!buf->arena || !buf->d_x || !buf->d_logits || !buf->blk_parg[1] || !buf->ewin || !buf->wlist || !buf->pw_rows || !buf->tpos || !buf->wrow) return GNET_ERR_INVALID;   // plan(training >= 1)
+  if (cfg->num_pwfeat_fc == 0 ? !buf->spos : (!buf->pw_h1 || !buf->pw_h2 || !buf->d_h1 || !buf->w1_s || !buf->w1_t)) return GNET_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   const ParamLayout L = make_layout(cfg);
   const int B = cfg->num_blocks;
@@ -1113,6 +1158,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   // node chunks per class row: ~2048 workgroups in all (at 256 -- one chunk for 80 classes, 160 workgroups scanning all detections --
   // the kernel took 68 us; 1024: 23; 2048: 17; 4096: 18)
   const int g_w1c = E > 0 ? max(1, min(128, 2048 / (2 * L.cprime))) : 0;
+  const int g_rawc = (E > 0 && L.raw) ? max(1, min(64, min((N + 255) / 256, 1024 / (2 * L.cprime)))) : 0;   // chunks per class row of raw_w1_classrows
   const EdgeGeom G = edge_geom(E, N);
 
   // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
@@ -1150,11 +1196,21 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
 #endif
           ));
     }
+    if (b <= B && E > 0 && L.raw) {
+      RawW1Args rw;
+      rw.n_det = N; rw.cprime = L.cprime; rw.multiclass = cfg->num_classes > 1; rw.nchunks = g_rawc;
+      rw.d_rc = buf->d_rc; rw.d_rn = buf->d_rn; rw.g1c = buf->d_g1; rw.spos = buf->spos + (size_t)(b - 1) * G.tf_stride;
+      rw.scores = in->det_scores; rw.classes = in->det_classes; rw.mult = cfg->pw_feat_multiplyer;
+      rw.arena = buf->arena; rw.stride = stride; rw.o_w1 = L.blk[b].w1;
+      GNET_LAUNCH(prof, GNET_K_W1_CLASS, s, raw_w1_classrows<<<dim3(2 * L.cprime, g_rawc), 64, 0, s>>>(rw));
+    }
     n.x_prev = b >= 2 ? buf->block_feats[b - 1] : buf->start_feat;
     if (b <= B) {
       const BlockLayout& K = L.blk[b];
-      n.r = buf->blk_r[b]; n.w1 = params + K.w1; n.wr = params + K.wr;
-      n.o_w1 = K.w1; n.o_b1 = K.b1; n.o_wr = K.wr; n.o_br = K.br;
+      // (the kernel addresses the centre / neighbour rows of pw_fc1 as rows 32-95: with kp pairwise rows they start at row kp)
+      const int64_t w1_cn = K.w1 + (int64_t)(L.kp - D_E) * D_P;
+      n.r = buf->blk_r[b]; n.w1 = params + w1_cn; n.wr = params + K.wr;
+      n.o_w1 = w1_cn; n.o_b1 = K.b1; n.o_wr = K.wr; n.o_br = K.br;
       n.r_nb = cfg->neighbor_feats ? buf->blk_rnb[b] : nullptr;
       n.wrn = cfg->neighbor_feats ? params + K.wrn : nullptr;
       n.o_wrn = K.wrn; n.o_brn = K.brn;
@@ -1184,7 +1240,7 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
       if (st != GNET_OK) return st;
     }
   }
-  if (E > 0) {
+  if (E > 0 && !L.raw) {
     // rows of the pw-MLP backward = edges that won in at least one block (list B of edge_stage_prepare)
     const unsigned long long* eany = (const unsigned long long*)buf->ewin + (size_t)B * G.bm_stride;
     const int* wg_off = buf->rl_scratch + (size_t)(B + 1) * G.n_wg;
@@ -1211,6 +1267,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     r.blk_sz = (B > 1) ? (L.blk[2].wr - L.blk[1].wr) : (L.hw1 - L.blk[1].wr);
     r.nblocks = B;
     r.n_w1c = g_w1c; r.n_w1 = g_w1; r.n_pw = g_pw; r.n_edge = g_edge; r.n_node = g_node; r.n_head = g_head;
+    r.kp = L.kp; r.cls_rows = L.raw ? 2 * L.cprime : 0; r.n_cls = g_rawc;
+    if (L.raw) { r.w1c_end = 0; r.pw1_end = 0; }      // no pw-MLP parameters: the blocks start at offset 0
     r.grads = grads;
     GNET_LAUNCH(prof, GNET_K_REDUCE, s, reduce_partials<<<(int)((L.total + 255) / 256), 256, 0, s>>>(r));
   }

@@ -353,6 +353,7 @@ struct TposArgs {
   const unsigned long long* ewin; const int* wprefix;
   const int* row_ptr; const int* edge_c; const int* edge_n; const int* edge_t;
   int* tpos; int* wrow;
+  int* spos; long long sp_stride;         // num_pwfeat_fc = 0: list position of every detection's self pair (filled with -1); else NULL
 };
 
 __global__ void __launch_bounds__(256) winner_tpos(const TposArgs a) {
@@ -372,6 +373,7 @@ __global__ void __launch_bounds__(256) winner_tpos(const TposArgs a) {
     const int t = wl[p];
     const int e = a.edge_t[t];
     if (e != t) tpos[e] = p;          // (a self pair is the involution's fixed point)
+    else if (a.spos) a.spos[(size_t)blk * a.sp_stride + a.edge_c[t]] = p;
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i <= a.n_det; i += stride) wrow[i] = winner_pos(ewin, wprefix, a.row_ptr[i]);
 }
@@ -390,6 +392,7 @@ struct EdgeBwdWArgs {
   float* g1c;                       // [W,64] g1 of the winner rows, list order
   float* arena; long long stride;
   long long o_w1, o_w2, o_b2;
+  int w1_rows;                      // pairwise rows of pw_fc1 this kernel owns: 32 (at o_w1), or the 7 geometry rows with num_pwfeat_fc = 0 (pw = the geometry columns padded to 32: the other 25 rows of P^T . g1 are exact zeros and belong to nobody)
   GNET_TRACE_FIELD
 };
 
@@ -844,7 +847,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = D_P * D_P + (16 * wave + r) * 64 + lane;
-      ar[a.o_w1 + (size_t)crow(r, half) * D_P + 32 * wave + col] = r0[o] + r1[o];
+      if (crow(r, half) < a.w1_rows) ar[a.o_w1 + (size_t)crow(r, half) * D_P + 32 * wave + col] = r0[o] + r1[o];
     }
   }
   if (tid < D_P) ar[a.o_b2 + tid] = r0[D_P * D_P + 2048 + tid] + r1[D_P * D_P + 2048 + tid];
@@ -862,6 +865,7 @@ int edge_stage_clear(const gnet_config* cfg, const gnet_shape* shape, gnet_buffe
   HIP_CHECK_RET(hipMemsetAsync(buf->rl_scratch + (size_t)(B + 1) * (2 * G.n_wg + 1), 0, (size_t)GNET_MAX_BLOCKS * sizeof(int), s));
   // tpos = -1 everywhere: winner_tpos scatters the positions of the winners' reversed pairs over it
   if (E > 0) HIP_CHECK_RET(hipMemsetAsync(buf->tpos, 0xff, (size_t)B * G.wl_stride * sizeof(int), s));
+  if (E > 0 && buf->spos) HIP_CHECK_RET(hipMemsetAsync(buf->spos, 0xff, (size_t)B * G.tf_stride * sizeof(int), s));
   return GNET_OK;
 }
 
@@ -907,6 +911,7 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   t.ewin = (const unsigned long long*)buf->ewin; t.wprefix = buf->wprefix;
   t.row_ptr = buf->row_ptr; t.edge_c = buf->edge_c; t.edge_n = buf->edge_n; t.edge_t = buf->edge_t;   // (edge_t: gnet_graph_transpose, earlier on this stream)
   t.tpos = buf->tpos; t.wrow = buf->wrow; t.n_wg = (int)G.n_wg; t.wlist = buf->wlist; t.wg_off = l.wg_off;
+  t.spos = L.raw ? buf->spos : nullptr; t.sp_stride = (long long)G.tf_stride;
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_tpos<<<dim3(min((E + 255) / 256, 1024), B), 256, 0, s>>>(t));
   return GNET_OK;
 }
@@ -934,7 +939,8 @@ int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const Para
   e.pw = buf->pw_feats; e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b]; e.d_pc = buf->d_pc;
   e.w1t = pt + K.w1; e.w2 = params + K.w2;
   e.d_pw = buf->d_pw; e.g1c = buf->d_g1;
-  e.arena = buf->arena; e.stride = arena_stride(L.total); e.o_w1 = K.w1; e.o_w2 = K.w2; e.o_b2 = K.b2;
+  e.arena = buf->arena; e.stride = arena_stride(L.total); e.o_w2 = K.w2; e.o_b2 = K.b2;
+  e.o_w1 = K.w1 + (L.raw ? (int64_t)2 * L.cprime * D_P : 0); e.w1_rows = L.raw ? 7 : D_E;
   GNET_TRACE_SET(e, "EDGE_BWD", b == B / 2);
   GNET_LAUNCH(prof, GNET_K_EDGE_BWD, s, edge_bwd_w<<<n_partials, 64 * EBW_WAVES, kEdgeBwdWSmem, s>>>(e));
   return GNET_OK;

@@ -79,7 +79,7 @@ static inline int launch_status() { return hipGetLastError() == hipSuccess ? GNE
 // ---- parameter layout (offsets in floats into the flat buffer; see gossipnet_hip.h) ------
 struct BlockLayout {
   int64_t wr, br;    // reduce_dim [128,32], [32]
-  int64_t w1, b1;    // pw_fc1 [96,64] rows 0-31 pw, 32-63 centre, 64-95 neighbour; [64]
+  int64_t w1, b1;    // pw_fc1 [kp+64,64] rows 0..kp-1 pairwise (kp = 32, or 2C'+7 with num_pwfeat_fc = 0), then 32 centre, 32 neighbour; [64]
   int64_t w2, b2;    // pw_fc2 [64,64]
   int64_t w3, b3;    // fc1 [64,64]
   int64_t w4, b4;    // fc2 [64,128]
@@ -92,13 +92,15 @@ struct ParamLayout {
   BlockLayout blk[GNET_MAX_BLOCKS + 1];  // 1-based
   int64_t hw1, hb1, hw2, hb2, hwl, hbl;
   int64_t total;
+  int raw;           // num_pwfeat_fc == 0: no pw-MLP, the blocks' pw_fc1 reads the raw 2C'+7 geometry columns (network.py:217-221)
+  int kp;            // rows of the pairwise part of a block's pw_fc1: 32 (pwfeat_narrow_dim), or dpw when raw
 };
 
 static inline int config_supported(const gnet_config* c) {
   if (!c) return 0;
   return c->num_classes >= 1 && c->num_blocks >= 1 && c->num_blocks <= GNET_MAX_BLOCKS &&
          c->shortcut_dim == D_S && c->reduced_dim == D_R && c->pairfeat_dim == D_P &&
-         c->pwfeat_dim == D_H && c->pwfeat_narrow_dim == D_E && c->num_pwfeat_fc == 3 &&
+         ((c->num_pwfeat_fc == 3 && c->pwfeat_dim == D_H && c->pwfeat_narrow_dim == D_E) || c->num_pwfeat_fc == 0) &&
          c->predict_fc_dim == D_HEAD && c->num_predict_fc == 3 && c->num_block_pw_fc == 2 &&
          c->num_block_fc == 2;
 }
@@ -107,18 +109,22 @@ static inline ParamLayout make_layout(const gnet_config* c) {
   ParamLayout L;
   L.cprime = c->num_classes > 1 ? c->num_classes : 1;
   L.dpw = 2 * L.cprime + 7;
+  L.raw = c->num_pwfeat_fc == 0;
+  L.kp = L.raw ? L.dpw : D_E;
   int64_t o = 0;
-  L.pw1 = o; o += (int64_t)L.dpw * D_H;
-  L.pb1 = o; o += D_H;
-  L.pw2 = o; o += D_H * D_H;
-  L.pb2 = o; o += D_H;
-  L.pw3 = o; o += D_H * D_E;
-  L.pb3 = o; o += D_E;
+  if (!L.raw) {
+    L.pw1 = o; o += (int64_t)L.dpw * D_H;
+    L.pb1 = o; o += D_H;
+    L.pw2 = o; o += D_H * D_H;
+    L.pb2 = o; o += D_H;
+    L.pw3 = o; o += D_H * D_E;
+    L.pb3 = o; o += D_E;
+  } else { L.pw1 = L.pb1 = L.pw2 = L.pb2 = L.pw3 = L.pb3 = 0; }
   for (int b = 1; b <= c->num_blocks; ++b) {
     BlockLayout& B = L.blk[b];
     B.wr = o; o += D_S * D_R;
     B.br = o; o += D_R;
-    B.w1 = o; o += (D_E + 2 * D_R) * D_P;
+    B.w1 = o; o += (int64_t)(L.kp + 2 * D_R) * D_P;
     B.b1 = o; o += D_P;
     B.w2 = o; o += D_P * D_P;
     B.b2 = o; o += D_P;

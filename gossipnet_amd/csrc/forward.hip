@@ -16,16 +16,24 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// pack_transpose: matrix id -> (offset, in, out) computed from the flat layout.
-__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, long long* off, int* in, int* out) {
-  const long long pw_sz = (long long)dpw * D_H + D_H + D_H * D_H + D_H + D_H * D_E + D_E;
-  const long long blk_core = D_S * D_R + D_R + (D_E + 2 * D_R) * D_P + D_P + D_P * D_P + D_P + D_P * D_P + D_P +
+// pack_transpose: matrix id -> (offset, in, out) computed from the flat layout.  raw (num_pwfeat_fc = 0): no pw-MLP matrices,
+// and a block's pw_fc1 is [dpw + 64, 64] -- *kind = 1 marks it: its packed copy keeps the [64][96] shape every consumer reads
+// (columns 0-6 = the seven geometry rows, 7-31 = zeros, 32-63 centre, 64-95 neighbour: the edge kernels then multiply the
+// geometry columns, padded to 32 in pw_feats, by it -- exact zeros for the padding -- and the 2C' score rows enter through the
+// per-detection tables node_fwd adds to rc / rn).
+__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, int raw, long long* off, int* in, int* out, int* kind) {
+  const int kp = raw ? dpw : D_E;
+  const long long pw_sz = raw ? 0 : (long long)dpw * D_H + D_H + D_H * D_H + D_H + D_H * D_E + D_E;
+  const long long blk_core = D_S * D_R + D_R + (long long)(kp + 2 * D_R) * D_P + D_P + D_P * D_P + D_P + D_P * D_P + D_P +
                              D_P * D_S + D_S;
   const long long blk_sz = blk_core + (nf ? D_S * D_R + D_R : 0);      // reduce_dim_neighbor follows fc2
-  if (id == 0) { *off = 0; *in = dpw; *out = D_H; return; }
-  if (id == 1) { *off = (long long)dpw * D_H + D_H; *in = D_H; *out = D_H; return; }
-  if (id == 2) { *off = (long long)dpw * D_H + D_H + D_H * D_H + D_H; *in = D_H; *out = D_E; return; }
-  id -= 3;
+  *kind = 0;
+  if (!raw) {
+    if (id == 0) { *off = 0; *in = dpw; *out = D_H; return; }
+    if (id == 1) { *off = (long long)dpw * D_H + D_H; *in = D_H; *out = D_H; *kind = 2; return; }
+    if (id == 2) { *off = (long long)dpw * D_H + D_H + D_H * D_H + D_H; *in = D_H; *out = D_E; return; }
+    id -= 3;
+  }
   const int mpb = 5 + (nf ? 1 : 0);
   if (id < mpb * nblocks) {
     const int b = id / mpb, m = id % mpb;
@@ -33,8 +41,8 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, l
     if (m == 5) { *off = o + blk_core; *in = D_S; *out = D_R; return; }
     if (m == 0) { *off = o; *in = D_S; *out = D_R; return; }
     o += D_S * D_R + D_R;
-    if (m == 1) { *off = o; *in = D_E + 2 * D_R; *out = D_P; return; }
-    o += (D_E + 2 * D_R) * D_P + D_P;
+    if (m == 1) { *off = o; *in = kp + 2 * D_R; *out = D_P; *kind = raw ? 1 : 0; return; }
+    o += (long long)(kp + 2 * D_R) * D_P + D_P;
     if (m == 2) { *off = o; *in = D_P; *out = D_P; return; }
     o += D_P * D_P + D_P;
     if (m == 3) { *off = o; *in = D_P; *out = D_P; return; }
@@ -50,11 +58,11 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, l
 
 constexpr int PACK_X = 32;   // workgroups per matrix: the 256 x 256 one is 32 strided 4-byte gathers per thread at 8 (23 us), 8 at 32 (14 us)
 __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ params, float* __restrict__ packed,
-                                                      int dpw, int nblocks, int nf) {
-  long long off; int in, out;
-  mat_info(blockIdx.y, dpw, nblocks, nf, &off, &in, &out);
+                                                      int dpw, int nblocks, int nf, int raw) {
+  long long off; int in, out, kind;
+  mat_info(blockIdx.y, dpw, nblocks, nf, raw, &off, &in, &out, &kind);
   const int total = in * out;
-  if (blockIdx.y == 1) {
+  if (kind == 2) {
     // pw_feats/fc2 (256 x 256) is streamed from L2 by pw_fwd as MFMA operand fragments: FRAGMENT-MAJOR, so that the 64
     // lanes of one load instruction read one contiguous 1 KB block (8 cache lines) instead of 32 bytes of each of 32 rows
     // (32 lines per instruction: the stream's tag look-ups, not its bytes, loaded the CU's texture path).  Wave w owns output
@@ -64,6 +72,18 @@ __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ 
       const int t = i & 3, lane = (i >> 2) & 63, s_ = (i >> 8) & 31, w = i >> 13;
       const int o = 32 * w + (lane & 31), k = 8 * s_ + 4 * (lane >> 5) + t;
       packed[off + i] = params[off + (long long)k * out + o];
+    }
+    return;
+  }
+  if (kind == 1) {
+    // raw pw_fc1 [dpw + 64, 64] -> [64][96]: geometry rows | zeros | centre | neighbour
+    const int g0 = dpw - 7;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < D_P * (D_E + 2 * D_R); i += gridDim.x * 256) {
+      const int o = i / (D_E + 2 * D_R), k = i - o * (D_E + 2 * D_R);
+      float v = 0.f;
+      if (k < 7) v = params[off + (long long)(g0 + k) * D_P + o];
+      else if (k >= D_E) v = params[off + (long long)(dpw + k - D_E) * D_P + o];
+      packed[off + i] = v;
     }
     return;
   }
@@ -98,6 +118,10 @@ struct GeoArgs {
   // per thread and launch.
   const int* row_ptr; int* straddle; int ef_tiles, ef_waves;
   int* pw_claim; int pw_claim0;   // pw_fwd's tile counter and its start value (the tiles behind every workgroup's first two)
+  // num_pwfeat_fc = 0 (network.py:217-221: pw_feats = the raw feature columns): no tables here (the score columns enter every
+  // block's pw_fc1 through per-block tables, node_fwd); the 7 geometry columns go to pw [E,32] padded with zeros -- the
+  // edge kernels' pairwise operand -- and a self pair's neighbour row is row n_det + 1 + c of rn (its score term alone)
+  int raw; float* pw;
 };
 
 // _geometry_feats (network.py:411-454), one thread per edge.  The 2C one-hot x score columns become the per-detection
@@ -110,7 +134,7 @@ __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
     const int eb = a.row_ptr[i], ee = a.row_ptr[i + 1];
     a.straddle[i] = (ee == eb || efw_owner(eb >> 5, a.ef_tiles, a.ef_waves) != efw_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
   }
-  for (int idx = e; idx < a.n_det * (D_H / 4); idx += gridDim.x * 256) {
+  for (int idx = e; !a.raw && idx < a.n_det * (D_H / 4); idx += gridDim.x * 256) {
     const int i = idx >> 6, q = idx & 63;
     float sc = a.scores[i] * a.mult, sn = sc;          // x * 1.0f is exact: the default multiplier changes no bit
     int rc = 0, rn = 1;
@@ -146,6 +170,14 @@ __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const float m = a.mult;                   // x * 1.0f is exact: the default changes no bit
   gp[0] = make_float4(a.edge_iou[e] * m, xd * m, yd * m, l2 * m);
   gp[1] = make_float4(wd * m, hd * m, ad * m, 0.f);
+  if (a.raw) {
+    float4* pp = reinterpret_cast<float4*>(a.pw + (size_t)e * D_E);
+    pp[0] = gp[0]; pp[1] = gp[1];
+#pragma unroll
+    for (int k = 2; k < D_E / 4; ++k) pp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.edge_nz[e] = c == n ? a.n_det + 1 + c : n;
+    return;
+  }
   a.edge_nz[e] = c == n ? a.n_det : n;
 }
 
@@ -1004,6 +1036,11 @@ struct NodeFwdArgs {
   const int* straddle;           // [N] see GeoArgs (NULL: the batch has no edge at all -- every record starts from zero)
   const float* hw1t; const float* hb1; const float* hw2t; const float* hb2; const float* hwl; const float* hbl;
   float* head1; float* head2; float* pred;
+  // num_pwfeat_fc = 0: the 2C' one-hot x score columns of the raw pairwise features (network.py:413-419) enter the next block's
+  // pw_fc1 as ONE row of its weight matrix per detection and role: rc[i] += s_i W1[class_i - 1], rn[i] += s_i W1[C' + class_i - 1],
+  // and row n_det + 1 + i of rn = that neighbour term alone (i's self pair: its neighbour FEATURES are zeroed, network.py:371-374,
+  // its neighbour score column is not).  raw_w1 = the next block's pw_fc1 in its natural layout [2C' + 7 + 64, 64]; NULL otherwise.
+  const float* raw_w1; const float* scores; const int* classes; int cprime, multiclass; float mult;
   GNET_TRACE_FIELD
 };
 
@@ -1166,10 +1203,28 @@ __global__ void __launch_bounds__(256) node_fwd(const NodeFwdArgs a) {
       mma_abt_r<D_R>(acc, part ? sYn : sY, E_LD1, gW1, lane);
       const float bb = gB1;
       float* dst = part == 0 ? a.rc : a.rn;
+      if (a.raw_w1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int node = row0 + crow(r, half);
-        if (node < a.n_det) dst[(size_t)node * D_P + 32 * nt + col] = acc[r] + bb;
+        for (int r = 0; r < 16; ++r) {
+          const int node = row0 + crow(r, half);
+          if (node < a.n_det) {
+            float sc = a.scores[node] * a.mult;                // x * 1.0f is exact
+            int row = part ? 1 : 0;
+            if (a.multiclass) {                                // scatter_nd one-hot x score; a class outside [1, C]: a zero column
+              const int cl = a.classes[node] - 1;
+              if (cl >= 0 && cl < a.cprime) row = (part ? a.cprime : 0) + cl; else { sc = 0.f; row = 0; }
+            }
+            const float tv = sc * a.raw_w1[(size_t)row * D_P + 32 * nt + col];
+            dst[(size_t)node * D_P + 32 * nt + col] = (acc[r] + bb) + tv;
+            if (part) a.rn[(size_t)(a.n_det + 1 + node) * D_P + 32 * nt + col] = tv;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int node = row0 + crow(r, half);
+          if (node < a.n_det) dst[(size_t)node * D_P + 32 * nt + col] = acc[r] + bb;
+        }
       }
     }
     // row n_det of rn stays zero: the edge kernels read it for self pairs (edge_nz)
@@ -1235,8 +1290,9 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   float* pt = buf->packed_t;
 
   void* prof = buf->profiler;
-  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(PACK_X, 3 + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats));
+  GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(PACK_X, (L.raw ? 0 : 3) + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats, L.raw));
 
+  const int pw_grid = min((E + PW_T - 1) / PW_T, 512);
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
     GeoArgs g;
@@ -1245,11 +1301,13 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.cprime = L.cprime; g.multiclass = cfg->num_classes > 1;
     g.geo = buf->geo; g.edge_nz = buf->edge_nz; g.n_det = N; g.mult = cfg->pw_feat_multiplyer;
     g.w1 = params + L.pw1; g.b1 = params + L.pb1; g.tc = buf->pw_tc; g.tn = buf->pw_tn;
+    g.raw = L.raw; g.pw = buf->pw_feats;
     g.row_ptr = buf->row_ptr; g.straddle = buf->scratch_i;
-    const int pw_tiles = (E + PW_T - 1) / PW_T, pw_grid = min(pw_tiles, 512);
     g.pw_claim = buf->scratch_i + N; g.pw_claim0 = 2 * pw_grid;
     g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
     GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
+  }
+  if (E > 0 && !L.raw) {
     PwFwdArgs a;
     a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.edge_c = buf->edge_c; a.edge_n = buf->edge_n;
     a.tc = buf->pw_tc; a.tn = buf->pw_tn; a.w1 = params + L.pw1;
@@ -1310,6 +1368,9 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     n.hw1t = pt + L.hw1; n.hb1 = params + L.hb1; n.hw2t = pt + L.hw2; n.hb2 = params + L.hb2;
     n.hwl = params + L.hwl; n.hbl = params + L.hbl;
     n.head1 = buf->head1; n.head2 = buf->head2; n.pred = buf->prediction;
+    n.raw_w1 = (L.raw && b < B) ? params + L.blk[b + 1].w1 : nullptr;
+    n.scores = in->det_scores; n.classes = in->det_classes; n.cprime = L.cprime; n.multiclass = cfg->num_classes > 1;
+    n.mult = cfg->pw_feat_multiplyer;
     GNET_TRACE_SET(n, "NODE_FWD", b == B / 2);
     GNET_LAUNCH(prof, GNET_K_NODE_FWD, s, node_fwd<<<ntile_n, 256, 0, s>>>(n));
     if (b < B) {

@@ -43,17 +43,24 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
   b.prediction = c.take<float>(Np);
   b.scratch_i = c.take<int32_t>(N + 1024);
   b.geo = c.take<float>(Ep * 8);
-  b.pw_tc = c.take<float>(Np * D_H);
-  b.pw_tn = c.take<float>(Np * D_H);
+  // (num_pwfeat_fc = 0: no pw-MLP -- its tables, activations and gradients are not carved; pw_feats holds the geometry columns
+  // padded to 32, the blocks' rn tables carry one more row per detection: its neighbour score term alone, read by its self pair)
+  const size_t rn_rows = L.raw ? 2 * N + 34 : Np;
+  if (!L.raw) {
+    b.pw_tc = c.take<float>(Np * D_H);
+    b.pw_tn = c.take<float>(Np * D_H);
+  }
   if (training) {
-    b.pw_h1 = c.take<float>(Ep * D_H);
-    b.pw_h2 = c.take<float>(Ep * D_H);
+    if (!L.raw) {
+      b.pw_h1 = c.take<float>(Ep * D_H);
+      b.pw_h2 = c.take<float>(Ep * D_H);
+    }
     b.block_feats[0] = nullptr;
     for (size_t k = 1; k <= B; ++k) {
       b.block_feats[k] = c.take<float>(Np * D_S);
       b.blk_r[k] = c.take<float>(Np * D_R);
       b.blk_rc[k] = c.take<float>(Np * D_P);
-      b.blk_rn[k] = c.take<float>(Np * D_P);
+      b.blk_rn[k] = c.take<float>(rn_rows * D_P);
       b.blk_pm[k] = c.take<uint64_t>(2 * Np * D_P);      // pm, then parg (one memset clears both)
       b.blk_parg[k] = b.blk_pm[k] + Np * D_P;
       b.blk_q[k] = c.take<float>(Np * D_P);
@@ -75,7 +82,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
     b.d_rc = c.take<float>(Np * D_P);
     b.d_rn = c.take<float>(Np * D_P);
     b.d_pw = c.take<float>(Ep * D_E);
-    b.d_h1 = c.take<float>(Ep * D_H);
+    if (!L.raw) b.d_h1 = c.take<float>(Ep * D_H);
     b.d_g1 = c.take<float>(Ep * D_P);
     {
       const EdgeGeom G = edge_geom((int64_t)E, (int64_t)N);
@@ -87,18 +94,21 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
       b.apos = c.take<int32_t>(B * G.ap_stride);
       b.tpos = c.take<int32_t>(B * G.wl_stride);
       b.wrow = c.take<int32_t>(B * G.tf_stride);
+      if (L.raw) b.spos = c.take<int32_t>(B * G.tf_stride);
       b.rl_scratch = c.take<int32_t>((B + 1) * (2 * G.n_wg + 1) + GNET_MAX_BLOCKS + 64);   // + per-block tie-list counters
     }
     b.pw_rows = c.take<int32_t>(Ep);
-    b.w1_s = c.take<float>(Np * D_H);
-    b.w1_t = c.take<float>(Np * D_H);
+    if (!L.raw) {
+      b.w1_s = c.take<float>(Np * D_H);
+      b.w1_t = c.take<float>(Np * D_H);
+    }
     b.arena_floats = arena_floats(cfg, sh);
     b.arena = c.take<float>(b.arena_floats);
   } else {
     // inference: per-block tensors are transient -> two alternating sets
     float* xf[2] = {c.take<float>(Np * D_S), c.take<float>(Np * D_S)};
     float* rc = c.take<float>(Np * D_P);
-    float* rn = c.take<float>(Np * D_P);
+    float* rn = c.take<float>(rn_rows * D_P);
     uint64_t* pm = c.take<uint64_t>(Np * D_P);
     for (size_t k = 1; k <= B; ++k) {
       b.block_feats[k] = xf[k & 1];

@@ -45,15 +45,19 @@ def param_spec(num_classes, num_blocks):
     d = 2 * cp + 7
     g = cfg.gnet
     spec = []
-    dims = [d, g.pwfeat_dim, g.pwfeat_dim, g.pwfeat_narrow_dim]
-    for i in range(3):
+    # _pw_feats_fc (network.py:324-342): num_pwfeat_fc - 1 layers of pwfeat_dim, then one of pwfeat_narrow_dim; with
+    # num_pwfeat_fc = 0 (the reference's default, network.py:217-221) the blocks read the raw feature columns
+    nfc = int(g.num_pwfeat_fc)
+    dims = [d] + [g.pwfeat_dim] * max(nfc - 1, 0) + ([g.pwfeat_narrow_dim] if nfc > 0 else [])
+    for i in range(nfc):
         spec.append(("gnet/pw_feats/fc%d/weights" % (i + 1), (dims[i], dims[i + 1])))
         spec.append(("gnet/pw_feats/fc%d/biases" % (i + 1), (dims[i + 1],)))
+    pw_in = dims[-1]
     for b in range(1, num_blocks + 1):
         p = "gnet/block%d/" % b
         spec += [
             (p + "reduce_dim/weights", (g.shortcut_dim, g.reduced_dim)), (p + "reduce_dim/biases", (g.reduced_dim,)),
-            (p + "pw_fc1/weights", (g.pwfeat_narrow_dim + 2 * g.reduced_dim, g.pairfeat_dim)),
+            (p + "pw_fc1/weights", (pw_in + 2 * g.reduced_dim, g.pairfeat_dim)),
             (p + "pw_fc1/biases", (g.pairfeat_dim,)),
             (p + "pw_fc2/weights", (g.pairfeat_dim, g.pairfeat_dim)), (p + "pw_fc2/biases", (g.pairfeat_dim,)),
             (p + "fc1/weights", (g.pairfeat_dim, g.pairfeat_dim)), (p + "fc1/biases", (g.pairfeat_dim,)),
@@ -218,7 +222,7 @@ class Gnet(object):
             n = (off + 3) & ~3
             from .fc import FcWorkspace
             self._fc_ws = FcWorkspace(self.device)
-        key = (self.name, num_classes, g.num_blocks, str(self.device), self._imfeats, self.imfeat_channels, bool(g.neighbor_feats))
+        key = (self.name, num_classes, g.num_blocks, str(self.device), self._imfeats, self.imfeat_channels, bool(g.neighbor_feats), int(g.num_pwfeat_fc))
         if reuse:
             if key not in Gnet._scopes:
                 raise ValueError("Variable scope gnet does not exist, cannot reuse")
@@ -257,6 +261,7 @@ class Gnet(object):
         # the default training path recomputes them for the rows the backward pass needs
         self.keep_edge_activations = False
         self._profiler = None
+        self.transpose_after_forward = False     # (measurement switch: see _prepare_matching)
         self._batch = batch
         if batch is not None:
             self.feed(batch)
@@ -323,6 +328,16 @@ class Gnet(object):
         off = ptr - self._ws.data_ptr()
         return self._ws[off:off + count * esz].view(dtype)
 
+    def _scoped(self, kclass, stream_ptr, fn, *args):
+        """Run a C entry point that takes no gnet_buffers (the graph build) inside a profiler scope of class `kclass`."""
+        prof = self._profiler
+        if not prof:
+            return fn(*args)
+        idx = self._lib.gnet_profiler_begin(prof, _lib.KCLASSES.index(kclass), stream_ptr)
+        st = fn(*args)
+        self._lib.gnet_profiler_end(prof, idx, stream_ptr)
+        return st
+
     def _count_graph(self, db):
         """Pass 1 of the graph build (per-row neighbour counts + scan) on a SIDE stream, with the edge count copied to
         pinned host memory there.  The host then waits for that small kernel only -- never for the main stream -- so
@@ -346,8 +361,8 @@ class Gnet(object):
             self._side.wait_event(self._rp_free[k])
         with torch.cuda.stream(self._side):
             s = C.c_void_p(self._side.cuda_stream)
-            _lib.check(lib.gnet_graph_count(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, _vp(self._row_ptr_tmp[k]),
-                                            _vp(self._scratch_tmp[k]), s), "gnet_graph_count")
+            _lib.check(self._scoped("graph", s, lib.gnet_graph_count, _vp(db.dets), N, _vp(db.det_off), db.n_img, thr,
+                                    _vp(self._row_ptr_tmp[k]), _vp(self._scratch_tmp[k]), s), "gnet_graph_count")
             if N > 0:
                 self._e_host[k].copy_(self._row_ptr_tmp[k][N:N + 1], non_blocking=True)
             self._count_done = torch.cuda.Event()
@@ -379,8 +394,8 @@ class Gnet(object):
         self._view(buf.row_ptr, N + 1, torch.int32).copy_(self._row_ptr_tmp[k][:N + 1])
         self._rp_free[k] = torch.cuda.Event()
         self._rp_free[k].record(torch.cuda.current_stream(self.device))
-        _lib.check(lib.gnet_graph_fill(_vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr, buf.edge_c,
-                                       buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
+        _lib.check(self._scoped("graph", s, lib.gnet_graph_fill, _vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr,
+                                buf.edge_c, buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
         self.num_edges = E
         return shape, buf
 
@@ -400,9 +415,11 @@ class Gnet(object):
             self._prep_done.record(self._side)
             if shape.n_edge > 0:
                 # the reverse-edge permutation is read by the backward pass only (which waits for `_bprep_done`,
-                # recorded later on this stream)
-                _lib.check(self._lib.gnet_graph_transpose(buf.row_ptr, buf.edge_c, buf.edge_n, shape.n_edge, buf.edge_t, ss),
-                           "gnet_graph_transpose")
+                # recorded later on this stream).  Beside the forward pass by default; `transpose_after_forward` (bench.py's
+                # A/B of its placement) issues it behind the forward pass instead (_prepare_backward).
+                if backward and not self.transpose_after_forward:
+                    _lib.check(self._scoped("graph", ss, self._lib.gnet_graph_transpose, buf.row_ptr, buf.edge_c, buf.edge_n,
+                                            shape.n_edge, buf.edge_t, ss), "gnet_graph_transpose")
                 if backward:     # the zeroing half of the backward preparation does not need the forward pass
                     _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                                                C.byref(buf), 1, ss), "gnet_backward_prepare")
@@ -416,8 +433,12 @@ class Gnet(object):
         self._fwd_done.record(main)
         self._side.wait_event(self._fwd_done)
         with torch.cuda.stream(self._side):
+            ss = C.c_void_p(self._side.cuda_stream)
+            if self.transpose_after_forward and shape.n_edge > 0:
+                _lib.check(self._scoped("graph", ss, self._lib.gnet_graph_transpose, buf.row_ptr, buf.edge_c, buf.edge_n,
+                                        shape.n_edge, buf.edge_t, ss), "gnet_graph_transpose")
             _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
-                                                       C.byref(buf), 2, C.c_void_p(self._side.cuda_stream)), "gnet_backward_prepare")
+                                                       C.byref(buf), 2, ss), "gnet_backward_prepare")
             self._bprep_done.record(self._side)
 
     def _mode(self, training):
@@ -673,7 +694,27 @@ class Gnet(object):
 
     @property
     def pw_feats(self):
-        return self._view(self._buf.pw_feats, self._shape.n_edge * 32, torch.float32).view(-1, 32)
+        """Gnet.pw_feats (network.py:221): the pairwise-feature MLP's output [E,32] -- or, with cfg.gnet.num_pwfeat_fc = 0,
+        the raw _geometry_feats columns [E, 2C'+7] x pw_feat_multiplyer themselves (assembled on demand from the geometry
+        columns the kernels keep and the one-hot x score columns, network.py:413-419; the hot path never materialises them)."""
+        E = self._shape.n_edge
+        if self._cfg.num_pwfeat_fc > 0:
+            return self._view(self._buf.pw_feats, E * 32, torch.float32).view(-1, 32)
+        geo = self._view(self._buf.geo, E * 8, torch.float32).view(-1, 8)[:, :7]
+        db = self._dbatch
+        N = db.n_det
+        mult = float(self._cfg.pw_feat_multiplyer)
+        if self._cfg.num_classes > 1:
+            Cn = self._cfg.num_classes
+            cls = db.det_classes.long() - 1
+            ok = (cls >= 0) & (cls < Cn)
+            sc = torch.zeros(N, Cn, dtype=torch.float32, device=self.device)
+            idx = torch.nonzero(ok).view(-1)
+            sc[idx, cls[idx]] = db.det_scores[idx] * mult
+        else:
+            sc = (db.det_scores * mult).view(-1, 1)
+        pairs = self.neighbor_pair_idxs
+        return torch.cat([sc[pairs[:, 0]], sc[pairs[:, 1]], geo], 1)
 
     @property
     def block_feats(self):

@@ -39,12 +39,13 @@ extern "C" {
 typedef void* gnet_stream_t; /* hipStream_t */
 
 /* Hyper-parameters: the cfg.gnet.* / cfg.train.* values Gnet reads at construction
- * (nms_net/config.py:46-79, experiments/<exp>/conf.yaml).  Only the configuration of the two
- * shipped experiments is compiled: shortcut 128, reduced 32, pairfeat 64,
- * pwfeat 256, pwfeat_narrow 32, num_pwfeat_fc 3, predict_fc 128, num_predict_fc 3,
- * num_block_pw_fc 2, num_block_fc 2 (anything else: GNET_ERR_UNSUPPORTED).  num_classes, num_blocks,
- * neighbor_thresh, neighbor_feats, pw_feat_multiplyer and the loss flags are run-time values; the image-feature
- * variant (cfg.gnet.imfeats) is selected per call through gnet_buffers.start_feat. */
+ * (nms_net/config.py:46-79, experiments/<exp>/conf.yaml).  Compiled layer widths: shortcut 128, reduced 32, pairfeat 64,
+ * predict_fc 128, num_predict_fc 3, num_block_pw_fc 2, num_block_fc 2, and the pairwise-feature MLP either as in the two
+ * shipped experiments (num_pwfeat_fc 3, pwfeat 256, pwfeat_narrow 32) or ABSENT (num_pwfeat_fc 0, the reference's default,
+ * config.py:73 / network.py:217-221: the blocks' pw_fc1 then reads the 2C'+7 raw _geometry_feats columns; pwfeat_dim and
+ * pwfeat_narrow_dim are ignored).  Anything else: GNET_ERR_UNSUPPORTED.  num_classes, num_blocks, neighbor_thresh,
+ * neighbor_feats, pw_feat_multiplyer and the loss flags are run-time values; the image-feature variant (cfg.gnet.imfeats) is
+ * selected per call through gnet_buffers.start_feat. */
 typedef struct gnet_config {
   int32_t num_classes;     /* C; multiclass = C > 1 (network.py:151)            */
   int32_t num_blocks;      /* cfg.gnet.num_blocks                                */
@@ -102,7 +103,7 @@ typedef struct gnet_buffers {
   float* block_feats[GNET_MAX_BLOCKS + 1]; /* [n_det,128] each; [0] = zeros      */
   float* blk_r[GNET_MAX_BLOCKS + 1];       /* [n_det,32]  relu(reduce_dim)        */
   float* blk_rc[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[32:64] + b1        */
-  float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det,64]  r.W1[64:96]             */
+  float* blk_rn[GNET_MAX_BLOCKS + 1];      /* [n_det+1,64] r.W1[64:96], row n_det = zeros (self pairs); with num_pwfeat_fc = 0: [2 n_det+2,64], row n_det+1+i = detection i's neighbour score term alone (its self pair) */
   uint64_t* blk_pm[GNET_MAX_BLOCKS + 1];   /* [n_det,64]  (segment max bits<<32)|tie count (the count is formed by a training forward only; a forward-only pass leaves a meaningless low word) */
   float* blk_q[GNET_MAX_BLOCKS + 1];       /* [n_det,64]  relu(fc1)               */
   float* blk_rnb[GNET_MAX_BLOCKS + 1];     /* [n_det,32]  relu(reduce_dim_neighbor) (neighbor_feats, training)   */
@@ -136,6 +137,7 @@ typedef struct gnet_buffers {
   int32_t* apos;      /* [num_blocks][n_det+32,64] per (detection, column): bits 0-23 = list position of the arg-max edge + 1 (0 = no gradient), bit 30 = the detection's tie flag */
   int32_t* tpos;      /* [num_blocks][n_edge+64] list position of every edge's REVERSED pair in the block's winner list; -1 = not a winner (or a self pair) */
   int32_t* wrow;      /* [num_blocks][n_det+32] list position of the first winner of every detection's edge range (CSR row pointers of the winner lists) */
+  int32_t* spos;      /* [num_blocks][n_det+32] num_pwfeat_fc = 0 only: list position of every detection's SELF pair in the block's winner list, -1 = not a winner (its neighbour SCORE column receives gradient although its neighbour features are zeroed, network.py:371-374) */
   int32_t* rl_scratch;/* scan scratch of the list construction; also holds the list lengths */
   int32_t* pw_rows;   /* [n_edge+64] ascending indices of the edges with a non-zero d_pw row (rows of the pw-MLP backward) */
   float* w1_s;        /* [n_det,256] sum of d_h1 over the detection's own pairs (centre role)      */
@@ -154,7 +156,7 @@ typedef struct gnet_buffers {
 
 /* ---- parameters ------------------------------------------------------------
  * One flat fp32 buffer in TF-variable order, weights [in,out]:
- *   gnet/pw_feats/fc{1,2,3}/{weights,biases}
+ *   gnet/pw_feats/fc{1,2,3}/{weights,biases}                  (absent with num_pwfeat_fc = 0; pw_fc1 is then [2C'+7+64, 64])
  *   gnet/block{k}/{reduce_dim,pw_fc1,pw_fc2,fc1,fc2[,reduce_dim_neighbor]}/{weights,biases}   k = 1..B
  *   gnet/predict/fc{1,2}/fully_connected/{weights,biases}
  *   gnet/predict/logits/fully_connected/{weights,biases}

@@ -51,23 +51,30 @@ def imfeat_param_spec(imfeat):
     return spec
 
 
-def param_spec(num_classes, num_blocks, imfeat=None, neighbor_feats=False):
+def pw_mlp_dims(num_classes, num_pwfeat_fc, narrow=PWFEAT_NARROW_DIM):
+    """_pw_feats_fc (network.py:324-342, called only when num_pwfeat_fc > 0, :217-221): num_pwfeat_fc - 1 layers of
+    pwfeat_dim, then one of pwfeat_narrow_dim.  With num_pwfeat_fc = 0 (the reference's default, config.py:73) the list is
+    just the raw feature width: the blocks' pw_fc1 reads the 2C'+7 columns of _geometry_feats."""
+    d = pw_feat_dim(num_classes)
+    return [d] + [PWFEAT_DIM] * max(num_pwfeat_fc - 1, 0) + ([narrow] if num_pwfeat_fc > 0 else [])
+
+
+def param_spec(num_classes, num_blocks, imfeat=None, neighbor_feats=False, num_pwfeat_fc=NUM_PWFEAT_FC):
     """Ordered (TF variable name, shape) list; FC weights are [in, out]
     (tf.contrib.layers.fully_connected).  Scopes: network.py:167,218,260,267,
     334,341,347,354,385,397,405; SURVEY.md §8f.  imfeat: the reduce_imfeats variables follow."""
     if imfeat is not None:
-        return param_spec(num_classes, num_blocks, None, neighbor_feats) + imfeat_param_spec(imfeat)
+        return param_spec(num_classes, num_blocks, None, neighbor_feats, num_pwfeat_fc) + imfeat_param_spec(imfeat)
     spec = []
-    d = pw_feat_dim(num_classes)
-    dims = [d, PWFEAT_DIM, PWFEAT_DIM, PWFEAT_NARROW_DIM]
-    for i in range(NUM_PWFEAT_FC):
+    dims = pw_mlp_dims(num_classes, num_pwfeat_fc)
+    for i in range(num_pwfeat_fc):
         spec.append(("gnet/pw_feats/fc%d/weights" % (i + 1), (dims[i], dims[i + 1])))
         spec.append(("gnet/pw_feats/fc%d/biases" % (i + 1), (dims[i + 1],)))
     for b in range(1, num_blocks + 1):
         p = "gnet/block%d/" % b
         spec += [
             (p + "reduce_dim/weights", (SHORTCUT_DIM, REDUCED_DIM)), (p + "reduce_dim/biases", (REDUCED_DIM,)),
-            (p + "pw_fc1/weights", (PWFEAT_NARROW_DIM + 2 * REDUCED_DIM, PAIRFEAT_DIM)), (p + "pw_fc1/biases", (PAIRFEAT_DIM,)),
+            (p + "pw_fc1/weights", (dims[-1] + 2 * REDUCED_DIM, PAIRFEAT_DIM)), (p + "pw_fc1/biases", (PAIRFEAT_DIM,)),
             (p + "pw_fc2/weights", (PAIRFEAT_DIM, PAIRFEAT_DIM)), (p + "pw_fc2/biases", (PAIRFEAT_DIM,)),
             (p + "fc1/weights", (PAIRFEAT_DIM, PAIRFEAT_DIM)), (p + "fc1/biases", (PAIRFEAT_DIM,)),
             (p + "fc2/weights", (PAIRFEAT_DIM, SHORTCUT_DIM)), (p + "fc2/biases", (SHORTCUT_DIM,)),
@@ -82,13 +89,13 @@ def param_spec(num_classes, num_blocks, imfeat=None, neighbor_feats=False):
     return spec
 
 
-def init_params(num_classes, num_blocks, seed=42, bias_init=0.01, imfeat=None, neighbor_feats=False):
+def init_params(num_classes, num_blocks, seed=42, bias_init=0.01, imfeat=None, neighbor_feats=False, num_pwfeat_fc=NUM_PWFEAT_FC):
     """xavier-uniform weights (network.py:203-205, limit sqrt(6/(fan_in+fan_out))),
     constant biases (network.py:215).  TF's RNG stream cannot be reproduced; the
     seed only fixes OUR stream."""
     g = torch.Generator().manual_seed(seed)
     out = {}
-    for name, shape in param_spec(num_classes, num_blocks, imfeat, neighbor_feats):
+    for name, shape in param_spec(num_classes, num_blocks, imfeat, neighbor_feats, num_pwfeat_fc):
         if name.endswith("weights"):
             lim = math.sqrt(6.0 / (shape[0] + shape[1]))
             out[name] = ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim).to(torch.float32).numpy()
@@ -327,7 +334,7 @@ class GnetOracle:
     def __init__(self, num_classes, num_blocks=16, params=None, class_weights=None,
                  dtype=torch.float32, thresh=NEIGHBOR_THRESH, normalize_loss=False,
                  loss_multiplyer=1.0, bias_init=0.01, matching_fn=None, pw_feat_multiplyer=1.0, imfeat=None,
-                 neighbor_feats=False):
+                 neighbor_feats=False, num_pwfeat_fc=NUM_PWFEAT_FC):
         self.num_classes = num_classes
         self.num_blocks = num_blocks
         self.dtype = dtype
@@ -338,8 +345,10 @@ class GnetOracle:
         self.pw_feat_multiplyer = pw_feat_multiplyer    # config.py:77, network.py:199-200
         self.imfeat = imfeat                            # image-feature variant (network.py:223-240), see imfeat_param_spec
         self.neighbor_feats = neighbor_feats            # config.py:72, network.py:356-365
+        self.num_pwfeat_fc = num_pwfeat_fc              # config.py:73, network.py:217-221 (0: no pairwise-feature MLP)
         if params is None:
-            params = init_params(num_classes, num_blocks, bias_init=bias_init, imfeat=imfeat, neighbor_feats=neighbor_feats)
+            params = init_params(num_classes, num_blocks, bias_init=bias_init, imfeat=imfeat, neighbor_feats=neighbor_feats,
+                                 num_pwfeat_fc=num_pwfeat_fc)
         self.params = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True)
                        for k, v in params.items()}
         if class_weights is None:
@@ -383,7 +392,7 @@ class GnetOracle:
         rec = (lambda key: pre[key]) if (keep and pins is None) else (lambda key: None)
         note = (lambda key, t: own[key].append((t.detach() > 0).numpy())) if keep else (lambda key, t: None)
         note_im = lambda t: note("im", t)
-        for i in range(1, NUM_PWFEAT_FC + 1):
+        for i in range(1, self.num_pwfeat_fc + 1):       # network.py:217-221: only when num_pwfeat_fc > 0
             f = _fc(f, P, "gnet/pw_feats/fc%d" % i, True, stats, pin("pw", i - 1), rec("pw"))
             note("pw", f)
         pw = f
@@ -487,7 +496,7 @@ class GnetOracle:
         return out, grads
 
 
-def flatten(params_or_grads, num_classes, num_blocks, imfeat=None, neighbor_feats=False):
+def flatten(params_or_grads, num_classes, num_blocks, imfeat=None, neighbor_feats=False, num_pwfeat_fc=NUM_PWFEAT_FC):
     """Flat fp32 vector in param_spec order (the layout of include/gossipnet_hip.h)."""
     return np.concatenate([np.asarray(params_or_grads[n], dtype=np.float32).reshape(-1)
-                           for n, _ in param_spec(num_classes, num_blocks, imfeat, neighbor_feats)])
+                           for n, _ in param_spec(num_classes, num_blocks, imfeat, neighbor_feats, num_pwfeat_fc)])

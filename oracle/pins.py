@@ -6,10 +6,10 @@ import torch
 from . import gnet_oracle as go
 
 
-def grad_errors(net, gref, c, b, imfeat=None, neighbor_feats=False):
+def grad_errors(net, gref, c, b, imfeat=None, neighbor_feats=False, num_pwfeat_fc=go.NUM_PWFEAT_FC):
     """Per-tensor max |g_hip - g_ref| / max |g_ref| (TF variable name -> error)."""
     errs = {}
-    for name, shape in go.param_spec(c, b, imfeat, neighbor_feats):
+    for name, shape in go.param_spec(c, b, imfeat, neighbor_feats, num_pwfeat_fc):
         g = net.gradients[name].detach().cpu().numpy().reshape(-1)       # (by name: the flat buffer may hold alignment padding)
         gr = np.asarray(gref[name], np.float64).reshape(-1)
         m = np.abs(gr).max() if gr.size else 0.0
@@ -54,9 +54,10 @@ def gpu_pins(net, image=None):
         rp = net.row_ptr.cpu().numpy()
         e0, e1 = int(rp[d0]), int(rp[d1])
     cpu = lambda t: t.cpu().numpy()
-    pins = {"pw": [cpu(dv("pw_h1", E * 256).view(E, 256)[e0:e1] > 0), cpu(dv("pw_h2", E * 256).view(E, 256)[e0:e1] > 0),
-                   cpu(net.pw_feats[e0:e1] > 0)],
-            "r": [], "rn": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}
+    pins = {"pw": [], "r": [], "rn": [], "h1": [], "sel": [], "q": [], "x": [], "im": []}
+    if net._buf.pw_h1:          # (num_pwfeat_fc = 0: no pairwise-feature MLP, no masks of it)
+        pins["pw"] = [cpu(dv("pw_h1", E * 256).view(E, 256)[e0:e1] > 0), cpu(dv("pw_h2", E * 256).view(E, 256)[e0:e1] > 0),
+                      cpu(net.pw_feats[e0:e1] > 0)]
     if getattr(net, "_imfeats", False):
         pins["im"] = [cpu(a_[d0:d1] > 0) for a_ in net._imfeat_acts]
     bf = net.block_feats

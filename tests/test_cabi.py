@@ -71,8 +71,17 @@ def test_param_count_and_unsupported_config():
     assert lib.gnet_param_count(C.byref(ok)) == 581793          # multiclass, B = 16
     one = _lib.gnet_config(1, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 3, 128, 3, 2, 2, 1.0, 0)
     assert lib.gnet_param_count(C.byref(one)) == 541345
-    bad = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 64, 0, 128, 3, 2, 2, 1.0, 0)   # reference default
-    assert lib.gnet_param_count(C.byref(bad)) == _lib.ERR_UNSUPPORTED
+    # the reference's default hyper-parameters (config.py:73-75: num_pwfeat_fc = 0, pwfeat_narrow_dim = 64): no pairwise-feature
+    # MLP, every block's pw_fc1 reads the 2C'+7 raw feature columns -- 16 x ((167 + 64) x 64 + 26 976 - 96 x 64) + head 33 153
+    raw = _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 64, 0, 128, 3, 2, 2, 1.0, 0)
+    blk = 128 * 32 + 32 + (167 + 64) * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 * 128 + 128
+    assert lib.gnet_param_count(C.byref(raw)) == 16 * blk + 33153
+    raw1 = _lib.gnet_config(1, 2, 0.2, 0, 1.0, 128, 32, 64, 256, 64, 0, 128, 3, 2, 2, 1.0, 0)
+    assert lib.gnet_param_count(C.byref(raw1)) == 2 * (blk - (167 - 9) * 64) + 33153
+    for bad in (_lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 64, 3, 128, 3, 2, 2, 1.0, 0),     # a 64-wide narrow layer
+                _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 32, 64, 256, 32, 2, 128, 3, 2, 2, 1.0, 0),     # a two-layer pw-MLP
+                _lib.gnet_config(80, 16, 0.2, 0, 1.0, 128, 64, 64, 256, 32, 3, 128, 3, 2, 2, 1.0, 0)):    # reduced_dim 64
+        assert lib.gnet_param_count(C.byref(bad)) == _lib.ERR_UNSUPPORTED
 
 
 def test_workspace_query_and_plan_argument_checks():
@@ -91,17 +100,24 @@ def test_workspace_query_and_plan_argument_checks():
 
 
 def test_param_spec_matches_oracle_and_layout():
-    from gossipnet_amd.config import reset_cfg
+    from gossipnet_amd.config import experiment_cfg
     from gossipnet_amd.network import param_spec
     from oracle import gnet_oracle as go
-    reset_cfg()
+    from gossipnet_amd.config import cfg, reset_cfg
+    experiment_cfg()
     for c, b in ((80, 16), (1, 1), (3, 5)):
         assert param_spec(c, b) == go.param_spec(c, b)
+    reset_cfg()                                  # the reference's defaults: no pairwise-feature MLP
+    assert cfg.gnet.num_pwfeat_fc == 0 and cfg.gnet.pwfeat_narrow_dim == 64 and cfg.gnet.bias_const_init == 0.0   # config.py:73-77
+    for c, b in ((80, 16), (1, 2)):
+        assert param_spec(c, b) == go.param_spec(c, b, num_pwfeat_fc=0)
+        assert ("gnet/block1/pw_fc1/weights", (2 * c + 7 + 64, 64)) in param_spec(c, b)
+    experiment_cfg()
 
 
 def test_config_merge_rules(tmp_path):
-    from gossipnet_amd.config import cfg, cfg_from_file, reset_cfg
-    reset_cfg()
+    from gossipnet_amd.config import cfg, cfg_from_file, experiment_cfg
+    experiment_cfg()
     p = tmp_path / "conf.yaml"
     p.write_text("gnet:\n  num_blocks: 1\n  bias_const_init: 0.1\ntrain:\n  imdb: coco_2014_train\n")
     cfg_from_file(str(p))                       # out-of-scope keys of the reference configs are ignored
@@ -112,21 +128,21 @@ def test_config_merge_rules(tmp_path):
     bad.write_text("gnet:\n  num_blocks: 'one'\n")
     with pytest.raises(ValueError):
         cfg_from_file(str(bad))                 # config.py:95-103: type mismatch
-    reset_cfg()
+    experiment_cfg()
     assert cfg.gnet.num_blocks == 16
 
 
 def test_reference_experiment_configs_load():
     """The values of the two shipped experiments select the compiled configuration."""
-    from gossipnet_amd.config import cfg, cfg_from_file, reset_cfg
+    from gossipnet_amd.config import cfg, cfg_from_file, experiment_cfg
     import tempfile
-    reset_cfg()
+    experiment_cfg()
     text = "gnet:\n  bias_const_init: 0.1\n  neighbor_feats: false\n  num_blocks: 1\n  num_pwfeat_fc: 3\n  pwfeat_narrow_dim: 32\nrandom_seed: 42\n"
     with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
         f.write(text)
     cfg_from_file(f.name)
     assert cfg.gnet.num_blocks == 1 and cfg.gnet.num_pwfeat_fc == 3
-    reset_cfg()
+    experiment_cfg()
 
 
 def test_device_batch_offsets_on_cpu():

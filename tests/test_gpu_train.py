@@ -69,7 +69,7 @@ def test_one_rank_nccl_step_equals_single_process_step(tmp_path):
     script = """
 import os, sys, numpy as np, torch
 sys.path.insert(0, %r)
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet
 from gossipnet_amd.synthetic import make_image
 from gossipnet_amd.train import Optimizer, train_step
@@ -81,7 +81,7 @@ if use_dist:
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-reset_cfg(); cfg.gnet.num_blocks = 3
+experiment_cfg(); cfg.gnet.num_blocks = 3
 net = Gnet(80, weight_reg=0.0005)
 if use_dist: broadcast_parameters(net.params, dist)
 opt = Optimizer(net)
@@ -128,7 +128,7 @@ def _two_ranks_equal_single_process(tmp_path, n_images, backend):
     script = """
 import os, sys, numpy as np, torch
 sys.path.insert(0, %r)
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet
 from gossipnet_amd.synthetic import make_image
 from gossipnet_amd.train import Optimizer, train_step
@@ -144,7 +144,7 @@ if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-reset_cfg(); cfg.gnet.num_blocks = 3
+experiment_cfg(); cfg.gnet.num_blocks = 3
 cfg.train.optimizer = "sgd"                     # momentum update: linear in the gradient (Adam's g / sqrt(v) turns a
                                                 # 1e-7 reduction-order difference of a cancelling sum into a visible step)
 cfg.random_seed = 42 + rank                     # replicas start DIFFERENT: the broadcast must make them equal
@@ -174,8 +174,8 @@ if world > 1:
     r0, r1 = np.load(files[0]), np.load(files[1])
     assert np.array_equal(r0, r1), "replicas hold identical parameters after the all-reduce"
     assert np.isfinite(want).all() and np.abs(r0 - want).max() <= 1e-6 * np.abs(want).max()
-    from gossipnet_amd.config import reset_cfg
-    reset_cfg()
+    from gossipnet_amd.config import experiment_cfg
+    experiment_cfg()
     start = make_pair(80, 3)[0]            # (same seed-42 initialisation as rank 0: the steps did move the parameters)
     assert np.abs(want - start.params.cpu().numpy()).max() > 1e-4
 

@@ -36,7 +36,7 @@ def test_class_equal_weights_known_answer():
     [1 + 7, 1 + 2, 1 + 2] = [8, 3, 3], 14 samples; expected [0.9, 0.05, 0.05] -> 14 * e / counts."""
     from gossipnet_amd.config import reset_cfg
     from nms_net.class_weights import class_equal_weights, get_class_counts
-    reset_cfg()
+    reset_cfg()                   # the reference's defaults: pos_weight 0.1 (config.py:41)
     imdb = {"num_classes": 2, "roidb": [{"gt_classes": np.array([1, 1, 2]), "det_classes": np.ones(10, np.int32)},
                                         {"gt_classes": np.array([2])}]}
     assert get_class_counts(imdb).tolist() == [8, 3, 3]
@@ -78,15 +78,15 @@ def test_timer_running_average():
 def test_learning_rate_table_semantics():
     """reference train.py:26-37 fed consecutive iterations: entry k's rate up to and including its iteration, the last
     rate ever after (hand-traced: cursor 0 returns 0.1 at iterations 1, 2 and moves at 2; 0.01 at 3, 4; then the last)."""
-    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.train import LearningRate
-    reset_cfg()
+    experiment_cfg()
     cfg.train.lr_multi_step = [(2, 0.1), (4, 0.01)]
     lr = LearningRate()
     assert [lr.get_lr(i) for i in range(0, 8)] == [0.1, 0.1, 0.1, 0.01, 0.01, 0.01, 0.01, 0.01]
     # stateless: a run resumed at iteration 3 is on the second rate at once
     assert LearningRate().get_lr(3) == 0.01
-    reset_cfg()
+    experiment_cfg()
     lr = LearningRate()          # config.py default table
     assert lr.get_lr(10000) == 0.001 and lr.get_lr(10001) == 0.0001 and lr.get_lr(80001) == 1e-7 and lr.get_lr(10 ** 7) == 1e-7
 
@@ -94,9 +94,9 @@ def test_learning_rate_table_semantics():
 def test_flat_buffer_offsets_core_packed_imfeats_aligned():
     """Core variables are packed in the C ABI's order (581 793 floats for C=80, B=16); the reduce_imfeats tensors behind
     them start on 16-byte boundaries (fc.hip reads float4) and the padding is zero."""
-    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.network import Gnet, param_spec
-    reset_cfg()
+    experiment_cfg()
     net = Gnet(80, device="cpu")
     offs = net.tensor_offsets()
     sizes = [int(np.prod(s)) for _, s in param_spec(80, 16)]
@@ -118,7 +118,7 @@ def test_flat_buffer_offsets_core_packed_imfeats_aligned():
     named = net.flat_to_named(net.params)
     assert named["gnet/reduce_imfeats/fully_connected/weights"].shape == (7 * 7 * 32, 64)
     assert named["gnet/reduce_imfeats/fully_connected_1/biases"].data_ptr() == net.variables["gnet/reduce_imfeats/fully_connected_1/biases"].data_ptr()
-    reset_cfg()
+    experiment_cfg()
 
 
 def test_stale_library_is_detected_and_unhashed_library_is_loaded(tmp_path, monkeypatch):

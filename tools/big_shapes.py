@@ -4,11 +4,11 @@ pass -- inference runs), and the device repeating an earlier step bit for bit af
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
 dev = torch.device("cuda", 0)
-reset_cfg()
+experiment_cfg()
 net = Gnet(80, device=dev)
 imgs = [make_image(10000, 80, seed=1), make_image(9000, 80, seed=2)]
 gs, ls = [], []

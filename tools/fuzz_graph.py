@@ -6,7 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
 from oracle import gnet_oracle as go
@@ -20,9 +20,9 @@ nets = {}
 for case in range(cases):
     thr = float(rng.choice([0.2, 0.2, 0.2, 0.0, 0.5, 1.0]))
     if thr not in nets:
-        reset_cfg(); cfg.gnet.num_blocks = 1; cfg.gnet.neighbor_thresh = thr
+        experiment_cfg(); cfg.gnet.num_blocks = 1; cfg.gnet.neighbor_thresh = thr
         nets[thr] = Gnet(80, device=dev)
-    reset_cfg(); cfg.gnet.num_blocks = 1; cfg.gnet.neighbor_thresh = thr
+    experiment_cfg(); cfg.gnet.num_blocks = 1; cfg.gnet.neighbor_thresh = thr
     net = nets[thr]
     imgs = []
     for _ in range(int(rng.integers(1, 5))):
@@ -69,5 +69,5 @@ for case in range(cases):
         raise
     if os.environ.get("FUZZ_VERBOSE"):
         print("case", case, thr, desc, "E", len(pairs), flush=True)
-reset_cfg()
+experiment_cfg()
 print("graph fuzz: %d cases in %.1f s, all bit-exact" % (cases, time.time() - t0))

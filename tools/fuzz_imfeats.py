@@ -7,7 +7,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet
 from gossipnet_amd.synthetic import make_image
 from oracle import gnet_oracle as go
@@ -22,7 +22,7 @@ for case in range(cases):
     ch = int(rng.choice([4, 32, 64, 256, 512]))          # (gnet_fc_*: K = 49 ch and N multiples of 4, else GNET_ERR_UNSUPPORTED)
     dim = int(rng.choice([0, 64, 128]))
     imf = {"channels": ch, "imfeat_dim": dim, "crop": 7, "stride": 16}
-    reset_cfg()
+    experiment_cfg()
     cfg.gnet.num_blocks = NB
     cfg.gnet.imfeats = True
     cfg.gnet.imfeat_dim = dim
@@ -62,5 +62,5 @@ for case in range(cases):
         raise
     if os.environ.get("FUZZ_VERBOSE"):
         print("case", case, ch, dim, desc, flush=True)
-reset_cfg()
+experiment_cfg()
 print("imfeats fuzz: %d cases (%d compared with the oracle) in %.1f s, no fault" % (cases, compared, time.time() - t0))

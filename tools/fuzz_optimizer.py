@@ -4,14 +4,14 @@ python tools/fuzz_optimizer.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet
 from gossipnet_amd.train import Optimizer
 from oracle import optim_oracle as oo, gnet_oracle as go
 rng = np.random.default_rng(0)
 bad = 0
 for case in range(24):
-    reset_cfg()
+    experiment_cfg()
     imf = bool(case % 2)
     cfg.gnet.num_blocks = int(rng.integers(1, 4))
     nc = int(rng.choice([1, 80]))
@@ -48,4 +48,4 @@ for case in range(24):
         if not np.isfinite(got).all() or err > 3e-6:
             bad += 1; print("case", case, kind, clip, "imfeat", imf, "step", t, "err", err, "finite", np.isfinite(got).all())
 print("optimizer fuzz: 24 configurations x 3 steps,", bad, "mismatches")
-reset_cfg()
+experiment_cfg()

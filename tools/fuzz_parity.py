@@ -25,17 +25,17 @@ elif CONF == 1:
     net, orc = make_pair(NC, NB, normalize_loss=True)
 elif CONF == 2:
     NC, NB = 80, 1
-    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.network import Gnet
-    reset_cfg(); cfg.gnet.num_blocks = NB; cfg.gnet.bias_const_init = 0.5; cfg.gnet.pw_feat_multiplyer = 0.7
+    experiment_cfg(); cfg.gnet.num_blocks = NB; cfg.gnet.bias_const_init = 0.5; cfg.gnet.pw_feat_multiplyer = 0.7
     params = go.init_params(NC, NB, bias_init=0.5)
     net = Gnet(NC); net.load_params(params)
     orc = go.GnetOracle(NC, NB, params=params, pw_feat_multiplyer=0.7) if "pw_feat_multiplyer" in go.GnetOracle.__init__.__code__.co_varnames else None
 else:
     NC, NB = 80, 2
-    from gossipnet_amd.config import cfg, reset_cfg
+    from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.network import Gnet
-    reset_cfg(); cfg.gnet.num_blocks = NB; cfg.gnet.neighbor_feats = True
+    experiment_cfg(); cfg.gnet.num_blocks = NB; cfg.gnet.neighbor_feats = True
     params = go.init_params(NC, NB, neighbor_feats=True)
     net = Gnet(NC); net.load_params(params)
     orc = go.GnetOracle(NC, NB, params=params, neighbor_feats=True)

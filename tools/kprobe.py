@@ -3,13 +3,13 @@ python tools/kprobe.py [images] [preset]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
 dev = torch.device("cuda", 0)
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 preset = sys.argv[2] if len(sys.argv) > 2 else "dense"
-reset_cfg()
+experiment_cfg()
 net = Gnet(80, device=dev)
 imgs = [make_image(2000, 80, seed=i, preset=preset) for i in range(images)]
 for mode, batch in (("train", DeviceBatch(imgs, dev)),

@@ -12,10 +12,10 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dbg = torch.zeros(40 * 16, dtype=torch.int64, device="cuda")
 os.environ["GNET_DBG_PTR"] = str(dbg.data_ptr())
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
-reset_cfg()
+experiment_cfg()
 net = Gnet(80, device=torch.device("cuda"))
 imgs = [make_image(2000, 80, seed=i, preset="dense") for i in range(8)]
 b = DeviceBatch(imgs, torch.device("cuda"))

@@ -3,12 +3,12 @@ python tools/quick_bench.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
 dev = torch.device("cuda", 0)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-reset_cfg()
+experiment_cfg()
 net = Gnet(80, device=dev)
 for images in (1, 8):
     batch = DeviceBatch([make_image(2000, 80, seed=i) for i in range(images)], dev)

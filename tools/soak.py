@@ -6,14 +6,14 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from gossipnet_amd.config import cfg, reset_cfg
+from gossipnet_amd.config import cfg, experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
 from gossipnet_amd.train import Optimizer, train_step
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda", 0)
-reset_cfg()
+experiment_cfg()
 cfg.train.optimizer = "adam"
 net = Gnet(80, device=dev)
 opt = Optimizer(net)

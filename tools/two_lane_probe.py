@@ -3,11 +3,11 @@ python tools/two_lane_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gossipnet_amd.config import reset_cfg
+from gossipnet_amd.config import experiment_cfg
 from gossipnet_amd.network import Gnet, DeviceBatch
 from gossipnet_amd.synthetic import make_image
 dev = torch.device("cuda", 0)
-reset_cfg()
+experiment_cfg()
 imgs = [make_image(2000, 80, seed=i) for i in range(8)]
 
 

@@ -19,12 +19,12 @@ bufs = {}
 for k in KERNELS:
     bufs[k] = torch.zeros(MAXWG * 16, dtype=torch.int64, device="cuda")
     os.environ["GNET_TRACE_" + k] = str(bufs[k].data_ptr())
-from gossipnet_amd.config import cfg, reset_cfg  # noqa: E402
+from gossipnet_amd.config import cfg, experiment_cfg  # noqa: E402
 from gossipnet_amd.network import Gnet, DeviceBatch  # noqa: E402
 from gossipnet_amd.synthetic import make_image  # noqa: E402
 
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-reset_cfg()
+experiment_cfg()
 net = Gnet(80, device=torch.device("cuda"))
 b = DeviceBatch([make_image(2000, 80, seed=i, preset="dense") for i in range(images)], torch.device("cuda"))
 for _ in range(4):
