@@ -886,7 +886,7 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   for (int b = 1; b <= B; ++b) {
     w.pm[b - 1] = (const unsigned long long*)buf->blk_pm[b]; w.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
     w.rc[b - 1] = buf->blk_rc[b]; w.rn[b - 1] = buf->blk_rn[b];
-    w.w1t[b - 1] = pt + L.blk[b].w1; w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
+    w.w1t[b - 1] = pt + packed_w1_off(L, b); w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
   }
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_ties<<<dim3(16, B), 256, 0, s>>>(w));
@@ -937,7 +937,7 @@ int edge_stage_block(const gnet_config* cfg, const gnet_shape* shape, const Para
   e.apos = buf->apos + (size_t)(b - 1) * G.ap_stride;
   e.xmask = (const unsigned long long*)buf->xmask + (size_t)(b - 1) * G.xm_stride;
   e.pw = buf->pw_feats; e.rc = buf->blk_rc[b]; e.rn = buf->blk_rn[b]; e.d_pc = buf->d_pc;
-  e.w1t = pt + K.w1; e.w2 = params + K.w2;
+  e.w1t = pt + packed_w1_off(L, b); e.w2 = params + K.w2;
   e.d_pw = buf->d_pw; e.g1c = buf->d_g1;
   e.arena = buf->arena; e.stride = arena_stride(L.total); e.o_w2 = K.w2; e.o_b2 = K.b2;
   e.o_w1 = K.w1 + (L.raw ? (int64_t)2 * L.cprime * D_P : 0); e.w1_rows = L.raw ? 7 : D_E;

@@ -144,6 +144,14 @@ static inline ParamLayout make_layout(const gnet_config* c) {
   return L;
 }
 
+// Where the TRANSPOSED copy of block b's pw_fc1 lives in packed_t.  Every consumer reads it as [64][96] (pairwise | centre |
+// neighbour columns).  With a pw-MLP that is the transpose of the [96, 64] variable, at the variable's own offset; with
+// num_pwfeat_fc = 0 the variable is [2C'+7+64, 64] -- smaller than 96 rows for a single class -- and the [64][96] copy (geometry
+// rows | zeros | centre | neighbour, forward.hip pack_transpose) lives behind the parameters' copies.
+constexpr int64_t W1T_FLOATS = (int64_t)D_P * (D_E + 2 * D_R);
+static inline int64_t packed_w1_off(const ParamLayout& L, int b) { return L.raw ? L.total + (int64_t)(b - 1) * W1T_FLOATS : L.blk[b].w1; }
+static inline int64_t packed_floats(const ParamLayout& L, int nblocks) { return L.total + (L.raw ? (int64_t)nblocks * W1T_FLOATS : 0); }
+
 // ---- geometry of the winner maps / lists of the backward edge stage (plan.hip, backward*.hip) ----------
 struct EdgeGeom {
   size_t n_words;     // 64-bit words of a 1-bit-per-edge map
@@ -312,30 +320,6 @@ __device__ __forceinline__ void drain_vmem_before_loop() {
   __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
 }
 
-// Two row tiles (A0, A1) against the same Bt (B fetched once).
-template <int K>
-__device__ __forceinline__ void mma_abt2(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1,
-                                         int lda, const float* Bt, int ldb, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const float* a0p = A0 + r * lda + 4 * h;
-  const float* a1p = A1 + r * lda + 4 * h;
-  const float* bp = Bt + r * ldb + 4 * h;
-#pragma unroll 4
-  for (int k = 0; k < K; k += 8) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + k);
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + k);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + k);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
-  }
-}
-
 // Variants whose B operand streams from global memory (weights that do not fit in LDS): the 16-byte
 // B loads run PF k-steps (8 k each) ahead of the MFMAs that consume them, in a register ring.
 template <int K, int PF>
@@ -358,95 +342,6 @@ __device__ __forceinline__ void mma_abt_gB(f32x16& acc, const float* A, int lda,
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
   }
-}
-
-// Two row tiles against a B operand streamed from global memory, as a ROLLED software pipeline over pairs of k-steps
-// (8 k each) pinned with scheduling barriers: the weight fragments of the NEXT pair are requested before the 16 MFMAs
-// of this pair.  (Written as an unrolled register ring, the scheduler sinks every load to just in front of its first
-// use -- `global_load; s_waitcnt vmcnt(0); v_mfma` -- and each k-step pays an L2 latency.)
-template <int K>
-__device__ __forceinline__ void mma_abt2_gB(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1, int lda,
-                                            const float* __restrict__ Bt, int ldb, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const float* a0p = A0 + r * lda + 4 * h;
-  const float* a1p = A1 + r * lda + 4 * h;
-  const float* bp = Bt + (size_t)r * ldb + 4 * h;
-  static_assert(K % 16 == 0, "pairs of k-steps");
-  f32x4 bA = *reinterpret_cast<const f32x4*>(bp), bB = *reinterpret_cast<const f32x4*>(bp + 8);
-#pragma unroll 1
-  for (int k = 0; k < K; k += 16) {
-    const int kn = min(k + 16, K - 16);                  // (the last pair re-reads itself)
-    const f32x4 nA = *reinterpret_cast<const f32x4*>(bp + kn), nB = *reinterpret_cast<const f32x4*>(bp + kn + 8);
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + k), a1 = *reinterpret_cast<const f32x4*>(a1p + k);
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(a0p + k + 8), c1 = *reinterpret_cast<const f32x4*>(a1p + k + 8);
-    __builtin_amdgcn_sched_barrier(0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bA.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bA.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bA.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bA.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bA.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bA.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bA.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bA.w, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.x, bB.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.x, bB.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.y, bB.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.y, bB.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.z, bB.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.z, bB.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.w, bB.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.w, bB.w, acc1, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    bA = nA; bB = nB;
-  }
-}
-
-// Two row tiles against a B operand stored FRAGMENT-MAJOR (forward.hip pack_transpose): Bf + (s * 64 + lane) * 4 is the lane's
-// 16-byte fragment of k-step group s -- one contiguous 1 KB block per load instruction.
-// The two operand streams are pipelined at DIFFERENT depths, in units of one fragment (8 MFMAs: four k-steps
-// of both row tiles): the B fragments come from L2 (~1 us under load) and are requested three units ahead, the A rows come from
-// LDS and are requested one unit ahead.  32 operand registers instead of 48, the same k order (bit-identical sums).
-#define GNET_MMA8(acc0, acc1, p0, p1, bP)                                               \
-  do {                                                                                 \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.x, bP.x, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.x, bP.x, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.y, bP.y, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.y, bP.y, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.z, bP.z, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.z, bP.z, acc1, 0, 0, 0);            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.w, bP.w, acc0, 0, 0, 0);            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.w, bP.w, acc1, 0, 0, 0);            \
-  } while (0)
-template <int K, int DB = 4>
-__device__ __forceinline__ void mma_abt2_fB_deep(f32x16& acc0, f32x16& acc1, const float* A0, const float* A1, int lda,
-                                                 const float* __restrict__ Bf, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const float* a0p = A0 + r * lda + 4 * h;
-  const float* a1p = A1 + r * lda + 4 * h;
-  const float* bp = Bf + 4 * lane;
-  constexpr int NF = K / 8;
-  static_assert(NF % DB == 0 && NF >= 2 * DB && DB % 2 == 0, "rings of DB fragments");
-#define GNET_BF(f_) (*reinterpret_cast<const f32x4*>(bp + (f_) * 256))
-#define GNET_A0(f_) (*reinterpret_cast<const f32x4*>(a0p + (f_) * 8))
-#define GNET_A1(f_) (*reinterpret_cast<const f32x4*>(a1p + (f_) * 8))
-  f32x4 b[DB], x[2], y[2];
-#pragma unroll
-  for (int i = 0; i < DB - 1; ++i) b[i] = GNET_BF(i);
-  x[0] = GNET_A0(0); y[0] = GNET_A1(0);
-#pragma unroll 1
-  for (int f = 0; f < NF; f += DB) {
-#pragma unroll
-    for (int i = 0; i < DB; ++i) {
-      b[(i + DB - 1) % DB] = GNET_BF(min(f + i + DB - 1, NF - 1));           // (the tail re-reads the last fragment)
-      x[(i + 1) & 1] = GNET_A0(min(f + i + 1, NF - 1)); y[(i + 1) & 1] = GNET_A1(min(f + i + 1, NF - 1));
-      __builtin_amdgcn_sched_barrier(0);
-      GNET_MMA8(acc0, acc1, x[i & 1], y[i & 1], b[i]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#undef GNET_BF
-#undef GNET_A0
-#undef GNET_A1
 }
 
 // acc[m][n] += X[32 rows x (32*MI)]^T * Y[32 rows x (32*NJ)] (weight-gradient shape: the

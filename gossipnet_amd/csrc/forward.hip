@@ -3,14 +3,14 @@
 //
 // Kernels
 //   pack_transpose   W[in,out] -> Wt[out,in] for every FC (B operands are read 4-along-K)
-//   pw_fwd           _geometry_feats (network.py:411-454) fused with _pw_feats_fc (:324-342):
-//                    the [E,167] feature matrix never exists; fc1 uses the one-hot x score
-//                    structure of its first 2C columns (2 row lookups + 7 geometry FMAs per output).
+//   edge_geometry    _geometry_feats (network.py:411-454): the 7 geometry columns per edge; the 2C' one-hot x score columns
+//                    as two per-detection tables (the [E,167] feature matrix never exists)
+//   pw_fwd2          _pw_feats_fc (:324-342): fc1 = two table rows + a K = 8 product, fc2 with its weights resident in
+//                    registers, fc3 chained on fc2's accumulators (skipped with num_pwfeat_fc = 0)
 //   edge_fwd         per block: build_context + pw_fc1 + pw_fc2 + segment_max (:367-388)
 //   node_fwd         per block: fc1, fc2, shortcut (:390-408) of block b and reduce_dim (:348-354)
 //                    + the per-node halves of pw_fc1 of block b+1; after the last block: head (:258-273)
 // All dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
-#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -21,7 +21,7 @@ namespace {
 // (columns 0-6 = the seven geometry rows, 7-31 = zeros, 32-63 centre, 64-95 neighbour: the edge kernels then multiply the
 // geometry columns, padded to 32 in pw_feats, by it -- exact zeros for the padding -- and the 2C' score rows enter through the
 // per-detection tables node_fwd adds to rc / rn).
-__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, int raw, long long* off, int* in, int* out, int* kind) {
+__device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, int raw, long long* off, int* in, int* out, int* kind, long long* poff) {
   const int kp = raw ? dpw : D_E;
   const long long pw_sz = raw ? 0 : (long long)dpw * D_H + D_H + D_H * D_H + D_H + D_H * D_E + D_E;
   const long long blk_core = D_S * D_R + D_R + (long long)(kp + 2 * D_R) * D_P + D_P + D_P * D_P + D_P + D_P * D_P + D_P +
@@ -41,7 +41,12 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, i
     if (m == 5) { *off = o + blk_core; *in = D_S; *out = D_R; return; }
     if (m == 0) { *off = o; *in = D_S; *out = D_R; return; }
     o += D_S * D_R + D_R;
-    if (m == 1) { *off = o; *in = kp + 2 * D_R; *out = D_P; *kind = raw ? 1 : 0; return; }
+    if (m == 1) {
+      *off = o; *in = kp + 2 * D_R; *out = D_P; *kind = raw ? 1 : 0;
+      // (raw: the [64][96] copy lives behind the parameters' copies -- common.hpp packed_w1_off)
+      if (raw) *poff = pw_sz + (long long)nblocks * blk_sz + (D_S * D_HEAD + D_HEAD + D_HEAD * D_HEAD + D_HEAD + D_HEAD + 1) + (long long)b * (D_P * (D_E + 2 * D_R));
+      return;
+    }
     o += (long long)(kp + 2 * D_R) * D_P + D_P;
     if (m == 2) { *off = o; *in = D_P; *out = D_P; return; }
     o += D_P * D_P + D_P;
@@ -59,8 +64,8 @@ __device__ __forceinline__ void mat_info(int id, int dpw, int nblocks, int nf, i
 constexpr int PACK_X = 32;   // workgroups per matrix: the 256 x 256 one is 32 strided 4-byte gathers per thread at 8 (23 us), 8 at 32 (14 us)
 __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ params, float* __restrict__ packed,
                                                       int dpw, int nblocks, int nf, int raw) {
-  long long off; int in, out, kind;
-  mat_info(blockIdx.y, dpw, nblocks, nf, raw, &off, &in, &out, &kind);
+  long long off, poff = -1; int in, out, kind;
+  mat_info(blockIdx.y, dpw, nblocks, nf, raw, &off, &in, &out, &kind, &poff);
   const int total = in * out;
   if (kind == 2) {
     // pw_feats/fc2 (256 x 256) is streamed from L2 by pw_fwd as MFMA operand fragments: FRAGMENT-MAJOR, so that the 64
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ 
       float v = 0.f;
       if (k < 7) v = params[off + (long long)(g0 + k) * D_P + o];
       else if (k >= D_E) v = params[off + (long long)(dpw + k - D_E) * D_P + o];
-      packed[off + i] = v;
+      packed[poff + i] = v;
     }
     return;
   }
@@ -94,9 +99,6 @@ __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int PW_T = 64;         // edges per workgroup iteration
-constexpr int PW_LD = D_H + 4;   // padded LDS row (conflict-free 16-B operand reads)
-
 struct GeoArgs {
   int n_edge;
   const int* edge_c; const int* edge_n; const float* edge_iou;
@@ -117,7 +119,6 @@ struct GeoArgs {
   // writes them with a plain store.  node_fwd reads the flag instead of dividing row pointers by the range size 16 times
   // per thread and launch.
   const int* row_ptr; int* straddle; int ef_tiles, ef_waves;
-  int* pw_claim; int pw_claim0;   // pw_fwd's tile counter and its start value (the tiles behind every workgroup's first two)
   // num_pwfeat_fc = 0 (network.py:217-221: pw_feats = the raw feature columns): no tables here (the score columns enter every
   // block's pw_fc1 through per-block tables, node_fwd); the 7 geometry columns go to pw [E,32] padded with zeros -- the
   // edge kernels' pairwise operand -- and a self pair's neighbour row is row n_det + 1 + c of rn (its score term alone)
@@ -129,7 +130,6 @@ struct GeoArgs {
 // operation order.
 __global__ void __launch_bounds__(256) edge_geometry(const GeoArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e == 0) *a.pw_claim = a.pw_claim0;
   for (int i = e; i < a.n_det; i += gridDim.x * 256) {
     const int eb = a.row_ptr[i], ee = a.row_ptr[i + 1];
     a.straddle[i] = (ee == eb || efw_owner(eb >> 5, a.ef_tiles, a.ef_waves) != efw_owner((ee - 1) >> 5, a.ef_tiles, a.ef_waves)) ? 1 : 0;
@@ -189,227 +189,13 @@ struct PwFwdArgs {
   const float* tc; const float* tn;     // [N,256] per-detection score terms of fc1 (edge_geometry): tc includes the bias
   const float* w1;                      // natural [dpw,256]: the 7 geometry rows are read here
   const float* w2t; const float* b2;    // fc2 as operand fragments (pack_transpose: fragment-major), [256]
-  const float* w3t; const float* b3;    // transposed [32,256]
-  const float* w3;                      // natural [256,32] (pw_fwd2's resident fc3 operand)
+  const float* w3; const float* b3;     // natural [256,32] (the resident fc3 operand), [32]
   float* h1; float* h2; float* pw;
-  int training;
-  int* claim;                           // tile counter (reset by edge_geometry, the launch in front of this one)
-  GNET_TRACE_FIELD
 };
 
-// Memory discipline (vmcnt is one in-order counter for loads AND stores: a wait on a load also waits for
-// every older store to be acknowledged by L2, ~1-2 k cycles): inside a tile no global load is issued
-// behind a store.  The tile's 32 neighbour rows of W1 are all requested before the first is used; h1 and
-// h2 leave through LDS as whole 1 KB rows (one 16-byte store per lane) after the MFMA phase that reads
-// them; the next tile's geometry and the fc3 operand (W3) are fetched into registers before those stores.
-__global__ void __launch_bounds__(512, 4) pw_fwd(const PwFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sH = smem;                          // [64][260]
-  float* sR = sH;                            // [4][64][32] fc3 partials, aliased over sH (2 workgroups / CU)
-  float* sStage = sH + PW_T * PW_LD;         // 2 x { geo [64][8], centre index [64], neighbour index [64] }: this tile / the next
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31, half = lane >> 5;
-  // fc1's geometry rows as the A operand of a TRANSPOSED product (h1^T = Wg^T . geo^T, as edge_fwd_w's first layer): the
-  // wave owns output features [32 wave, 32 wave + 32); lane (feature col, half) supplies Wg[4 half + s][32 wave + col] at
-  // k-step s -- the k pairing (s, 4 + s) lets the B operand, the lane's edge's geometry columns 4 half .. 4 half + 3, be ONE
-  // 16-byte LDS read.  Row 7 of the geometry block does not exist (the eighth column is zero padding).
-  const int geo_row0 = 2 * a.cprime;
-  float wgA[4];
-#pragma unroll
-  for (int s_ = 0; s_ < 4; ++s_) {
-    const int k = 4 * half + s_;
-    wgA[s_] = k < 7 ? a.w1[(size_t)(geo_row0 + k) * D_H + 32 * wave + col] : 0.f;
-  }
-  const float bias2 = a.b2[32 * wave + col];
-  const float bias3 = a.b3[tid & 31];
-  // fc3: wave = (row tile mt, K quarter kq)
-  const int mt = wave & 1, kq = wave >> 1;
-  // The geometry columns [64][8] and the centre / neighbour indices [64] + [64] of a tile reach LDS by DMA (global_load_lds:
-  // lane i -> its 16 (waves 0 / 1: the two halves of the geometry) or 4 bytes (wave 2: edge_c, wave 3: edge_n) at base +
-  // size * i), one tile ahead, into the staging buffer the previous tile has finished with.  No staging registers: at 128
-  // registers per wave they were spilled, and a spill reload behind the tile's h1 / h2 stores made the in-order memory
-  // counter wait for those stores.
-  const int last = a.n_edge - 1;
-#define PW_STAGE_DMA(dst_, tile_)                                                                       \
-  do {                                                                                                  \
-    if (wave < 2) {                                                                                     \
-      const int e_ = min((tile_) * PW_T + (tid >> 1), last);                                            \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.geo + (size_t)e_ * 8 + 4 * (tid & 1)), \
-                                       (__attribute__((address_space(3))) void*)((dst_) + 256 * wave), 16, 0, 0);          \
-    } else if (wave < 4) {                                                                              \
-      const int* src_ = wave == 2 ? a.edge_c : a.edge_n;                                                \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + min((tile_) * PW_T + lane, last)), \
-                                       (__attribute__((address_space(3))) void*)((dst_) + PW_T * 8 + PW_T * (wave - 2)), 4, 0, 0); \
-    }                                                                                                   \
-  } while (0)
-  if ((int)blockIdx.x * PW_T < a.n_edge) {
-    PW_STAGE_DMA(sStage, (int)blockIdx.x);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's staging data (the loop's first barrier publishes it)
-  }
-  int it = 0;
-  // Tiles are CLAIMED, not dealt: of a CU's two workgroups the older one wins the issue arbitration and walks a tile ~15 %
-  // faster -- dealt round-robin, the older half of the grid ran out of tiles at 1.46 ms of a 1.71 ms launch (wg_trace, slot
-  // 14) and every CU spent the last 15 % with one workgroup.  A workgroup's first two tiles are fixed (blockIdx, blockIdx +
-  // grid); every further one comes from a counter, claimed two tiles ahead (the atomic's round trip hides behind fc3, the
-  // staging DMA of a tile is issued one tile ahead as before).  Which workgroup computes a tile changes no bit of it.
-  __shared__ int sClaim;
-  int tile = blockIdx.x, next = blockIdx.x + gridDim.x;
-
-  for (; tile * PW_T < a.n_edge; ++it) {
-    const int e0 = tile * PW_T;
-    // ---- phase 0: the tile's geometry columns and pair indices were staged during the previous tile
-    const float* sGeo = sStage + (it & 1) * (PW_T * 12);
-    const int* sIdx = reinterpret_cast<const int*>(sGeo + PW_T * 8);
-    float* nGeo = sStage + ((it & 1) ^ 1) * (PW_T * 12);
-    // this tile's staging DMA was issued a tile ago, in front of at least the four pw stores of every wave: "all but
-    // the four youngest operations" covers it without waiting for those stores
-    if (wave < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (it == 10) GSTAMP(a, 0);
-    __syncthreads();
-    if (it == 10) GSTAMP(a, 1);
-    // ---- phase 1: fc1 + ReLU.  h1[e] = relu(tc[c] + tn[n] + geo[e] . Wg): the accumulators of the transposed product
-    // (lane = edge col of row tile 0 / 1, register r = feature 32 wave + 8 (r >> 2) + 4 half + (r & 3)) START from the two
-    // table rows, gathered as the lane's own 16-byte pieces; 4 MFMAs per row tile add the geometry term (K = 8); one
-    // integer max rectifies; the rows go to LDS as 16-byte stores in the [edge][feature] layout fc2 reads.  ~100 vector
-    // instructions per wave and tile; the per-edge loop it replaces (two row look-ups, 7 FMAs on broadcast LDS reads and a
-    // store PER EDGE AND THREAD: ~640) took 18 of a tile's 46 us waiting for issue slots between the other workgroup's MFMAs.
-    f32x16 acc0, acc1;
-    int claimed = 0;
-    {
-      const unsigned fo = (unsigned)(32 * wave + 4 * half) * 4u;
-      const unsigned ocA = (unsigned)sIdx[col] * (D_H * 4u) + fo, onA = (unsigned)sIdx[PW_T + col] * (D_H * 4u) + fo;
-      const unsigned ocB = (unsigned)sIdx[32 + col] * (D_H * 4u) + fo, onB = (unsigned)sIdx[PW_T + 32 + col] * (D_H * 4u) + fo;
-      float4 tcA[4], tnA[4], tcB[4], tnB[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { tcA[g] = ldg4_b(a.tc, ocA + 32u * g); tnA[g] = ldg4_b(a.tn, onA + 32u * g); }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { tcB[g] = ldg4_b(a.tc, ocB + 32u * g); tnB[g] = ldg4_b(a.tn, onB + 32u * g); }
-      // the claim of the tile after the next one, HERE: the compiler waits for an atomic's result on the spot (vmcnt(0): the result
-      // merges with the other lanes' value), and behind the gathers that wait is the one this wave is about to make anyway.
-      // In front of fc3, where it used to sit, it made wave 0 wait for the acknowledgement of its eight h1 stores and the
-      // atomic's round trip in front of a workgroup barrier -- every wave of the tile waited with it.
-      if (tid == 0) claimed = atomicAdd(a.claim, 1);
-      const f32x4 gA = *reinterpret_cast<const f32x4*>(sGeo + col * 8 + 4 * half);
-      const f32x4 gB = *reinterpret_cast<const f32x4*>(sGeo + (32 + col) * 8 + 4 * half);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        acc0[4 * g + 0] = tcA[g].x + tnA[g].x; acc0[4 * g + 1] = tcA[g].y + tnA[g].y; acc0[4 * g + 2] = tcA[g].z + tnA[g].z; acc0[4 * g + 3] = tcA[g].w + tnA[g].w;
-      }
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[0], gA.x, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[1], gA.y, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gA.z, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gA.w, acc0, 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        acc1[4 * g + 0] = tcB[g].x + tnB[g].x; acc1[4 * g + 1] = tcB[g].y + tnB[g].y; acc1[4 * g + 2] = tcB[g].z + tnB[g].z; acc1[4 * g + 3] = tcB[g].w + tnB[g].w;
-      }
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[0], gB.x, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[1], gB.y, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gB.z, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gB.w, acc1, 0, 0, 0);
-      float* dA = sH + col * PW_LD + 32 * wave + 4 * half;
-      float* dB = dA + 32 * PW_LD;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<float4*>(dA + 8 * g) = make_float4(relu_bits(acc0[4 * g]), relu_bits(acc0[4 * g + 1]), relu_bits(acc0[4 * g + 2]), relu_bits(acc0[4 * g + 3]));
-        *reinterpret_cast<float4*>(dB + 8 * g) = make_float4(relu_bits(acc1[4 * g]), relu_bits(acc1[4 * g + 1]), relu_bits(acc1[4 * g + 2]), relu_bits(acc1[4 * g + 3]));
-      }
-    }
-    if (it == 10) GSTAMP(a, 2);
-    __syncthreads();
-    if (it == 10) GSTAMP(a, 3);
-    // ---- phase 2: fc2 (K = 256): wave w owns output columns [32w, 32w+32) for both row tiles.  At a raised wave priority:
-    // the CU's other workgroup is, more often than not, in one of its light phases (fc1, the h2 / partial-sum round trips, the
-    // stores), and its vector instructions no longer cut into this MFMA stream (the fp32 MFMA and the vector ALU share lanes):
-    // 2.13 -> 2.06 ms.  (A per-CU token that keeps the two workgroups' fc2 phases apart altogether -- CU id from HW_ID /
-    // XCC_ID, compare-and-swap on a global word -- gives the same 3 %, and 4 % together with this; not worth its machinery.)
-    acc0 = zero16(); acc1 = zero16();
-    __builtin_amdgcn_s_setprio(2);
-    mma_abt2_fB_deep<D_H, 4>(acc0, acc1, sH, sH + 32 * PW_LD, PW_LD, a.w2t + (size_t)wave * (32 * 256), lane);
-    __builtin_amdgcn_s_setprio(0);
-    // requested before this tile's stores: the next tile's geometry and records, straight into the other staging buffer
-    if (next * PW_T < a.n_edge) PW_STAGE_DMA(nGeo, next);
-    if (a.training) {      // fc1 activations: rows [8 wave, 8 wave + 8) of the tile (rows past E land in the slack)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int row = 8 * wave + q;
-        *reinterpret_cast<float4*>(a.h1 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
-      }
-    }
-    if (it == 10) GSTAMP(a, 4);
-    __syncthreads();   // every wave has finished reading fc1 activations
-    if (it == 10) GSTAMP(a, 5);
-    {
-      // one base register + constant offsets (hoisted out of the tile loop the sixteen row addresses were kept in registers
-      // of their own -- and spilled: their reloads sat behind the tile's global stores)
-      unsigned hb = (unsigned)((4 * half) * PW_LD + 32 * wave + col) * 4u;
-      asm volatile("" : "+v"(hb));
-      float* hp2 = reinterpret_cast<float*>(reinterpret_cast<char*>(sH) + hb);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        hp2[crow(r, 0) * PW_LD] = fmaxf(acc0[r] + bias2, 0.f);
-        hp2[(32 + crow(r, 0)) * PW_LD] = fmaxf(acc1[r] + bias2, 0.f);
-      }
-    }
-    // fc3 operand of this wave (its wait sits two barriers behind the h1 stores, which are long acknowledged)
-    f32x4 w3f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3t + (size_t)col * D_H + 64 * kq + 4 * half + 8 * k);
-    if (it == 10) GSTAMP(a, 6);
-    __syncthreads();
-    if (it == 10) GSTAMP(a, 7);
-    // ---- phase 3: fc3 (256 -> 32): wave = (row tile, K quarter), partial sums through LDS
-    {
-      f32x16 acc = zero16();
-
-      const float* ap = sH + (mt * 32 + col) * PW_LD + 64 * kq + 4 * half;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * k);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w3f[k].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w3f[k].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w3f[k].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w3f[k].w, acc, 0, 0, 0);
-      }
-      if (a.training) {    // fc2 activations, same row split
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int row = 8 * wave + q;
-          *reinterpret_cast<float4*>(a.h2 + (size_t)(e0 + row) * D_H + 4 * lane) = *reinterpret_cast<const float4*>(sH + row * PW_LD + 4 * lane);
-        }
-      }
-      if (it == 10) GSTAMP(a, 8);
-      __syncthreads();   // every wave is done with the fc2 outputs: the partials may overwrite them
-      if (it == 10) GSTAMP(a, 9);
-      unsigned rb = (unsigned)((kq * PW_T + mt * 32 + 4 * half) * D_E + col) * 4u;
-      asm volatile("" : "+v"(rb));                       // (one base register + constant offsets, as above)
-      float* rp2 = reinterpret_cast<float*>(reinterpret_cast<char*>(sR) + rb);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rp2[crow(r, 0) * D_E] = acc[r];
-    }
-    if (tid == 0) sClaim = claimed;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 512 * i;
-      float v = sR[0 * PW_T * D_E + idx];
-      v += sR[1 * PW_T * D_E + idx];
-      v += sR[2 * PW_T * D_E + idx];
-      v += sR[3 * PW_T * D_E + idx];
-      a.pw[(size_t)e0 * D_E + idx] = fmaxf(v + bias3, 0.f);     // rows past E land in the buffer's slack
-    }
-    tile = next;
-    next = __builtin_amdgcn_readfirstlane(sClaim);             // (rewritten only behind the next tile's barriers)
-    if (it == 10) GSTAMP(a, 15);
-  }
-  GSTAMP(a, 14);                               // (trace builds: when the workgroup ran out of tiles)
-#undef PW_STAGE_DMA
-}
-
-constexpr size_t kPwFwdSmem = (size_t)(PW_T * PW_LD + 2 * (PW_T * 12)) * sizeof(float);   // staging: 8 floats + 2 indices per edge (+ 2 spare)
 
 // ------------------------------------------------------------------------------------------
-// pw_fwd2: the same layer stack as pw_fwd with the WEIGHTS RESIDENT IN REGISTERS: one 8-wave workgroup per CU (two waves per
+// pw_fwd2: _pw_feats_fc with the WEIGHTS RESIDENT IN REGISTERS (round 5; it replaces pw_fwd, which streamed W2 from L2): one 8-wave workgroup per CU (two waves per
 // SIMD, 256 registers each), wave w owns output features [32 w, 32 w + 32) of fc2 for every tile the workgroup walks and keeps
 // its 256 x 32 slice of W2 (128 registers), its 32 x 32 slice of W3 (16) and its bias pieces (16) for the whole kernel -- fc2's
 // weight stream from L2 (the 11 % of round 4's probe, and 32 operand registers of pipeline) is gone.
@@ -1292,7 +1078,6 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
   void* prof = buf->profiler;
   GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(PACK_X, (L.raw ? 0 : 3) + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats, L.raw));
 
-  const int pw_grid = min((E + PW_T - 1) / PW_T, 512);
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
     GeoArgs g;
@@ -1303,7 +1088,6 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.w1 = params + L.pw1; g.b1 = params + L.pb1; g.tc = buf->pw_tc; g.tn = buf->pw_tn;
     g.raw = L.raw; g.pw = buf->pw_feats;
     g.row_ptr = buf->row_ptr; g.straddle = buf->scratch_i;
-    g.pw_claim = buf->scratch_i + N; g.pw_claim0 = 2 * pw_grid;
     g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
     GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
   }
@@ -1312,15 +1096,10 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     a.n_edge = E; a.cprime = L.cprime; a.geo = buf->geo; a.edge_c = buf->edge_c; a.edge_n = buf->edge_n;
     a.tc = buf->pw_tc; a.tn = buf->pw_tn; a.w1 = params + L.pw1;
     a.w2t = pt + L.pw2; a.b2 = params + L.pb2;
-    a.w3t = pt + L.pw3; a.b3 = params + L.pb3;
-    a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats; a.training = training; a.claim = buf->scratch_i + N;
-    GNET_TRACE_SET(a, "PW_FWD", true);
+    a.w3 = params + L.pw3; a.b3 = params + L.pb3;
+    a.h1 = buf->pw_h1; a.h2 = buf->pw_h2; a.pw = buf->pw_feats;
     // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
-    a.w3 = params + L.pw3;
-    if (getenv("GNET_PW_FWD_OLD")) {       // (A/B during round 5)
-      HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwdSmem));
-      GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd<<<pw_grid, 512, kPwFwdSmem, s>>>(a));
-    } else {
+    {
       const int grid2 = min((E + PW2_T - 1) / PW2_T, 256);
       if (training) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
@@ -1356,7 +1135,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     } else { n.w3t = n.b3 = n.w4t = n.b4 = nullptr; n.q = n.x_out = nullptr; }
     if (b < B) {
       n.wrt = pt + L.blk[b + 1].wr; n.br = params + L.blk[b + 1].br;
-      n.w1t = pt + L.blk[b + 1].w1; n.b1 = params + L.blk[b + 1].b1;
+      n.w1t = pt + packed_w1_off(L, b + 1); n.b1 = params + L.blk[b + 1].b1;
       n.r = buf->blk_r[b + 1]; n.rc = buf->blk_rc[b + 1]; n.rn = buf->blk_rn[b + 1];
       n.wrnt = cfg->neighbor_feats ? pt + L.blk[b + 1].wrn : nullptr;
       n.brn = cfg->neighbor_feats ? params + L.blk[b + 1].brn : nullptr;
@@ -1378,7 +1157,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         EdgeFwdArgs e;
         e.n_edge = E; e.edge_c = buf->edge_c; e.edge_n = buf->edge_n; e.pw = buf->pw_feats;
         e.rc = buf->blk_rc[b + 1]; e.rn = buf->blk_rn[b + 1];
-        e.w1t = pt + L.blk[b + 1].w1; e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
+        e.w1t = pt + packed_w1_off(L, b + 1); e.w2t = pt + L.blk[b + 1].w2; e.b2 = params + L.blk[b + 1].b2;
         e.pm = (unsigned long long*)buf->blk_pm[b + 1]; e.row_ptr = buf->row_ptr;
         e.edge_nz = buf->edge_nz;
         e.h1_out = keep_h1 ? buf->blk_h1[b + 1] : nullptr;

@@ -39,7 +39,7 @@ size_t carve(const gnet_config* cfg, const gnet_shape* sh, int training, void* w
   b.edge_t = c.take<int32_t>(Ep);
   b.edge_nz = c.take<int32_t>(Ep);
   b.pw_feats = c.take<float>(Ep * D_E);
-  b.packed_t = c.take<float>((size_t)L.total);
+  b.packed_t = c.take<float>((size_t)packed_floats(L, cfg->num_blocks));
   b.prediction = c.take<float>(Np);
   b.scratch_i = c.take<int32_t>(N + 1024);
   b.geo = c.take<float>(Ep * 8);

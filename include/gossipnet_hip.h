@@ -142,9 +142,9 @@ typedef struct gnet_buffers {
   int32_t* pw_rows;   /* [n_edge+64] ascending indices of the edges with a non-zero d_pw row (rows of the pw-MLP backward) */
   float* w1_s;        /* [n_det,256] sum of d_h1 over the detection's own pairs (centre role)      */
   float* w1_t;        /* [n_det,256] sum of d_h1 over the reversed pairs (neighbour role)          */
-  float* packed_t;    /* [param_count] transposed copies of the weight matrices */
+  float* packed_t;    /* [param_count (+ num_blocks x 64 x 96 with num_pwfeat_fc = 0)] transposed copies of the weight matrices */
   float* arena;       /* per-workgroup partial weight gradients */
-  int32_t* scratch_i; /* [n_det + 1024] per detection: 1 = its segment-max records start from zero in every block (no edge, or its edges are split between two waves' ranges of the forward edge kernel), written once per step by gnet_forward; [n_det]: the tile-claim counter of pw_fwd (reset and used inside gnet_forward only; no backward kernel touches scratch_i).  Because of this counter and the flags, two gnet_forward calls in flight at the same time must not share one planned workspace. */
+  int32_t* scratch_i; /* [n_det + 1024] per detection: 1 = its segment-max records start from zero in every block (no edge, or its edges are split between two waves' ranges of the forward edge kernel), written once per step by gnet_forward (no backward kernel touches scratch_i).  Two gnet_forward calls in flight at the same time must not share one planned workspace. */
   void* match_ws;     /* det_matching_workspace_bytes(n_det, n_gt) */
   size_t match_ws_bytes;
   size_t arena_floats;
