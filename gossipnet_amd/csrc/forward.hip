@@ -222,6 +222,11 @@ __device__ __forceinline__ void pw2_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// global accesses of pw_fwd2 as (wave-uniform 64-bit base, SGPRs) + (32-bit per-lane byte offset, one loop-invariant VGPR): the
+// `saddr + voffset` form costs no vector instruction per access (base[row * ld + lane] costs three to five 64-bit ones)
+__device__ __forceinline__ void pw2_st4(float* ubase, unsigned off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + off) = v; }
+__device__ __forceinline__ void pw2_st2(float* ubase, unsigned off, const float2& v) { *reinterpret_cast<float2*>(reinterpret_cast<char*>(ubase) + off) = v; }
+
 template <bool TRAINING>
 __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -262,6 +267,8 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
   const int er = tid >> 4, j0 = (tid & 15) * 2;   // the (edge, output pair) of a tile this thread reduces
   const float b3a = a.b3[j0], b3b = a.b3[j0 + 1];
   const unsigned fo = (unsigned)(32 * wave + 4 * half) * 4u;   // the lane's first feature piece in a table row (bytes)
+  const unsigned pw_lo = (unsigned)(er * D_E + j0) * 4u;       // the thread's output pair inside a tile of pw
+  const unsigned h2_lo = (unsigned)(col * D_H + 4 * half) * 4u;   // the lane's row and half inside a tile of h2
 
 #define PW2_EDGE(u_) min(min((u_), nt - 1) * PW2_T + col, last)
 #define PW2_REQUEST(c_, n_)                                                                        \
@@ -287,16 +294,26 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
       *reinterpret_cast<float4*>(d_ + 8 * g) = make_float4(relu_bits(h_[4 * g]), relu_bits(h_[4 * g + 1]), relu_bits(h_[4 * g + 2]), relu_bits(h_[4 * g + 3])); \
   } while (0)
 
+  // forward-only: the fc3 partial product of a tile is DEFERRED into the next tile's stream (its rectified accumulators and W3
+  // pieces kept across the barrier) -- the tile then ends with its last fc2 MFMAs instead of 16 MFMAs + 16 LDS stores + their
+  // drain with nothing of this wave's in the pipe: 1.65 -> 1.56 ms.  Not in a training step: there the same move is +1 % (the
+  // h2 stores at the tile's end want the fc3 MFMAs behind them).
+  constexpr bool DEFER = !TRAINING;
+  f32x16 hprev = zero16();        // (DEFER) the previous tile's rectified fc2 accumulators: fc3's A operand
+  if (DEFER) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w3r[r] = w3p[crow(r, 0) * D_E];
+  }
   // ---- front: the first tile's h1, the records of the second
   float4 tcv[4], tnv[4];
   f32x4 gv;
   int c1, n1;
   {
-    const int e = PW2_EDGE(t0);
-    const int c0 = a.edge_c[e], n0 = a.edge_n[e];
-    gv = *reinterpret_cast<const f32x4*>(a.geo + (size_t)e * 8 + 4 * half);
-    const int e1 = PW2_EDGE(t0 + 1);
-    c1 = a.edge_c[e1]; n1 = a.edge_n[e1];
+    const unsigned e = (unsigned)PW2_EDGE(t0);
+    const int c0 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e), n0 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e);
+    { const float4 g_ = ldg4_b(a.geo, 32u * e + 16u * half); gv = f32x4{g_.x, g_.y, g_.z, g_.w}; }
+    const unsigned e1 = (unsigned)PW2_EDGE(t0 + 1);
+    c1 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e1); n1 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e1);
     PW2_REQUEST(c0, n0);
     PW2_FC1(sH);
   }
@@ -313,13 +330,16 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
     f32x4 bq0 = PW2_HB(0), bq1 = PW2_HB(1), bq2;
     // requests of the next tile (its h1 is formed in the middle of this tile's stream) and the records of the one after it
     int c2, n2;
-    {
-      PW2_REQUEST(c1, n1);
-      const int e1 = PW2_EDGE(t + 1);
-      gv = *reinterpret_cast<const f32x4*>(a.geo + (size_t)e1 * 8 + 4 * half);
-      const int e2 = PW2_EDGE(t + 2);
-      c2 = a.edge_c[e2]; n2 = a.edge_n[e2];
+#define PW2_NEXT_REQUESTS()                                                                             \
+    {                                                                                                   \
+      PW2_REQUEST(c1, n1);                                                                              \
+      const unsigned e1 = (unsigned)PW2_EDGE(t + 1);                                                    \
+      { const float4 g_ = ldg4_b(a.geo, 32u * e1 + 16u * half); gv = f32x4{g_.x, g_.y, g_.z, g_.w}; }   \
+      const unsigned e2 = (unsigned)PW2_EDGE(t + 2);                                                    \
+      c2 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e2); n2 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e2); \
     }
+    f32x16 pacc = zero16();
+    if (!DEFER) PW2_NEXT_REQUESTS();        // (DEFER: behind the previous tile's fc3 MFMAs, whose operands need the registers first)
     f32x16 acc;
     float4 hrow;
 #define PW2_MMA4(bq_, w_, first_)                                                                       \
@@ -333,7 +353,30 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
 #pragma unroll
     for (int f = 0; f < 32; ++f) {
       if (f + 2 < 32) { if (f % 3 == 0) bq2 = PW2_HB(f + 2); else if (f % 3 == 1) bq0 = PW2_HB(f + 2); else bq1 = PW2_HB(f + 2); }
-      if (f == 3) {
+      if (DEFER) {
+      // the PREVIOUS tile's fc3 partial product (its rectified accumulators and W3 pieces were kept across the barrier): four MFMAs
+      // beside each of the first four fragments, the partial sums to LDS behind them -- the tile no longer ends with 16 MFMAs + 16 LDS
+      // stores + their drain in front of the barrier with nothing of this wave's in the pipe
+      if (f < 4) {
+#pragma unroll
+        for (int r = 4 * f; r < 4 * f + 4; ++r) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(hprev[r], w3r[r], r == 0 ? zero16() : pacc, 0, 0, 0);
+      }
+      if (f == 5) {
+        float* d_ = sP + ((it & 1) ^ 1) * PW2_PF + (wave * PW2_T + 4 * half) * D_E + col;      // P[(it - 1) & 1]: the previous tile's
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
+        PW2_NEXT_REQUESTS();
+      }
+      if (f == 9) {
+        // the fc3 of the tile BEFORE the previous one (its partial sums were published by the last barrier)
+        const float* pp = Pc + er * D_E + j0;                   // P[it & 1] = P[(it - 2) & 1]
+        float2 s_ = *reinterpret_cast<const float2*>(pp);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); s_.x += v.x; s_.y += v.y; }
+        const int ep = it > 1 ? e0 - 2 * PW2_T : a.n_edge + 32;
+        pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f)));
+      }
+      } else if (f == 3) {
         // the previous tile's fc3: sum of the eight waves' partial sums, bias, ReLU, 8 bytes per thread (a tile's 4 KB in a row);
         // the first tile of the range has no predecessor: a slack row takes the store
         const float* pp = Pp + er * D_E + j0;
@@ -341,13 +384,13 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
 #pragma unroll
         for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); s_.x += v.x; s_.y += v.y; }
         const int ep = it > 0 ? e0 - PW2_T : a.n_edge + 32;
-        *reinterpret_cast<float2*>(a.pw + (size_t)(ep + er) * D_E + j0) = make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f));
+        pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f)));
       }
       // training: four whole h1 rows per wave, read from LDS one fragment before they are stored
-      if (TRAINING && f >= 7 && f < 11) *reinterpret_cast<float4*>(a.h1 + (size_t)(e0 + 4 * wave + (f - 7)) * D_H + 4 * lane) = hrow;
+      if (TRAINING && f >= 7 && f < 11) pw2_st4(a.h1 + (size_t)(e0 + 4 * wave + (f - 7)) * D_H, 16u * lane, hrow);
       if (TRAINING && f >= 6 && f < 10) hrow = *reinterpret_cast<const float4*>(Hc + (4 * wave + (f - 6)) * PW2_LD + 4 * lane);
-      if (f == 16) PW2_FC1(Hn);
-      if (f == 24) {
+      if (f == (DEFER ? 20 : 16)) PW2_FC1(Hn);
+      if (f == (DEFER ? 26 : 24)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) w3r[r] = w3p[crow(r, 0) * D_E];
 #pragma unroll
@@ -364,14 +407,16 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
       acc[4 * g + 2] = relu_bits(acc[4 * g + 2] + b2q[g].z); acc[4 * g + 3] = relu_bits(acc[4 * g + 3] + b2q[g].w);
     }
     if (TRAINING) {
-      float* d_ = a.h2 + (size_t)(e0 + col) * D_H + 32 * wave + 4 * half;
+      float* d_ = a.h2 + (size_t)e0 * D_H + 32 * wave;          // (uniform; the lane's row and half: h2_lo)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(d_ + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      for (int g = 0; g < 4; ++g) pw2_st4(d_, h2_lo + 32u * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
     }
-    f32x16 pacc = zero16();
+    if (DEFER) {
+      hprev = acc;
+    } else {
+      pacc = zero16();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], w3r[r], pacc, 0, 0, 0);
-    {
+      for (int r = 0; r < 16; ++r) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], w3r[r], pacc, 0, 0, 0);
       float* d_ = Pc + (wave * PW2_T + 4 * half) * D_E + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
@@ -380,15 +425,35 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
     pw2_barrier();
   }
   {
-    // the last tile's fc3
     const int itl = t1 - t0 - 1;
+    if (DEFER) {
+      // drain: the last tile's fc3 product, then the reduction of the tile before it (the last tile's own follows below)
+      f32x16 pacc = zero16();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(hprev[r], w3r[r], pacc, 0, 0, 0);
+      {
+        float* d_ = sP + (itl & 1) * PW2_PF + (wave * PW2_T + 4 * half) * D_E + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
+      }
+      pw2_barrier();
+      if (itl > 0) {
+        const float* pp = sP + ((itl & 1) ^ 1) * PW2_PF + er * D_E + j0;
+        float2 s_ = *reinterpret_cast<const float2*>(pp);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); s_.x += v.x; s_.y += v.y; }
+        pw2_st2(a.pw + (size_t)((t1 - 2) * PW2_T) * D_E, pw_lo, make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f)));
+      }
+    }
+    // the last tile's fc3
     const float* pp = sP + (itl & 1) * PW2_PF + er * D_E + j0;
     float2 s_ = *reinterpret_cast<const float2*>(pp);
 #pragma unroll
     for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); s_.x += v.x; s_.y += v.y; }
-    *reinterpret_cast<float2*>(a.pw + (size_t)((t1 - 1) * PW2_T + er) * D_E + j0) = make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f));
+    pw2_st2(a.pw + (size_t)((t1 - 1) * PW2_T) * D_E, pw_lo, make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f)));
   }
 #undef PW2_EDGE
+#undef PW2_NEXT_REQUESTS
 #undef PW2_REQUEST
 #undef PW2_FC1
 #undef PW2_HB
