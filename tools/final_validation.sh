@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 python -m pytest tests -m gpu -q -rs > $O/tests.log 2>&1; tail -4 $O/tests.log
 timeout 900 python tools/fuzz.py 15000 7 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
-for c in 0 1 2 3; do timeout 600 python tools/fuzz_parity.py 150 11 $c > $O/fuzz_parity_$c.log 2>&1; tail -1 $O/fuzz_parity_$c.log; done
+for c in 0 1 2 3 5 6; do timeout 600 python tools/fuzz_parity.py 150 11 $c > $O/fuzz_parity_$c.log 2>&1; tail -1 $O/fuzz_parity_$c.log; done
 timeout 300 python tools/fuzz_graph.py 100 3 > $O/fuzz_graph.log 2>&1; tail -1 $O/fuzz_graph.log
 timeout 300 python tools/fuzz_matching.py 2000 > $O/fuzz_matching.log 2>&1; tail -1 $O/fuzz_matching.log
 timeout 300 python tools/fuzz_optimizer.py > $O/fuzz_optimizer.log 2>&1; tail -1 $O/fuzz_optimizer.log

@@ -14,10 +14,19 @@ from gossipnet_amd.synthetic import make_image
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 # configuration (argv[3]): 0 = 80 classes, 2 blocks, class weights; 1 = one class, 3 blocks, normalised loss; 2 = 80 classes, one
-# block, biases 0.5, pw_feat_multiplyer 0.7; 3 = neighbor_feats (a second reduce FC per block), 2 blocks; 4 = as 0 with 16 blocks
+# block, biases 0.5, pw_feat_multiplyer 0.7; 3 = neighbor_feats (a second reduce FC per block), 2 blocks; 4 = as 0 with 16 blocks;
+# 5 = the reference's default hyper-parameters (num_pwfeat_fc = 0: raw pairwise features), 80 classes, 3 blocks, class weights;
+# 6 = the same with one class, pw_feat_multiplyer 0.7
 CONF = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 NF = CONF == 3
-if CONF in (0, 4):
+NFC = 0 if CONF in (5, 6) else 3
+if CONF == 5:
+    NC, NB = 80, 3
+    net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32), num_pwfeat_fc=0)
+elif CONF == 6:
+    NC, NB = 1, 2
+    net, orc = make_pair(NC, NB, bias=0.5, num_pwfeat_fc=0, pw_feat_multiplyer=0.7)
+elif CONF in (0, 4):
     NC, NB = 80, (2 if CONF == 0 else 16)                # (4 = the real depth, 16 blocks)
     net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32))
 elif CONF == 1:
@@ -107,7 +116,7 @@ for case in range(cases):
         # gradient is +0.2542 - 0.2516 -- one ulp of a summand is 1e-5 of the result -- and the 128-term dot products behind
         # predict/fc1's bias gradient, summed in another order, differ by a few 1e-7 whatever the size of their sum.)
         pinned = {}
-        for name, _shape in go.param_spec(NC, NB, None, NF):
+        for name, _shape in go.param_spec(NC, NB, None, NF, NFC):
             g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
             gr = gsum[name].reshape(-1)
             pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 5e-2)) if gr.size else 0.0
