@@ -807,9 +807,12 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       // d_h1 rows go back to their edge positions (rows past the list: the slack row E); exactly 16 stores
       const int* rp = sRows[it & 1] + 4 * half;
       const float* hp = sH1 + (4 * half) * LD256 + 32 * wave + col;
+      // (address = the lane's column base + (row id << 10) with the id as an UNSIGNED 64-bit shift operand: one v_lshl_add_u64 per
+      // store; the signed size_t product cost a sign extension, a 64-bit shift and a 64-bit add each)
+      char* lane_base = reinterpret_cast<char*>(a.d_h1 + 32 * wave + col);
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        a.d_h1[(size_t)rp[crow(r, 0)] * D_H + 32 * wave + col] = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
+        *reinterpret_cast<float*>(lane_base + ((unsigned long long)(unsigned)rp[crow(r, 0)] << 10)) = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
     }
     if (it == 5) GSTAMP(a, 12);
   }
