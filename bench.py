@@ -199,13 +199,15 @@ def rccl_evidence(log_pattern):
             "bus_ids": devs[:16], "rings": rings, "init_complete": "Init COMPLETE" in text, "log_lines": len(text.splitlines())}
 
 
-def time_config(dev, classes, blocks, dets, images, preset, steps, warmup, inference=False):
+def time_config(dev, classes, blocks, dets, images, preset, steps, warmup, inference=False, num_pwfeat_fc=3):
     """detections/s of one configuration on one GPU (no kernel timing)."""
     from gossipnet_amd.config import cfg, experiment_cfg
     from gossipnet_amd.network import Gnet, DeviceBatch
     from gossipnet_amd.synthetic import make_image
     experiment_cfg()
     cfg.gnet.num_blocks = blocks
+    if num_pwfeat_fc == 0:                                  # the reference's default hyper-parameters (config.py:73-75)
+        cfg.gnet.num_pwfeat_fc, cfg.gnet.pwfeat_narrow_dim = 0, 64
     net = Gnet(classes, device=dev)
     imgs = [make_image(dets, classes, seed=1000 + i, preset=preset) for i in range(images)]
     if inference:                                          # test.py:44-45 feeds dets / det_scores / det_classes only
@@ -595,6 +597,8 @@ def main():
             oc["configs[2] N=2000 C=80, 8 images/step, coco_like preset"] = time_config(dev, 80, 16, 2000, 8, "coco_like", 10, 3)
             oc["configs[3] dense N=10000 C=80, 1 image/step"] = time_config(dev, 80, 16, 10000, 1, "dense", 5, 2)
             oc["configs[2] N=2000 C=80, 8 images/step, INFERENCE (forward only, test.py:70)"] = time_config(dev, 80, 16, 2000, 8, "dense", 10, 3, inference=True)
+            oc["N=2000 C=80, 8 images/step, the reference's DEFAULT hyper-parameters (num_pwfeat_fc = 0: no pairwise-feature MLP)"] = time_config(dev, 80, 16, 2000, 8, "dense", 10, 3, num_pwfeat_fc=0)
+            experiment_cfg()
             out["other_configs"] = oc
         if world == 1 and not args.no_other_configs:
             out["roi_pool"] = roi_pool_bench(dev)

@@ -94,3 +94,79 @@ def test_raw_batch_of_images_and_multiplier():
     net.run([{k: im[k] for k in ("dets", "det_scores", "det_classes")} for im in imgs])
     torch.cuda.synchronize()
     assert rel_err(net.prediction.cpu().numpy(), logits) < 1e-6
+
+
+def test_raw_with_neighbor_feats():
+    """num_pwfeat_fc = 0 together with cfg.gnet.neighbor_feats (network.py:356-365): the neighbour score term rides on the rn
+    table of the SECOND reduce FC's features; its variables follow fc2 in every block's group."""
+    from gossipnet_amd.config import cfg, experiment_cfg
+    from gossipnet_amd.network import Gnet
+    from oracle import gnet_oracle as go
+    c, b = 80, 3
+    experiment_cfg(num_pwfeat_fc=0, pwfeat_narrow_dim=64, num_blocks=b, neighbor_feats=True)
+    params = go.init_params(c, b, neighbor_feats=True, num_pwfeat_fc=0)
+    net = Gnet(c)
+    net.keep_edge_activations = True
+    net.load_params(params)
+    orc = go.GnetOracle(c, b, params=params, neighbor_feats=True, num_pwfeat_fc=0)
+    for seed in (0, 1):
+        batch = make_image(150, c, seed=seed)
+        ref = orc.forward(batch, keep=True)
+        net.run(batch)
+        torch.cuda.synchronize()
+        forward_checks(net, ref, b)
+        check_outputs(net, ref)
+        _, gpin = orc.forward_backward(batch, pins=gpu_pins(net))
+        errs = grad_errors(net, gpin, c, b, neighbor_feats=True, num_pwfeat_fc=0)
+        assert any("reduce_dim_neighbor" in k for k in errs)
+        assert max(errs.values()) <= PINNED, max(errs.items(), key=lambda kv: kv[1])
+    experiment_cfg()
+
+
+def test_raw_exact_ties_from_duplicate_detections():
+    """Duplicate detections: exact positive ties of the segment maximum (TF splits the gradient evenly) -- the tie repair
+    recomputes pw_fc1 / pw_fc2 from the padded geometry operand and the self-pair rows of rn."""
+    net, orc = make_pair(80, 2, bias=0.5, num_pwfeat_fc=0)
+    net.keep_edge_activations = True
+    for seed in range(2):
+        base = make_image(60, 80, seed=seed)
+        rep = np.repeat(np.arange(60), 3)
+        np.random.default_rng(seed).shuffle(rep)
+        batch = dict(base)
+        for k in ("dets", "det_scores", "det_classes"):
+            batch[k] = base[k][rep]
+        ref = orc.forward(batch, keep=True)
+        net.run(batch)
+        torch.cuda.synchronize()
+        pm = net.debug_view("blk_pm", 180 * 64, dtype=torch.int64, index=1).cpu().numpy()
+        assert (((pm & 0xffffffff) > 1) & ((pm >> 32) > 0)).any(), "test must contain positive ties"
+        assert rel_err(net.prediction.cpu().numpy(), ref["prediction"].detach().numpy()) < 1e-5
+        for blk in (1, 2):
+            winner_records_exact(net, blk)
+        n_diff, worst, where = mask_disagreements(gpu_pins(net), ref)
+        assert worst <= KINK, (seed, n_diff, worst, where)
+        _, gpin = orc.forward_backward(batch, pins=gpu_pins(net))
+        pinned = grad_errors(net, gpin, 80, 2, num_pwfeat_fc=0)
+        assert max(pinned.values()) <= PINNED, (seed, max(pinned.items(), key=lambda kv: kv[1]))
+
+
+def test_raw_train_steps_and_checkpoint_names(tmp_path):
+    """The training step around the path (train.py:64-77, 316-320) and a checkpoint keyed by the TF variable names with the
+    reference's default hyper-parameters: no gnet/pw_feats/* variables, pw_fc1 is [2C'+7+64, 64]."""
+    from gossipnet_amd.config import cfg
+    from gossipnet_amd.train import Optimizer, train_step
+    from gossipnet_amd import checkpoint
+    net, _ = make_pair(80, 2, num_pwfeat_fc=0)
+    net.weight_reg = cfg.train.weight_decay
+    opt = Optimizer(net)
+    batch = make_image(150, 80, seed=0)
+    losses = [float(train_step(net, opt, batch, 1e-3)) for _ in range(8)]
+    assert losses[-1] < losses[0]
+    names = [nm for nm, _ in net._spec]
+    assert not any(nm.startswith("gnet/pw_feats/") for nm in names)
+    assert tuple(net.variables["gnet/block1/pw_fc1/weights"].shape) == (2 * 80 + 7 + 64, 64)
+    path = checkpoint.save(net, str(tmp_path / "gnet-8"), global_step=8, optimizer=opt)
+    before = net.params.clone()
+    net.params.zero_()
+    checkpoint.load(net, path, optimizer=opt)
+    assert torch.equal(net.params, before)
