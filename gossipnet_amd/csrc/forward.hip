@@ -297,14 +297,8 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
   // forward-only: the fc3 partial product of a tile is DEFERRED into the next tile's stream (its rectified accumulators and W3
   // pieces kept across the barrier) -- the tile then ends with its last fc2 MFMAs instead of 16 MFMAs + 16 LDS stores + their
   // drain with nothing of this wave's in the pipe: 1.65 -> 1.56 ms.  Not in a training step: there the same move is +1 % (the
-  // h2 stores at the tile's end want the fc3 MFMAs behind them).
-#ifdef PW2_DEFER_TRAIN
-  constexpr bool DEFER = true;          // (probe: the training kernel defers fc3 AND its h2 stores into the next tile's stream)
-  constexpr bool H2_LATE = TRAINING;
-#else
+  // h2 stores at the tile's end want the fc3 MFMAs behind them), and with the h2 stores deferred as well +5 % (1.74 -> 1.82 ms).
   constexpr bool DEFER = !TRAINING;
-  constexpr bool H2_LATE = false;
-#endif
   f32x16 hprev = zero16();        // (DEFER) the previous tile's rectified fc2 accumulators: fc3's A operand
   if (DEFER) {
 #pragma unroll
@@ -371,15 +365,8 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
         float* d_ = sP + ((it & 1) ^ 1) * PW2_PF + (wave * PW2_T + 4 * half) * D_E + col;      // P[(it - 1) & 1]: the previous tile's
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
-        if (!H2_LATE) PW2_NEXT_REQUESTS();
+        PW2_NEXT_REQUESTS();
       }
-      if (H2_LATE && f >= 6 && f < 10) {
-        // the PREVIOUS tile's h2 rows, one 16-byte piece per lane and fragment (the first tile's "previous" rows: slack rows)
-        const int g = f - 6;
-        float* d_ = a.h2 + (size_t)(it > 0 ? e0 - PW2_T : a.n_edge + 32) * D_H + 32 * wave;
-        pw2_st4(d_, h2_lo + 32u * g, make_float4(hprev[4 * g], hprev[4 * g + 1], hprev[4 * g + 2], hprev[4 * g + 3]));
-      }
-      if (H2_LATE && f == 10) PW2_NEXT_REQUESTS();
       if (f == 9) {
         // the fc3 of the tile BEFORE the previous one (its partial sums were published by the last barrier)
         const float* pp = Pc + er * D_E + j0;                   // P[it & 1] = P[(it - 2) & 1]
@@ -400,12 +387,9 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
         pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f)));
       }
       // training: four whole h1 rows per wave, read from LDS one fragment before they are stored
-      {
-        constexpr int H1F = H2_LATE ? 11 : 6;
-        if (TRAINING && f >= H1F + 1 && f < H1F + 5) pw2_st4(a.h1 + (size_t)(e0 + 4 * wave + (f - H1F - 1)) * D_H, 16u * lane, hrow);
-        if (TRAINING && f >= H1F && f < H1F + 4) hrow = *reinterpret_cast<const float4*>(Hc + (4 * wave + (f - H1F)) * PW2_LD + 4 * lane);
-      }
-      if (f == (H2_LATE ? 23 : DEFER ? 20 : 16)) PW2_FC1(Hn);
+      if (TRAINING && f >= 7 && f < 11) pw2_st4(a.h1 + (size_t)(e0 + 4 * wave + (f - 7)) * D_H, 16u * lane, hrow);
+      if (TRAINING && f >= 6 && f < 10) hrow = *reinterpret_cast<const float4*>(Hc + (4 * wave + (f - 6)) * PW2_LD + 4 * lane);
+      if (f == (DEFER ? 20 : 16)) PW2_FC1(Hn);
       if (f == (DEFER ? 26 : 24)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) w3r[r] = w3p[crow(r, 0) * D_E];
@@ -422,7 +406,7 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
       acc[4 * g + 0] = relu_bits(acc[4 * g + 0] + b2q[g].x); acc[4 * g + 1] = relu_bits(acc[4 * g + 1] + b2q[g].y);
       acc[4 * g + 2] = relu_bits(acc[4 * g + 2] + b2q[g].z); acc[4 * g + 3] = relu_bits(acc[4 * g + 3] + b2q[g].w);
     }
-    if (TRAINING && !H2_LATE) {
+    if (TRAINING) {
       float* d_ = a.h2 + (size_t)e0 * D_H + 32 * wave;          // (uniform; the lane's row and half: h2_lo)
 #pragma unroll
       for (int g = 0; g < 4; ++g) pw2_st4(d_, h2_lo + 32u * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
@@ -444,11 +428,6 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
     const int itl = t1 - t0 - 1;
     if (DEFER) {
       // drain: the last tile's fc3 product, then the reduction of the tile before it (the last tile's own follows below)
-      if (H2_LATE) {
-        float* d_ = a.h2 + (size_t)((t1 - 1) * PW2_T) * D_H + 32 * wave;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pw2_st4(d_, h2_lo + 32u * g, make_float4(hprev[4 * g], hprev[4 * g + 1], hprev[4 * g + 2], hprev[4 * g + 3]));
-      }
       f32x16 pacc = zero16();
 #pragma unroll
       for (int r = 0; r < 16; ++r) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(hprev[r], w3r[r], pacc, 0, 0, 0);
