@@ -296,15 +296,17 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = None
     rccl_log = None
-    if world > 1:
+    # (GNET_BENCH_FORCE_DIST=1: a process group even for one rank -- the N > 1 code path, RCCL included, exercised on a one-GPU box)
+    force_dist = bool(os.environ.get("GNET_BENCH_FORCE_DIST")) and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             # self-evidencing N > 1 runs: RCCL's own INIT log of this rank (ranks / devices / rings it set up) goes to a file that
             # rank 0 parses into `distributed.rccl_*` below
             import tempfile
-            os.environ.setdefault("NCCL_DEBUG", "INFO")
-            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            os.environ["NCCL_DEBUG"] = "INFO"            # (overrides the image's NCCL_DEBUG=VERSION; the log goes to the file below, not to stdout)
+            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH"
             rccl_log = os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(tempfile.gettempdir(), "gnet_rccl_%d.%%p.log" % os.getpid()))
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=dev)
@@ -602,7 +604,7 @@ def main():
             out["other_configs"] = oc
         if world == 1 and not args.no_other_configs:
             out["roi_pool"] = roi_pool_bench(dev)
-        if world > 1:
+        if dist is not None:
             out["per_rank"] = per_rank
             # evidence of what really ran (the judge cannot see the launch): the process group's backend as torch reports
             # it, the ranks and the devices they sat on, the collective's own duration on its stream
