@@ -204,7 +204,7 @@ extern "C" int gnet_profiler_destroy(void* profiler) {
   return GNET_OK;
 }
 
-extern "C" const char* gnet_version(void) { return "gossipnet_hip 0.4 (gfx950, fp32 MFMA)"; }
+extern "C" const char* gnet_version(void) { return "gossipnet_hip 0.5 (gfx950, fp32 MFMA)"; }
 
 extern "C" int gnet_abi_version(void) { return GNET_ABI_VERSION; }
 

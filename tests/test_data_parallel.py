@@ -71,3 +71,18 @@ def test_shard_images_lpt_balances_edge_counts():
     loads = [sum(costs[i] for i in s) for s in shards]
     assert abs(loads[0] - loads[1]) <= 20
     assert shard_images(imgs, 1, 4) == [1, 5]
+
+
+def test_rccl_log_parser(tmp_path):
+    """bench.py's reading of RCCL's own INIT log (NCCL_DEBUG=INFO written to NCCL_DEBUG_FILE): ranks, version, bus ids, rings."""
+    import bench
+    p = tmp_path / "gnet_rccl_1.77.log"
+    p.write_text("node:77:77 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6\n"
+                 "node:77:90 [0] NCCL INFO comm 0x1 rank 3 nranks 8 cudaDev 3 nvmlDev 3 busId dc000 commId 0x2 - Init START\n"
+                 "node:77:90 [0] NCCL INFO Channel 00/16 : 0 1 2 3 4 5 6 7\n"
+                 "node:77:90 [0] NCCL INFO Trees [0] 4/-1/-1->3->2\n"
+                 "node:77:90 [0] NCCL INFO comm 0x1 rank 3 nranks 8 cudaDev 3 nvmlDev 3 busId dc000 commId 0x2 - Init COMPLETE\n")
+    r = bench.rccl_evidence(str(tmp_path / "gnet_rccl_1.%p.log"))
+    assert r["rccl_ranks_seen"] == [{"rank": 3, "nranks": 8}] and r["init_complete"] and r["bus_ids"] == ["busId dc000"]
+    assert r["version"].startswith("RCCL version") and len(r["rings"]) == 2
+    assert "note" in bench.rccl_evidence(None) and "note" in bench.rccl_evidence(str(tmp_path / "none.%p.log"))

@@ -205,6 +205,32 @@ def test_bench_two_ranks_functional(tmp_path):
     assert line["cpu_baseline"] is None and line["roofline"] is None          # rank 0 at N = 1 only / kernel timing off
 
 
+def test_bench_one_rank_rccl_evidence_and_kernel_classes(tmp_path):
+    """bench.py's N > 1 code path over RCCL with the one rank a one-GPU box has (GNET_BENCH_FORCE_DIST: a process group, the
+    side-stream all-reduce launched without a wait, the next backward pass deferred behind it), and what the line then says
+    about the run: RCCL's own INIT log parsed into distributed.rccl, the `graph` and `loss` kernel classes in the table."""
+    import json, subprocess, sys, os, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = str(s_.getsockname()[1]); s_.close()
+    env = dict(os.environ, GNET_BENCH_FORCE_DIST="1")
+    env.pop("GNET_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--images", "2", "--dets", "500", "--blocks", "2", "--no-other-configs", "--cpu-seconds", "0"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    d = line["distributed"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["allreduce_samples"] >= 3
+    r = d["rccl"]
+    assert r.get("init_complete") and {"rank": 0, "nranks": 1} in r["rccl_ranks_seen"] and "RCCL" in (r.get("version") or "")
+    k = line["kernel_ms_per_step"]
+    assert k.get("graph", 0) > 0 and k.get("loss", 0) > 0 and k.get("pw_fwd", 0) > 0 and k.get("edge_bwd", 0) > 0
+    assert line["side_stream"]["graph_transpose_ms_alone"] > 0
+    ab = line["side_stream"]["graph_transpose_placement_ms_per_step"]
+    assert set(ab) == {"beside_pw_fwd", "after_forward"} and all(v > 0 for v in ab.values())
+
+
 def test_checkpoint_round_trip_tf_bundle(tmp_path):
     """save(fmt="tf") writes a Saver V2 bundle keyed by the TF variable names (+ Adam slots, global_step); load() restores
     it into a fresh Gnet / Optimizer: same parameters, same next step."""
