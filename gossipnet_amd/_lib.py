@@ -100,6 +100,15 @@ def load():
     if _lib is not None:
         return _lib
     from . import build as _build
+    global LIB_PATH
+    if os.environ.get("GNET_LIB_AB"):
+        # measurement only (A/B of two builds on one box, tools/): load exactly this file, no source-hash check, no rebuild -- the
+        # ABI guard below still applies
+        LIB_PATH = os.environ["GNET_LIB_AB"]
+        import torch  # noqa: F401
+        lib = C.CDLL(LIB_PATH)
+        check_abi(lib)
+        return _bind(lib)
     # A library whose recorded source hash DIFFERS from the tree is rebuilt (never silently used); one without a record
     # (built by other tooling, deployed without the sources' toolchain) is loaded as it is, with a warning.
     stale = missing = not os.path.exists(LIB_PATH)
@@ -123,6 +132,11 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     check_abi(lib)
+    return _bind(lib)
+
+
+def _bind(lib):
+    global _lib
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     P = C.POINTER
     lib.gnet_param_count.restype = i64

@@ -633,6 +633,10 @@ __device__ __forceinline__ void dma_rows32_ids(float* sdst, const float* __restr
   }
 }
 
+// BIG: the [E,256] fp32 arrays exceed 4 GB (E > 2^22 - 64): row offsets need 64 bits.  Otherwise every d_h1 store is
+// (uniform base) + (32-bit offset): one 32-bit vector instruction per address -- the 64-bit form costs a 64-bit shift and a 64-bit
+// add per store, and 64-bit vector instructions beside an MFMA stream are far dearer than their count (pw_fwd2 lost 2 % to nine).
+template <bool BIG>
 __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // two tile buffers {h1 [32][260], h2 [32][260]} filled by DMA one tile ahead, + d3 [32][36]
@@ -659,7 +663,7 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   for (int k = 0; k < 4; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3 + (size_t)(32 * wave + col) * D_E + 4 * half + 8 * k);
   float pq0 = 0.f, pq1 = 0.f, dq0 = 0.f, dq1 = 0.f;     // d3 tile sources: elements tid and tid + 512 of [32][32]
   // rows past the list re-read its last row (finite data); their d3 rows are zero
-#define PB_ROW(tile_, r_) a.rows[min((tile_) * 32 + (r_), n_rows - 1)]
+#define PB_ROW(tile_, r_) (int)ldg_b(reinterpret_cast<const unsigned*>(a.rows), 4u * (unsigned)min((tile_) * 32 + (r_), n_rows - 1))   /* uniform base + 32-bit offset */
   // the row indices themselves are fetched one tile earlier still (ra / rb / rs), so the d3 source requests
   // never wait for an index
   int ra = 0, rb = 0, rs = 0, rs_tile = 0;
@@ -807,12 +811,17 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
       // d_h1 rows go back to their edge positions (rows past the list: the slack row E); exactly 16 stores
       const int* rp = sRows[it & 1] + 4 * half;
       const float* hp = sH1 + (4 * half) * LD256 + 32 * wave + col;
-      // (address = the lane's column base + (row id << 10) with the id as an UNSIGNED 64-bit shift operand: one v_lshl_add_u64 per
-      // store; the signed size_t product cost a sign extension, a 64-bit shift and a 64-bit add each)
-      char* lane_base = reinterpret_cast<char*>(a.d_h1 + 32 * wave + col);
+      if (BIG) {
+        char* lane_base = reinterpret_cast<char*>(a.d_h1 + 32 * wave + col);
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        *reinterpret_cast<float*>(lane_base + ((unsigned long long)(unsigned)rp[crow(r, 0)] << 10)) = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<float*>(lane_base + ((unsigned long long)(unsigned)rp[crow(r, 0)] << 10)) = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
+      } else {
+        const unsigned lane_off = (unsigned)(32 * wave + col) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg_b(a.d_h1, ((unsigned)rp[crow(r, 0)] << 10) + lane_off, hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f);
+      }
     }
     if (it == 5) GSTAMP(a, 12);
   }
@@ -1165,7 +1174,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   const EdgeGeom G = edge_geom(E, N);
 
   // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
-  HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
   { const int st = edge_stage_set_attributes(); if (st != GNET_OK) return st; }
 
   if (E > 0 && !prepared) {
@@ -1253,7 +1263,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     p.w2 = params + L.pw2; p.w3 = params + L.pw3; p.d_h1 = buf->d_h1;
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
     GNET_TRACE_SET(p, "PW_BWD", true);
-    GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<<<g_pw, 512, kPwBwdSmem, s>>>(p));
+    if ((long long)E + 64 > (1ll << 22)) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<true><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
+    else { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<false><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
     PwW1Args w;
     w.n_det = N; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;
     w.row_ptr = buf->row_ptr; w.edge_t = buf->edge_t; w.geo = buf->geo; w.d_h1 = buf->d_h1;

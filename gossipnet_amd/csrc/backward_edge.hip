@@ -488,12 +488,12 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   // column records (lane = column j) of the first two detections of the next tile
   int apA = 0, apB = 0, apC = 0;
   float dvA = 0.f, dvB = 0.f, dvC = 0.f;
-#define EBW_LOAD_LIST(tile_) do { nx2_e = a.wlist[min((tile_) * 32 + col, W - 1)]; } while (0)
+#define EBW_LOAD_LIST(tile_) do { nx2_e = (int)ldg_b(reinterpret_cast<const unsigned*>(a.wlist), 4u * (unsigned)min((tile_) * 32 + col, W - 1)); } while (0)   /* (uniform base + 32-bit offsets throughout: no 64-bit vector address arithmetic) */
 #define EBW_LOAD_ROWS(tile_)     /* uses nx2_e = list entries of tile_ */                               \
   do {                                                                                                  \
     nx_e = nx2_e;                                                                                       \
-    nx_c = (tile_) * 32 + col < W ? a.edge_c[nx_e] : -1;                                                \
-    nx_nz = a.edge_nz[nx_e];                                                                            \
+    nx_c = (tile_) * 32 + col < W ? (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * (unsigned)nx_e) : -1; \
+    nx_nz = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_nz), 4u * (unsigned)nx_e);              \
   } while (0)
 #define EBW_LOAD_BIAS()          /* column records of the next tile's first detections; uses nx_c */                               \
   do {                                                                                                  \
@@ -506,16 +506,16 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
     }                                                                                                   \
     const unsigned oa_ = (unsigned)max(cA_, 0) * D_P + lane, ob_ = (unsigned)max(cB_, 0) * D_P + lane;  \
     const unsigned oc_ = (unsigned)max(cC_, 0) * D_P + lane;                                            \
-    apA = a.apos[oa_]; dvA = a.d_pc[oa_];                                                               \
-    apB = a.apos[ob_]; dvB = a.d_pc[ob_];                                                               \
-    apC = a.apos[oc_]; dvC = a.d_pc[oc_];                                                               \
+    apA = (int)ldg_b(reinterpret_cast<const unsigned*>(a.apos), 4u * oa_); dvA = ldg_b(a.d_pc, 4u * oa_); \
+    apB = (int)ldg_b(reinterpret_cast<const unsigned*>(a.apos), 4u * ob_); dvB = ldg_b(a.d_pc, 4u * ob_); \
+    apC = (int)ldg_b(reinterpret_cast<const unsigned*>(a.apos), 4u * oc_); dvC = ldg_b(a.d_pc, 4u * oc_); \
   } while (0)
   // bias rows rc[c], rn[n] as the lane's own sixteen 16-byte pieces (lane = row, features 8 g + 4 half .. + 3 and + 32) and its
   // P row (B layout) of the tile whose records are in nx_e / nx_c / nx_nz: all twenty requests in flight together
 #define EBW_LOAD_TILE(bx, by, bpa)                                                                      \
   do {                                                                                                  \
-    const float* ap_ = a.pw + (size_t)nx_e * D_E + 4 * half;                                            \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) bpa[k_] = *reinterpret_cast<const f32x4*>(ap_ + 8 * k_); \
+    const unsigned po_ = (unsigned)nx_e * (D_E * 4u) + 16u * half;                                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { const float4 v_ = ldg4_b(a.pw, po_ + 32u * k_); bpa[k_] = f32x4{v_.x, v_.y, v_.z, v_.w}; } \
     const unsigned oc_ = (unsigned)max(nx_c, 0) * (D_P * 4u) + 16u * half, on_ = (unsigned)nx_nz * (D_P * 4u) + 16u * half; \
     _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                  \
       bx[g_] = ldg4_b(a.rc, oc_ + 32u * g_);                                                            \

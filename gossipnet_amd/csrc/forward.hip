@@ -610,9 +610,10 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     const int nseg = __popc(heads);
     // rc rows of centres A / B -> LDS (this wave's 512 bytes), read back as the lane's own centre row
     if (lane < 32) *reinterpret_cast<float4*>(sRC + 4 * lane) = rcAB;
+    // (uniform base + 32-bit byte offset: a 64-bit vector instruction per address is dear beside the MFMA stream)
     nx_c = -1;
-    if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
-    nx_nz = a.edge_nz[e0 + 32 + col];
+    if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) nx_c = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * (unsigned)e); }
+    nx_nz = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_nz), 4u * (unsigned)(e0 + 32 + col));
     wave_lds_sync();
     f32x16 h1a, h1b;                                   // h1^T: lane = edge, register r = feature 8 (r >> 2) + 4 half + (r & 3) [+ 32]
     if (nseg <= 2) {                                   // centre rows were prefetched (A below thiA, B from it)
@@ -655,9 +656,9 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     }
     // ---- prefetch for the next tile: P rows, neighbour rows, the first two centre rows
     {
-      const float* ap = a.pw + (size_t)min(e0 + 32 + col, a.n_edge - 1) * D_E + 4 * half;
+      const unsigned po = (unsigned)min(e0 + 32 + col, a.n_edge - 1) * (D_E * 4u) + 16u * half;    // [E,32] fp32: < 2^31 bytes at the edge limit
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pa[k] = *reinterpret_cast<const f32x4*>(ap + 8 * k);
+      for (int k = 0; k < 4; ++k) { const float4 v_ = ldg4_b(a.pw, po + 32u * k); pa[k] = f32x4{v_.x, v_.y, v_.z, v_.w}; }
     }
 #pragma unroll
     for (int g = 0; g < 8; ++g) rnv[g] = ldg4_b(a.rn, (unsigned)nx_nz * (D_P * 4u) + 32u * g + 16u * half);
