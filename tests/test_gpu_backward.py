@@ -45,6 +45,12 @@ KINK = 2e-6       # a mask may differ from the oracle's own only where the oracl
 
 # kink-free seeds (of 6) measured on MI355X per case, minus one (a change of a kernel's summation order may move a unit
 # across its kink); the count is deterministic for fixed kernels.  Filled from the run recorded in profiles/r04_kinks.txt.
+# History: round 4 lowered two floors -- (200, 1, 1, 0.01) 4 -> 2 and (150, 80, 3, 0.01) 4 -> 3 -- when pw_feats/fc1 went from an
+# fma chain with the bias added last to tc[c] + tn[n] + a K = 8 MFMA product (another rounding order: more units of the 0.01-bias
+# cases land within 1e-7 of their kink on the other side); round 5's pw_fwd2 keeps that order for fc1 and changes fc2 / fc3's
+# (bias added to the finished sum, eight K = 32 partial sums for fc3): the floors held.  The count is a REGRESSION GUARD for "most
+# seeds need no pinning at all"; the acceptance criteria are the two asserts on every seed -- worst kink distance <= KINK and
+# pinned gradients <= PINNED -- which no kernel change has ever loosened.
 KINK_FREE_MIN = {(6, 1, 1, 0.01): 5, (6, 1, 1, 0.5): 5, (20, 1, 1, 0.01): 5, (20, 1, 1, 0.5): 5, (33, 1, 2, 0.01): 4, (33, 1, 2, 0.5): 5,
                  (64, 1, 2, 0.01): 5, (64, 1, 2, 0.5): 4, (64, 80, 1, 0.01): 3, (64, 80, 1, 0.5): 5, (64, 80, 2, 0.01): 2,
                  (64, 80, 2, 0.5): 5, (200, 1, 1, 0.01): 2, (200, 1, 1, 0.5): 4, (150, 80, 3, 0.01): 3, (150, 80, 3, 0.5): 5}
