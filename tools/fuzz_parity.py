@@ -23,9 +23,10 @@ NFC = 0 if CONF in (5, 6) else 3
 if CONF == 5:
     NC, NB = 80, 3
     net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32), num_pwfeat_fc=0)
-elif CONF == 6:
+elif CONF in (6, 7):                                    # (7 = 6 with the experiments' pw-MLP: the control for 6's error level)
     NC, NB = 1, 2
-    net, orc = make_pair(NC, NB, bias=0.5, num_pwfeat_fc=0, pw_feat_multiplyer=0.7)
+    NFC = 0 if CONF == 6 else 3
+    net, orc = make_pair(NC, NB, bias=0.5, num_pwfeat_fc=NFC, pw_feat_multiplyer=0.7)
 elif CONF in (0, 4):
     NC, NB = 80, (2 if CONF == 0 else 16)                # (4 = the real depth, 16 blocks)
     net, orc = make_pair(NC, NB, class_weights=np.linspace(0.5, 1.5, NC + 1).astype(np.float32))
@@ -83,7 +84,7 @@ def nasty_image():
 
 
 t0 = time.time()
-worst_pin, worst_kink = 0.0, 0.0
+worst_pin, worst_kink, n_fp64 = 0.0, 0.0, 0
 for case in range(cases):
     pairs = [nasty_image() for _ in range(1 if rng.uniform() < 0.6 else int(rng.integers(2, 5)))]
     imgs = [p[0] for p in pairs]
@@ -120,11 +121,32 @@ for case in range(cases):
             g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
             gr = gsum[name].reshape(-1)
             pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 5e-2)) if gr.size else 0.0
-        assert max(pinned.values()) <= PINNED, max(pinned.items(), key=lambda kv: kv[1])
+        if max(pinned.values()) > PINNED:
+            # at the bar: is it the device, or what fp32 can resolve here?  (three overlapping detections: the head's gradients are sums
+            # with heavy cancellation.)  The fp64 twin of the oracle on the same piece decides: the device must be no further from it
+            # than twice the fp32 oracle itself is, and within 2 x the bar.
+            o64 = go.GnetOracle(NC, NB, params={k: v.detach().numpy() for k, v in orc.params.items()}, dtype=torch.float64,
+                                class_weights=orc.class_weights.numpy(), normalize_loss=orc.normalize_loss,
+                                pw_feat_multiplyer=orc.pw_feat_multiplyer, neighbor_feats=NF, num_pwfeat_fc=NFC)
+            g64 = None
+            for i, im in enumerate(imgs):
+                _, b_ = o64.forward_backward(im, pins=gpu_pins(net, i if len(imgs) > 1 else None))
+                g64 = {k: np.asarray(v, np.float64) for k, v in b_.items()} if g64 is None else {k: g64[k] + b_[k] for k in g64}
+            for name, err in pinned.items():
+                if err <= PINNED:
+                    continue
+                g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
+                r64, r32 = g64[name].reshape(-1), gsum[name].reshape(-1)
+                den = np.abs(r64).max() + 5e-2
+                e_dev, e_f32 = np.abs(g - r64).max() / den, np.abs(r32 - r64).max() / den
+                print("case %d %s: %s at %.2e of the fp32 oracle; against the fp64 twin: device %.2e, fp32 oracle %.2e" % (case, desc, name, err, e_dev, e_f32), flush=True)
+                assert e_dev <= 2.0 * e_f32 and err <= 2.0 * PINNED, (name, err, e_dev, e_f32)
+                n_fp64 += 1
         worst_pin, worst_kink = max(worst_pin, max(pinned.values())), max(worst_kink, worst)
     except Exception as e:
         print("case %d (dets, gts, mode) %s: %s: %s" % (case, desc, type(e).__name__, e), flush=True)
         raise
     if os.environ.get("FUZZ_VERBOSE"):
-        print("case", case, desc, "E", int(net.num_edges), "pinned %.2e" % max(pinned.values()), flush=True)
-print("parity fuzz: %d cases in %.1f s; worst gradient error on the common piece %.2e, worst kink distance %.2e" % (cases, time.time() - t0, worst_pin, worst_kink))
+        print("case", case, desc, "E", int(net.num_edges), "pinned %.2e" % max(pinned.values()), max(pinned.items(), key=lambda kv: kv[1])[0], flush=True)
+print("parity fuzz: %d cases in %.1f s; worst gradient error on the common piece %.2e, worst kink distance %.2e%s"
+      % (cases, time.time() - t0, worst_pin, worst_kink, "; %d tensor(s) above the bar settled against the fp64 twin" % n_fp64 if n_fp64 else ""))
