@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
   } while (0)
   // h1^T piece of this wave: accumulators start from the two table rows, 4 MFMAs add the geometry term (K = 8), one integer
   // max rectifies, the rows go to LDS in the [edge][feature] layout fc2 reads
-#define PW2_FC1(dstH_, u_)                                                                         \
+#define PW2_FC1(dstH_)                                                                             \
   do {                                                                                             \
     f32x16 h_;                                                                                     \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
@@ -292,18 +292,7 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
     float* d_ = (dstH_) + col * PW2_LD + 32 * wave + 4 * half;                                     \
     _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                  \
       *reinterpret_cast<float4*>(d_ + 8 * g) = make_float4(relu_bits(h_[4 * g]), relu_bits(h_[4 * g + 1]), relu_bits(h_[4 * g + 2]), relu_bits(h_[4 * g + 3])); \
-    PW2_H1_DIRECT_STORE(u_);                                                                       \
   } while (0)
-#ifdef PW2_H1_DIRECT
-#define PW2_H1_DIRECT_STORE(u_)                                                                    \
-    if (TRAINING) {                                                                                \
-      float* g_ = a.h1 + (size_t)(min((u_), nt - 1) * PW2_T) * D_H + 32 * wave;                      \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                \
-        pw2_st4(g_, h2_lo + 32u * g, make_float4(relu_bits(h_[4 * g]), relu_bits(h_[4 * g + 1]), relu_bits(h_[4 * g + 2]), relu_bits(h_[4 * g + 3]))); \
-    }
-#else
-#define PW2_H1_DIRECT_STORE(u_)
-#endif
 
   // forward-only: the fc3 partial product of a tile is DEFERRED into the next tile's stream (its rectified accumulators and W3
   // pieces kept across the barrier) -- the tile then ends with its last fc2 MFMAs instead of 16 MFMAs + 16 LDS stores + their
@@ -326,7 +315,7 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
     const unsigned e1 = (unsigned)PW2_EDGE(t0 + 1);
     c1 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e1); n1 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e1);
     PW2_REQUEST(c0, n0);
-    PW2_FC1(sH, t0);
+    PW2_FC1(sH);
   }
   pw2_barrier();
 
@@ -397,12 +386,11 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
         const int ep = it > 0 ? e0 - PW2_T : a.n_edge + 32;
         pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(s_.x + b3a, 0.f), fmaxf(s_.y + b3b, 0.f)));
       }
-      // training: four whole h1 rows per wave, read from LDS one fragment before they are stored
-#ifndef PW2_H1_DIRECT
+      // training: four whole h1 rows per wave, read from LDS one fragment before they are stored (stored straight from fc1's
+      // accumulators instead, as 16-byte pieces like h2: +1.6 %, measured)
       if (TRAINING && f >= 7 && f < 11) pw2_st4(a.h1 + (size_t)(e0 + 4 * wave + (f - 7)) * D_H, 16u * lane, hrow);
       if (TRAINING && f >= 6 && f < 10) hrow = *reinterpret_cast<const float4*>(Hc + (4 * wave + (f - 6)) * PW2_LD + 4 * lane);
-#endif
-      if (f == (DEFER ? 20 : 16)) PW2_FC1(Hn, t + 1);
+      if (f == (DEFER ? 20 : 16)) PW2_FC1(Hn);
       if (f == (DEFER ? 26 : 24)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) w3r[r] = w3p[crow(r, 0) * D_E];
