@@ -589,23 +589,9 @@ struct PwBwdArgs {
   GNET_TRACE_FIELD
 };
 
-// Asynchronous global -> LDS copy of a [32][256] fp32 tile (one 1 KB row per wave-instruction: the LDS
-// destination of global_load_lds is wave-uniform base + lane * 16, exactly one padded row).  No staging
-// registers; completion is tracked by vmcnt.  Rows past the end re-read the last real row (finite data;
-// their d3 rows are zero, so they contribute nothing).
-__device__ __forceinline__ void dma_tile32(float* sdst, const float* __restrict__ g, long long e0, long long n_rows,
-                                           int wave, int lane) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = wave * 4 + q;
-    const long long er = min(e0 + row, n_rows - 1);
-    const float* src = g + (size_t)er * D_H + 4 * lane;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sdst + row * LD256), 16, 0, 0);
-  }
-}
-
-// the same copy for rows given by an index list (rows past the list re-read its last row)
+// Asynchronous global -> LDS copy of a [32][256] fp32 tile whose rows are given by an index list (one 1 KB row per
+// wave-instruction: the LDS destination of global_load_lds is wave-uniform base + lane * 16, exactly one padded row).  No staging
+// registers; completion is tracked by vmcnt.  Rows past the list re-read its last row (finite data; their d3 rows are zero).
 __device__ __forceinline__ void dma_rows32(float* sdst, const float* __restrict__ g, const int* __restrict__ rows, int p0,
                                            int n_rows, int wave, int lane) {
 #pragma unroll
@@ -617,216 +603,319 @@ __device__ __forceinline__ void dma_rows32(float* sdst, const float* __restrict_
                                      (__attribute__((address_space(3))) void*)(sdst + row * LD256), 16, 0, 0);
   }
 }
-// ... with the four row indices of this wave already in registers (fetched a tile earlier): the copies are issued back to
-// back.  (Fetching an index right in front of its copy made the in-order memory counter wait for the copies issued before
-// it -- a 1 KB HBM round trip each -- before the next one could start.)
-__device__ __forceinline__ void dma_rows32_ids(float* sdst, const float* __restrict__ g, const int (&er)[4], int wave, int lane) {
-  // the four row indices are wave-uniform: as scalars, the source address is a scalar base + the lane's constant 16-byte offset
-  // (no per-lane 64-bit address arithmetic; 10 registers less)
-  const unsigned lane_b = 16u * (unsigned)lane;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int rq = __builtin_amdgcn_readfirstlane(er[q]);
-    const char* src = reinterpret_cast<const char*>(g + (size_t)rq * D_H) + lane_b;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sdst + (wave * 4 + q) * LD256), 16, 0, 0);
-  }
-}
+// entry p of the row list as (uniform base) + (32-bit offset); positions past the list re-read its last entry
+#define PB_ROW(tile_, r_) (int)ldg_b(reinterpret_cast<const unsigned*>(a.rows), 4u * (unsigned)min((tile_) * 32 + (r_), n_rows - 1))
 
-// BIG: the [E,256] fp32 arrays exceed 4 GB (E > 2^22 - 64): row offsets need 64 bits.  Otherwise every d_h1 store is
-// (uniform base) + (32-bit offset): one 32-bit vector instruction per address -- the 64-bit form costs a 64-bit shift and a 64-bit
-// add per store, and 64-bit vector instructions beside an MFMA stream are far dearer than their count (pw_fwd2 lost 2 % to nine).
+// ------------------------------------------------------------------------------------------
+// pw_bwd_main (round 5, second form): ONE stream of 288 MFMAs per wave and tile behind ONE workgroup barrier (pw_fwd2's recipe, lesson 56).
+// 32-row tile / 8 waves, one workgroup per CU looping over its tiles of the row list; dW2 (256 x 256) lives in 128 accumulator registers
+// per wave across the whole range, dW3 in 16.  The first form had three phases per tile with all eight waves at the same point and the
+// pipe mostly empty: the d3 stage (no MFMA), a light phase between its two barriers (32 MFMAs behind LDS round trips) and the 16 d_h1
+// stores at the tile's end -- ~4.5 of a 19.7 us tile.  Here every light piece of the tiles t+1 / t+2 sits INSIDE the MFMAs of tile t:
+//   top   dW3 += h2(t)^T . d3(t)              16 MFMAs (operands: registers + a d3 tile staged two tiles ago) while the first dW2 operands
+//                                              come from LDS; between them the 16 stores of d h1(t-1), masked before the barrier
+//   I-a   dW2 += h1(t)^T . d2(t)              128 MFMAs; woven: W3, the four h1 row copies of tile t+1 (LDS-DMA), the d3 sources of tile
+//                                              t+2, the h2(t+1) requests, the row ids of tile t+3, the d3 stage of tile t+2, then
+//         d2(t+1) = d3(t+1) . W3^T             16 MFMAs, its mask (h2(t+1) > 0), column sums (d b2) and LDS store; the first W2 rows
+//   I-b   d h1(t) = d2(t) . W2^T              128 MFMAs, W2 rows streamed from L2 six k-steps ahead; woven: d b3
+//   tail  ReLU mask of d h1(t) (h1(t) is overwritten during the next tile), barrier
+// Rules it follows: (1) everything with HBM latency is requested in the LDS-fed half (I-a) -- memory returns in order, so a slow request
+// in front of the W2 stream would hold every one of its operands back; (2) h2 never goes through LDS: a wave touches only ITS OWN 32
+// columns of it (the mask of its d2 piece, the A operand of its dW3 rows), so it is 16 plain loads per lane (lane = column, register r =
+// tile row crow(r, half): two 128-byte segments per instruction) and the k-steps of dW3 pair the rows (crow(kk, 0), crow(kk, 1)) -- the
+// registers ARE the operand; (3) a buffer written during tile t is read only behind the next barrier and was last read before the
+// previous one: h1 x 2 (DMA), d2 x 2, d3 x 3 (+ their column sums), row ids x 4 = 150 KB of LDS; (4) 256 registers, no spill in the loop
+// (a reload is a scratch load + s_waitcnt vmcnt(0) in the middle of the copies in flight: the order of the pieces above is what fits).
+// Same d2 / dW2 / d h1 instruction sequences as the first form (same bits); dW3 sums its rows in another order.
+// Measured (A/B on one box, GNET_LIB_AB): 2.53-2.57 -> 2.46-2.50 ms.  Per-wave time stamps (GNET_TRACE build, wave 0 and wave 4 = the two
+// waves of SIMD 0): the older wave of a SIMD wins every issue slot and runs ~4 us ahead of its partner; alternating s_setprio per MFMA
+// group evens that out and changes nothing (the pair's total is what counts): the tile is 36.9 k cycles of MFMA + ~430 vector
+// instructions + 350 LDS instructions per SIMD at the 2.2 GHz the chip sustains here.
+constexpr int PBP_D = 2 * 32 * LD256;
+constexpr int PBP_D3 = 4 * 32 * LD256;
+constexpr int PBP_G3 = PBP_D3 + 3 * 32 * LD32;                // (three d3 tiles: t -- dW3 at the tile's top --, t+1, t+2)
+constexpr int PBP_ROWS = PBP_G3 + 3 * 256;                    // int [4][2][32]: list entries | the same with the slack row past the list
+constexpr size_t kPwBwdSmem = (size_t)(PBP_ROWS + 4 * 64) * sizeof(float);
+
 template <bool BIG>
 __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // two tile buffers {h1 [32][260], h2 [32][260]} filled by DMA one tile ahead, + d3 [32][36]
-  float* sD3 = smem + 4 * 32 * LD256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31, half = lane >> 5;
+  float* sD3 = smem + PBP_D3;
+  float* sG3 = smem + PBP_G3;
+  int* sRows = reinterpret_cast<int*>(smem + PBP_ROWS);
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x16 aW2[1][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) aW2[0][j] = zero16();
   f32x16 aW3 = zero16();
   float gb2 = 0.f, gb3 = 0.f;
-  __shared__ int sRows[2][32];              // edge index of the tile's rows (this tile / the next one)
-  __shared__ float sG3[8 * 32];             // per-wave column sums of the d3 tile (d b3)
   const int n_rows = *a.n_rows;
   const int ntiles = (n_rows + 31) / 32;
   const int G = (int)gridDim.x;
-  // Everything a tile reads from HBM is requested one tile ahead and BEFORE the tile's 16 d_h1 stores: the
-  // h1/h2 tiles by DMA into the other LDS buffer, the d_pw / pw values of the d3 tile into registers.  The
-  // wait at the top of a tile is then vmcnt(16): "everything but the 16 youngest operations", i.e. it never
-  // waits for the previous tile's stores to be acknowledged (vmcnt is one in-order counter for loads and
-  // stores).  W3 (the same for every tile) stays in registers for the same reason.
+  float pq0 = 0.f, pq1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+  int ra = 0, rb = 0, rs = 0;
   f32x4 w3f[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) w3f[k] = *reinterpret_cast<const f32x4*>(a.w3 + (size_t)(32 * wave + col) * D_E + 4 * half + 8 * k);
-  float pq0 = 0.f, pq1 = 0.f, dq0 = 0.f, dq1 = 0.f;     // d3 tile sources: elements tid and tid + 512 of [32][32]
-  // rows past the list re-read its last row (finite data); their d3 rows are zero
-#define PB_ROW(tile_, r_) (int)ldg_b(reinterpret_cast<const unsigned*>(a.rows), 4u * (unsigned)min((tile_) * 32 + (r_), n_rows - 1))   /* uniform base + 32-bit offset */
-  // the row indices themselves are fetched one tile earlier still (ra / rb / rs), so the d3 source requests
-  // never wait for an index
-  int ra = 0, rb = 0, rs = 0, rs_tile = 0;
-  int dr[4] = {0, 0, 0, 0};                  // rows of the tile's h1 / h2 copies issued by this wave
-#define PB_LOAD_ROWIDS(tile_)                                                                           \
-  do {                                                                                                  \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dr[q_] = PB_ROW(tile_, wave * 4 + q_);             \
-    ra = PB_ROW(tile_, tid >> 5); rb = PB_ROW(tile_, (tid >> 5) + 16);                                  \
-    /* an UNCONDITIONAL load (clamped index; the slack row is selected where the value is used): a load under an exec mask whose    \
-       result merges with the other side's value made the compiler wait for it -- vmcnt(0): for the tile copies and every load just \
-       issued in front of it, a full HBM round trip (2.3 us of every 21.9 us tile, tools/wg_trace.py) -- right here */             \
-    rs = PB_ROW(tile_, tid & 31);                                                                       \
+  float h2r[16];
+  f32x16 d2n;
+  // Every piece of the stream derives its LDS / global offsets from the lane id AFRESH (an opaque copy: the compiler cannot hoist them out
+  // of the loop).  Kept across the loop they are ~25 registers beside 144 accumulators + 16 h2 values + the operand rings: the compiler
+  // spilled nine of them, and a reload is a scratch load followed by s_waitcnt vmcnt(0) -- in the middle of the copies and stores in flight.
+#define PBP_LDG4(base_, off_) (*reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base_) + (off_)))
+#define PBP_LANE()                                                                                       \
+  int lane = lane0;                                                       \
+  const int tid = lane + 64 * wave, col = lane & 31, half = lane >> 5; (void)tid; (void)col; (void)half
+#define PBP_LOAD_IDS(tile_)                                                                              \
+  do { PBP_LANE(); ra = PB_ROW(tile_, tid >> 5); rb = PB_ROW(tile_, (tid >> 5) + 16); rs = PB_ROW(tile_, tid & 31); } while (0)
+#define PBP_REQUEST_D3()                                                                                 \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    const unsigned oa_ = (unsigned)ra * (D_E * 4u) + 4u * (tid & 31), ob_ = (unsigned)rb * (D_E * 4u) + 4u * (tid & 31);   \
+    pq0 = ldg_b(a.pw, oa_); dq0 = ldg_b(a.d_pw, oa_);                                                    \
+    pq1 = ldg_b(a.pw, ob_); dq1 = ldg_b(a.d_pw, ob_);                                                    \
   } while (0)
-#define PB_PREFETCH_D3(tile_)    /* tile_ = the tile whose row ids are in ra / rb / rs */                \
-  do {                                                                                                  \
-    const unsigned oa_ = (unsigned)ra * (D_E * 4u) + 4u * (tid & 31), ob_ = (unsigned)rb * (D_E * 4u) + 4u * (tid & 31);   /* [E,32] fp32: 32-bit byte offsets up to the edge limit */ \
-    pq0 = ldg_b(a.pw, oa_); dq0 = ldg_b(a.d_pw, oa_);                                                   \
-    pq1 = ldg_b(a.pw, ob_); dq1 = ldg_b(a.d_pw, ob_);                                                   \
-    rs_tile = (tile_) * 32 + (tid & 31) < n_rows ? rs : a.n_edge;   /* rows past the list: the slack row */ \
+  // d3 tile (ReLU of fc3 applied; rows past the list: zero) and its per-wave column sums (d b3) -> LDS
+#define PBP_STAGE_D3(tile_, b_)                                                                          \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    const int e0_ = (tile_) * 32, row0_ = tid >> 5, j_ = tid & 31;                                       \
+    const float va_ = (e0_ + row0_ < n_rows && pq0 > 0.f) ? dq0 : 0.f;                                   \
+    const float vb_ = (e0_ + row0_ + 16 < n_rows && pq1 > 0.f) ? dq1 : 0.f;                              \
+    sD3[(b_) * 32 * LD32 + row0_ * LD32 + j_] = va_;                                                     \
+    sD3[(b_) * 32 * LD32 + (row0_ + 16) * LD32 + j_] = vb_;                                              \
+    unsigned lo_, hi_; half_bcast(__float_as_uint(va_ + vb_), lo_, hi_);                                 \
+    if (lane < 32) sG3[(b_) * 256 + wave * 32 + lane] = __uint_as_float(lo_) + __uint_as_float(hi_);     \
+  } while (0)
+  // the tile's list entries, and the same with the slack row for positions past the list (every thread: rs is the entry of row
+  // tid & 31 -- sixteen threads store the same value, no branch)
+#define PBP_STAGE_IDS(tile_, q_)                                                                         \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    sRows[(q_) * 64 + (tid & 31)] = rs; sRows[(q_) * 64 + 32 + (tid & 31)] = (tile_) * 32 + (tid & 31) < n_rows ? rs : a.n_edge;   \
+  } while (0)
+#define PBP_LOAD_W3()                                                                                    \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    const unsigned o_ = (unsigned)((32 * wave + col) * D_E + 4 * half) * 4u;                             \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) w3f[k_] = PBP_LDG4(a.w3, o_ + 32u * k_);             \
+  } while (0)
+  // the wave's 32 columns of the tile's h2 rows: lane = column, register r = tile row crow(r, half)
+#define PBP_REQUEST_H2(rows_)                                                                            \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    const int* rp_ = (rows_) + 4 * half;                                                                 \
+    const unsigned lo_ = (unsigned)(32 * wave + col) * 4u;                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                  \
+      const unsigned rid_ = (unsigned)rp_[crow(r_, 0)];                                                  \
+      if (BIG) h2r[r_] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.h2) + ((unsigned long long)rid_ << 10) + lo_);   \
+      else h2r[r_] = ldg_b(a.h2, (rid_ << 10) + lo_);                                                    \
+    }                                                                                                    \
+  } while (0)
+  // mask of the d2 piece (h2 > 0), its column sums (d b2), the piece -> LDS
+#define PBP_FINISH_D2(D_)                                                                                \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) d2n[r_] = h2r[r_] > 0.f ? d2n[r_] : 0.f;            \
+    float p_ = d2n[0];                                                                                   \
+    _Pragma("unroll") for (int r_ = 1; r_ < 16; ++r_) p_ += d2n[r_];                                     \
+    unsigned lo_, hi_; half_bcast(__float_as_uint(p_), lo_, hi_);                                        \
+    gb2 += __uint_as_float(lo_) + __uint_as_float(hi_);                                                  \
+    float* d_ = (D_) + (4 * half) * LD256 + 32 * wave + col;                                             \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) d_[crow(r_, 0) * LD256] = d2n[r_];                 \
+  } while (0)
+  // d b3: the per-wave column sums of a staged d3 tile (every thread forms the sum of column tid & 31; the first 32 keep it: no branch)
+#define PBP_GB3(b_)                                                                                      \
+  do {                                                                                                   \
+    PBP_LANE();                                                                                          \
+    float p_ = sG3[(b_) * 256 + (tid & 31)];                                                             \
+    _Pragma("unroll") for (int w8_ = 1; w8_ < 8; ++w8_) p_ += sG3[(b_) * 256 + w8_ * 32 + (tid & 31)];   \
+    gb3 += tid < D_E ? p_ : 0.f;                                                                         \
+  } while (0)
+  // d(fc2 pre) piece of this wave before its mask = d3 . W3^T
+#define PBP_D2_MFMA(k_, q_, av_) d2n = __builtin_amdgcn_mfma_f32_32x32x2f32((av_)[q_], w3f[k_][q_], d2n, 0, 0, 0)
+
+  // d h1 of the previous tile: masked before the barrier, STORED at the next tile's top between the dW3 MFMAs
+#define PBP_STORE_DH1(rows_)                                                                             \
+  do {                                                                                                   \
+    const int* rp_ = (rows_) + 4 * half;                                                                 \
+    const unsigned lo_ = (unsigned)(32 * wave + col) * 4u;                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                  \
+      if (BIG) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.d_h1) + ((unsigned long long)(unsigned)rp_[crow(r_, 0)] << 10) + lo_) = acc[r_];   \
+      else stg_b(a.d_h1, ((unsigned)rp_[crow(r_, 0)] << 10) + lo_, acc[r_]);                             \
+    }                                                                                                    \
   } while (0)
   if ((int)blockIdx.x < ntiles) {
-    PB_LOAD_ROWIDS((int)blockIdx.x);
-    dma_rows32(smem, a.h1, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
-    dma_rows32(smem + 32 * LD256, a.h2, a.rows, (int)blockIdx.x * 32, n_rows, wave, lane);
-    PB_PREFETCH_D3((int)blockIdx.x);
-    PB_LOAD_ROWIDS(min((int)blockIdx.x + G, ntiles - 1));
-  }
-  drain_vmem_before_loop();
-  int it = 0;
-  for (int t = blockIdx.x; t < ntiles; t += G, ++it) {
-    const int e0 = t * 32;                 // first list position of the tile
-    float* sH1 = smem + (it & 1) * (2 * 32 * LD256);
-    float* sH2 = sH1 + 32 * LD256;        // fc2 output, then d(fc2 pre-activation)
-    float* nH1 = smem + ((it & 1) ^ 1) * (2 * 32 * LD256);
-    if (it == 5) GSTAMP(a, 0);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this tile's DMA and d3 sources (issued one tile ago) have landed
-    if (it == 5) GSTAMP(a, 1);
-    if (tid < 32) sRows[it & 1][tid] = rs_tile;
-    {
-      const int row0 = tid >> 5, j = tid & 31;            // rows past the list: zero gradient
-      const float va = (e0 + row0 < n_rows && pq0 > 0.f) ? dq0 : 0.f;                      // ReLU of fc3
-      const float vb = (e0 + row0 + 16 < n_rows && pq1 > 0.f) ? dq1 : 0.f;
-      sD3[row0 * LD32 + j] = va;
-      sD3[(row0 + 16) * LD32 + j] = vb;
-      // d b3: this wave's four rows per column (two per lane, the half-waves folded), summed over the waves behind the barrier
-      unsigned lo, hi; half_bcast(__float_as_uint(va + vb), lo, hi);
-      if (lane < 32) sG3[wave * 32 + lane] = __uint_as_float(lo) + __uint_as_float(hi);
-    }
-    if (it == 5) GSTAMP(a, 2);
+    // ---- prologue: h1(t0) on its way, d3(t0) and d3(t0 + G) staged, then d2(t0)
+    const int t0 = (int)blockIdx.x;
+    f32x16 acc = zero16();                                    // (the first tile's "previous tile": zeros to the slack row)
+    PBP_LOAD_IDS(t0);
+    dma_rows32(smem, a.h1, a.rows, t0 * 32, n_rows, wave, lane0);
+    PBP_LOAD_W3();
+    PBP_REQUEST_D3();
+    PBP_STAGE_D3(t0, 0);
+    PBP_STAGE_IDS(t0, 0);
+    { PBP_LANE(); sRows[3 * 64 + 32 + (tid & 31)] = a.n_edge; }
+    PBP_LOAD_IDS(t0 + G);
+    PBP_REQUEST_D3();
+    PBP_STAGE_D3(t0 + G, 1);
+    PBP_STAGE_IDS(t0 + G, 1);
+    PBP_LOAD_IDS(t0 + 2 * G);
     __syncthreads();
-    if (it == 5) GSTAMP(a, 3);
-    // d(fc2 pre) tile w = (d3 . W3^T) * (h2 > 0)
-    f32x16 d2 = zero16();
+    PBP_REQUEST_H2(sRows);
     {
-      const float* ap = sD3 + col * LD32 + 4 * half;
+      PBP_LANE();
+      const float* ap3 = sD3 + col * LD32 + 4 * half;
+      d2n = zero16();
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * k);
-        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w3f[k].x, d2, 0, 0, 0);
-        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w3f[k].y, d2, 0, 0, 0);
-        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w3f[k].z, d2, 0, 0, 0);
-        d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w3f[k].w, d2, 0, 0, 0);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap3 + 8 * k);
+        PBP_D2_MFMA(k, 0, av); PBP_D2_MFMA(k, 1, av); PBP_D2_MFMA(k, 2, av); PBP_D2_MFMA(k, 3, av);
       }
     }
-    if (it == 5) GSTAMP(a, 4);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d2[r] = sH2[crow(r, half) * LD256 + 32 * wave + col] > 0.f ? d2[r] : 0.f;
-    // d b2[32 w + col] += sum over the tile's rows of d2: the lane's sixteen rows, then the other half-wave's (a 32-read LDS
-    // column sum by half of the waves used to follow the barriers: 0.07 of the kernel's 2.70 ms with the one for d b3)
-    {
-      float p = d2[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) p += d2[r];
-      unsigned lo, hi; half_bcast(__float_as_uint(p), lo, hi);
-      gb2 += __uint_as_float(lo) + __uint_as_float(hi);
-    }
-    if (it == 5) GSTAMP(a, 5);
-    // d W3 += h2^T . d3 (rows [32w, 32w+32) of W3)
-    {
-      const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + h;
-        aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sH2[row * LD256 + 32 * wave + r], sD3[row * LD32 + r], aW3, 0, 0, 0);
-      }
-    }
-    if (tid < D_E) {
-      float p = sG3[tid];
-#pragma unroll
-      for (int w8 = 1; w8 < 8; ++w8) p += sG3[w8 * 32 + tid];
-      gb3 += p;
-    }
-    // (no barrier here: a wave reads -- mask above, A operand of d W3 -- and now overwrites only ITS OWN 32 columns of the fc2
-    // tile, and a wave's LDS operations execute in order; d3 and the per-wave sums are rewritten behind the next barrier)
-    if (it == 5) GSTAMP(a, 6);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sH2[crow(r, half) * LD256 + 32 * wave + col] = d2[r];
-    if (it == 5) GSTAMP(a, 7);
+    PBP_FINISH_D2(smem + PBP_D);
+    PBP_GB3(0);
+    drain_vmem_before_loop();
     __syncthreads();
-    if (it == 5) GSTAMP(a, 8);
-    // d W2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns): 16 row pairs x 8 MFMAs, the operands of pair kk + 1
-    // requested in front of the MFMAs of pair kk (pinned).  Everything the NEXT tile reads from HBM is requested INSIDE this
-    // stream, one request per row pair: the eight h1 / h2 row copies into the other buffer (last read during the previous tile),
-    // the d3 sources, the row ids of the tile after the next.  (Issued as a block right behind the barrier above they cost
-    // every wave ~1.3 us -- 8 LDS-DMA issues with their scalar address set-up, ten loads -- with no MFMA in the pipe of any
-    // SIMD: all eight waves are there at the same time.)  Unconditional: past the last tile the clamped rows are copied into a
-    // buffer nobody reads; in-order vmcnt still never waits on them before the d_h1 stores of this tile are issued.
-    {
-      const int tn = min(t + G, ntiles - 1), tnn = min(t + 2 * G, ntiles - 1);
-      const float* X = sH1 + 32 * wave; const float* Y = sH2;
-      float xa = X[half * LD256 + col], yb[8];
+
+    int it = 0, i3 = 0;                                       // i3 = it % 3: d3(t) lives in buffer i3, d3(t+1) in the next, d3(t+2) is staged
+    for (int t = t0; t < ntiles; t += G, ++it, i3 = i3 == 2 ? 0 : i3 + 1) {
+      const int p = it & 1;
+      const int i3n = i3 == 2 ? 0 : i3 + 1, i3w = i3n == 2 ? 0 : i3n + 1;
+      const float* H1c = smem + p * 32 * LD256;
+      float* H1n = smem + (p ^ 1) * 32 * LD256;
+      const float* Dc = smem + PBP_D + p * 32 * LD256;
+      float* Dn = smem + PBP_D + (p ^ 1) * 32 * LD256;
+      const float* D3c = sD3 + i3 * 32 * LD32;
+      const float* D3n = sD3 + i3n * 32 * LD32;
+      const int* rowsN = sRows + ((it + 1) & 3) * 64;
+      const int* rowsP = sRows + ((it + 3) & 3) * 64 + 32;    // the previous tile's rows, the slack row past the list
+      if (it == 5) { GSTAMP(a, 0); GSTAMP_W(a, 8, 256); }
+      constexpr int NS = D_H / 8, PF = 6;
+      f32x4 ring[PF];                                         // W2 rows of phase I-b, six k-steps ahead
+      // ---- I-a: dW2 += h1^T . d2 (rows [32w, 32w+32) of W2, all 256 columns)
+      {
+        PBP_LANE();
+        const int4 drv = *reinterpret_cast<const int4*>(rowsN + 4 * wave);      // the four rows of tile t+1 this wave copies (uniform)
+        const int dr[4] = {drv.x, drv.y, drv.z, drv.w};
+        const float* X = H1c + 32 * wave + half * LD256 + col; const float* Y = Dc + half * LD256 + col;
+        float xa = X[0], yb[8];
 #pragma unroll
-      for (int n = 0; n < 8; ++n) yb[n] = Y[half * LD256 + 32 * n + col];
+        for (int n = 0; n < 8; ++n) yb[n] = Y[32 * n];
+        // ---- II-b of this tile (its d2 was formed during the previous tile): dW3 += h2(t)^T . d3(t) -- operands in registers and in a d3
+        // buffer staged two tiles ago, so its 16 MFMAs run while the first dW2 operands are on their way from LDS; between them the
+        // 16 stores of the PREVIOUS tile's d h1 (masked before the barrier)
+        {
+          const float* b3p = D3c + (4 * half) * LD32 + col;
+          PBP_STORE_DH1(rowsP);
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * (kk + 1 < 16 ? kk + 1 : kk) + half;
-        const float xn = X[row * LD256 + col];
-        float yn[8];
+          for (int kk = 0; kk < 16; kk += 4) {
+            float b3[4];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) yn[n] = Y[row * LD256 + 32 * n + col];
-        if (kk < 8) {
-          const int q_ = kk & 3;
-          const int rq = __builtin_amdgcn_readfirstlane(dr[q_]);
-          const char* src = reinterpret_cast<const char*>((kk < 4 ? a.h1 : a.h2) + (size_t)rq * D_H) + 16u * (unsigned)lane;
-          float* dst = nH1 + (kk < 4 ? 0 : 32 * LD256) + (wave * 4 + q_) * LD256;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            for (int q = 0; q < 4; ++q) b3[q] = b3p[crow(kk + q, 0) * LD32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(h2r[kk + q], b3[q], aW3, 0, 0, 0);
+          }
         }
-        if (kk == 8) PB_PREFETCH_D3(tn);
-        if (kk == 9) PB_LOAD_ROWIDS(tnn);
+        if (it == 5) { GSTAMP(a, 1); GSTAMP_W(a, 9, 256); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) aW2[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, yb[n], aW2[0][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        xa = xn;
+        for (int kk = 0; kk < 16; ++kk) {
+          const int row = 2 * (kk + 1 < 16 ? kk + 1 : kk);
+          const float xn = X[row * LD256];
+          float yn[8];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) yb[n] = yn[n];
+          for (int n = 0; n < 8; ++n) yn[n] = Y[row * LD256 + 32 * n];
+          // everything with HBM latency is requested HERE, in the LDS-fed half of the stream: memory returns in order, so a slow request
+          // in front of the W2 stream of phase I-b would hold every one of its operands back
+          if (kk == 8 && it == 5) { GSTAMP(a, 2); GSTAMP_W(a, 10, 256); }
+          if (kk == 12 && it == 5) { GSTAMP(a, 3); GSTAMP_W(a, 11, 256); }
+          if (kk == 14 && it == 5) { GSTAMP(a, 4); GSTAMP_W(a, 12, 256); }
+          if (kk == 0) PBP_LOAD_W3();                       // (in front of the copies)
+          if (kk < 4) {
+            const int rq = __builtin_amdgcn_readfirstlane(dr[kk]);
+            const char* src = reinterpret_cast<const char*>(a.h1 + (size_t)rq * D_H) + 16u * (unsigned)lane;
+            float* dst = H1n + (wave * 4 + kk) * LD256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          }
+          if (kk == 4) { PBP_REQUEST_D3(); PBP_STAGE_IDS(t + 2 * G, (it + 2) & 3); }   // sources of tile t+2 (ids loaded during tile t-1)
+          if (kk == 5) PBP_REQUEST_H2(rowsN);
+          if (kk == 6) PBP_LOAD_IDS(t + 3 * G);
+          if (kk == 12) {                                   // II-a: d2(t+1) = d3(t+1) . W3^T
+            const float* ap3 = D3n + col * LD32 + 4 * half;
+            d2n = zero16();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x4 av = *reinterpret_cast<const f32x4*>(ap3 + 8 * k);
+              PBP_D2_MFMA(k, 0, av); PBP_D2_MFMA(k, 1, av); PBP_D2_MFMA(k, 2, av); PBP_D2_MFMA(k, 3, av);
+            }
+          }
+          if (kk == 12) PBP_STAGE_D3(t + 2 * G, i3w);
+          if (kk == 13) PBP_FINISH_D2(Dn);                  // its mask (h2(t+1), requested at kk = 5), column sums, the piece -> LDS
+          if (kk >= 14) {
+            const unsigned o_ = (unsigned)((32 * wave + col) * D_H + 4 * half) * 4u;
+#pragma unroll
+            for (int i = 3 * (kk - 14); i < 3 * (kk - 13); ++i) ring[i] = PBP_LDG4(a.w2, o_ + 32u * i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int n = 0; n < 8; ++n) aW2[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, yb[n], aW2[0][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          xa = xn;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) yb[n] = yn[n];
+        }
       }
-    }
-    if (it == 5) GSTAMP(a, 10);
-    // d(fc1 pre) tile w = (d2 . W2^T) * (h1 > 0)
-    {
-      f32x16 acc = zero16();
-      mma_abt_gB<D_H, 6>(acc, sH2, LD256, a.w2 + (size_t)(32 * wave) * D_H, D_H, lane);
-      if (it == 5) GSTAMP(a, 11);
-      // d_h1 rows go back to their edge positions (rows past the list: the slack row E); exactly 16 stores
-      const int* rp = sRows[it & 1] + 4 * half;
-      const float* hp = sH1 + (4 * half) * LD256 + 32 * wave + col;
-      if (BIG) {
-        char* lane_base = reinterpret_cast<char*>(a.d_h1 + 32 * wave + col);
+      if (it == 5) { GSTAMP(a, 5); GSTAMP_W(a, 13, 256); }
+      // ---- I-b: d(fc1 pre) tile = d2 . W2^T, the W2 rows streamed from L2 six k-steps ahead
+      acc = zero16();
+      {
+        PBP_LANE();
+        const float* ap = Dc + col * LD256 + 4 * half;
+        const unsigned o_ = (unsigned)((32 * wave + col) * D_H + 4 * half) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          *reinterpret_cast<float*>(lane_base + ((unsigned long long)(unsigned)rp[crow(r, 0)] << 10)) = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
-      } else {
-        const unsigned lane_off = (unsigned)(32 * wave + col) * 4u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stg_b(a.d_h1, ((unsigned)rp[crow(r, 0)] << 10) + lane_off, hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f);
+        for (int s = 0; s < NS; ++s) {
+          const f32x4 b = ring[s % PF];
+          if (s + PF < NS) ring[s % PF] = PBP_LDG4(a.w2, o_ + 32u * (s + PF));
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * s);
+          if (s == 16 && it == 5) { GSTAMP(a, 6); GSTAMP_W(a, 14, 256); }
+          if (s == 12) PBP_GB3(i3n);
+          __builtin_amdgcn_sched_barrier(0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      if (it == 5) { GSTAMP(a, 7); GSTAMP_W(a, 15, 256); }
+      // ---- tail: the ReLU mask of d h1(t) (h1(t) is overwritten during the next tile); its stores follow behind the barrier
+      {
+        PBP_LANE();
+        const float* hp = H1c + (4 * half) * LD256 + 32 * wave + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = hp[crow(r, 0) * LD256] > 0.f ? acc[r] : 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the h1 copies of tile t+1 (every later load has been consumed; the stores are a tile old)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (it == 5) GSTAMP(a, 12);
+    {                                                         // the last tile's d h1
+      PBP_LANE();
+      PBP_STORE_DH1(sRows + ((it + 3) & 3) * 64 + 32);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  GSTAMP(a, 15);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the last tile's look-ahead copies: nothing may be in flight into LDS at exit)
+#undef PBP_STORE_DH1
+  const int lane = lane0, tid = threadIdx.x, col = lane & 31;
+#undef PBP_LANE
+#undef PBP_LDG4
+#undef PBP_LOAD_IDS
+#undef PBP_REQUEST_D3
+#undef PBP_STAGE_D3
+#undef PBP_STAGE_IDS
+#undef PBP_LOAD_W3
+#undef PBP_REQUEST_H2
+#undef PBP_FINISH_D2
+#undef PBP_D2_MFMA
+#undef PBP_GB3
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
 #pragma unroll
   for (int j = 0; j < 8; ++j) store_acc(ar + a.o_w2 + (size_t)(32 * wave) * D_H + 32 * j, D_H, aW2[0][j], lane);
@@ -834,8 +923,6 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   if (lane < 32) ar[a.o_b2 + 32 * wave + col] = gb2;
   if (tid < D_E) ar[a.o_b3 + tid] = gb3;
 }
-
-constexpr size_t kPwBwdSmem = (size_t)(4 * 32 * LD256 + 32 * LD32) * sizeof(float);
 
 // fc1 of the pw-MLP: d W1 = X^T . d_h1 with X = [one-hot(c) * s_c | one-hot(n) * s_n | geo(7)].
 // The score columns factor through per-detection sums (deterministic, no class table in LDS):

@@ -66,7 +66,14 @@ static inline unsigned long long* gnet_trace_ptr(const char* name) {
     if ((args).trace && threadIdx.x == 0 && (slot) < 16)                                        \
       (args).trace[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64();                          \
   } while (0)
+// the same from the first lane of another wave (how far apart are the waves of a workgroup?)
+#define GSTAMP_W(args, slot, thread)                                                            \
+  do {                                                                                          \
+    if ((args).trace && threadIdx.x == (thread) && (slot) < 16)                                 \
+      (args).trace[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64();                          \
+  } while (0)
 #else
+#define GSTAMP_W(args, slot, thread) ((void)0)
 #define GNET_TRACE_FIELD
 #define GNET_TRACE_SET(args, name, cond) ((void)0)
 #define GSTAMP(args, slot) ((void)0)
