@@ -1350,6 +1350,9 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     p.w2 = params + L.pw2; p.w3 = params + L.pw3; p.d_h1 = buf->d_h1;
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
     GNET_TRACE_SET(p, "PW_BWD", true);
+#ifdef PW_BWD_FORCE_BIG      /* verification builds: the 64-bit addressing variant on shapes the tests can afford */
+    if (true) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<true><<<g_pw, 512, kPwBwdSmem, s>>>(p)); } else
+#endif
     if ((long long)E + 64 > (1ll << 22)) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<true><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
     else { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<false><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
     PwW1Args w;
