@@ -15,7 +15,10 @@ Inputs are resident in HBM before the timed region.  value = detections/sec over
 The JSON line also carries
   roofline      the dominant kernel class (by HIP-event time inside the timed region): FLOPs of the algorithm as this
                 kernel formulates it (= the MFMA FLOPs it issues) per launch / average launch duration
-                against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) = `frac`; `reference_formulation`
+                against the dense MFMA peak of the pipe it runs on (fp32: 157.3 TFLOP/s; a kernel that forms its fp32
+                products as six bf16 products -- edge_fwd_w -- on the bf16 pipe's 2516.6, its fp32 MFMAs at 16x) = `frac`;
+                `mfma_kernels` lists the four MFMA classes with `frac` = pipe time of the MFMAs issued / kernel time and
+                `fp32_equivalent` = FLOPs of the fp32 formulation / time against the fp32 peak; `reference_formulation`
                 = the same with the FLOPs of the reference's dense per-edge formulation, which a kernel can
                 exceed 1.0 on by not executing them; `traffic` = HBM bytes per launch from the separate rocprofv3
                 --pmc passes (profiles/r05_traffic.json), reported only while that file was collected from the same
@@ -24,7 +27,7 @@ The JSON line also carries
   roi_pool      the RoiPool / RoiPoolGrad ops at the reference's shape (R=2000 rois, 38x63x1024 map, 7x7 bins):
                 compulsory bytes / HIP-event time vs 8 TB/s
   hbm           the HBM-bound kernel classes: algorithmic bytes per launch / average launch duration vs 8 TB/s
-  executed      whole-step MFMA FLOPs really issued and their fraction of the fp32 MFMA peak
+  executed      whole-step MFMA FLOPs really issued per pipe, the pipe-time fraction of the step, and the fp32-equivalent rate
   other_configs the other BASELINE configurations and the reference's own step shape (1 image/step), measured
                 in the same run (rank 0, 1 GPU only): detections/s, E/N, ms/step
   cpu_baseline  the CPU oracle (oracle/gnet_oracle.py, a port of the reference TF-CPU path) timed on this host on
@@ -44,7 +47,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (64 FLOP / clk / SIMD x 1024 SIMDs x 2.4 GHz)
+BF16_MFMA_PEAK_TFLOPS = 2516.6    # dense v_mfma_f32_32x32x16_bf16: 32768 FLOP in 32 clk per SIMD (the guide's ~2.5 PFLOP/s)
 HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 
@@ -75,19 +79,35 @@ def nominal_flops(cls, E, N, C):
 
 
 def executed_mfma_flops(cls, E, N, winners_per_block, pw_rows):
-    """MFMA FLOPs one launch really issues (4096 per v_mfma_f32_32x32x2_f32), from the kernels' tile loops:
-    edge_fwd_w 96 MFMAs per 32 edges (pw_fc1 split P.Wp + rc[c] + rn[n]); edge_bwd_w 160 MFMAs per 32 winner rows;
-    pw_fwd2 fc2 + fc3 + fc1's K = 8 geometry product (the 2C score columns are two table rows per edge); pw_bwd_main 4 GEMMs per listed row."""
+    """MFMA FLOPs one launch really issues, per pipe: (fp32 FLOPs: 4096 per v_mfma_f32_32x32x2_f32, bf16 FLOPs: 32768 per
+    v_mfma_f32_32x32x16_bf16), from the kernels' tile loops:
+    edge_fwd_w forms its fp32 products as six bf16 products of three-term splits: 72 bf16 MFMAs per 32 edges (the fp32 formulation
+    it replaces: 96 fp32 MFMAs, see `fp32_equivalent_flops`); edge_bwd_w 24 bf16 MFMAs (h1, the forward's sequence) + 128 fp32 MFMAs
+    per 32 winner rows; pw_fwd2 fc2 + fc3 + fc1's K = 8 geometry product (the 2C score columns are two table rows per edge);
+    pw_bwd_main 4 GEMMs per listed row."""
     table = {
-        "edge_fwd": 96 * 4096.0 * E / 32,
-        "edge_bwd": 160 * 4096.0 * winners_per_block / 32,
-        "pw_fwd": 2.0 * E * (8 * 256 + 256 * 256 + 256 * 32),      # fc1's geometry term (K = 8 incl. the zero pad) + fc2 + fc3
-        "pw_bwd_main": 2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32),
-        "node_fwd": 2.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128),
-        "node_bwd": 4.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128),
-        "head_bwd": 4.0 * N * (2 * 128 * 128),
+        "edge_fwd": (0.0, 72 * 32768.0 * E / 32),
+        "edge_bwd": (128 * 4096.0 * winners_per_block / 32, 24 * 32768.0 * winners_per_block / 32),
+        "pw_fwd": (2.0 * E * (8 * 256 + 256 * 256 + 256 * 32), 0.0),      # fc1's geometry term (K = 8 incl. the zero pad) + fc2 + fc3
+        "pw_bwd_main": (2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32), 0.0),
+        "node_fwd": (2.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128), 0.0),
+        "node_bwd": (4.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128), 0.0),
+        "head_bwd": (4.0 * N * (2 * 128 * 128), 0.0),
     }
     return table.get(cls)
+
+
+def fp32_equivalent_flops(cls, E, N, winners_per_block, pw_rows):
+    """FLOPs of the kernel's fp32 formulation (what the bf16 products stand for): edge_fwd_w 12 288 per edge, edge_bwd_w 20 480 per winner row."""
+    ex = executed_mfma_flops(cls, E, N, winners_per_block, pw_rows)
+    if ex is None:
+        return None
+    return {"edge_fwd": 96 * 4096.0 * E / 32, "edge_bwd": 160 * 4096.0 * winners_per_block / 32}.get(cls, ex[0])
+
+
+def pipe_seconds(ex):
+    """Time the matrix pipes of the whole device need for these FLOPs at their dense peaks."""
+    return ex[0] / (FP32_MFMA_PEAK_TFLOPS * 1e12) + ex[1] / (BF16_MFMA_PEAK_TFLOPS * 1e12)
 
 
 def algorithmic_bytes(cls, E, N, B, winners_per_block, pw_rows, n_params):
@@ -446,15 +466,22 @@ def main():
                 # e.g. edge_fwd computes P.Wp + rc[c] + rn[n] per edge, the per-node products r.Wc / r.Wn live in
                 # node_fwd); the reference's dense per-edge formulation is reported beside it -- a kernel
                 # can exceed 1.0 of the peak on THOSE FLOPs by not executing them.
-                ex_tflops = ex / avg_s / 1e12 if ex else ach
-                roofline = {"bound": "mfma", "kernel": cls, "achieved": round(ex_tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ex_tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                # a kernel on the bf16 pipe (edge_fwd_w; edge_bwd_w in part) is priced on THAT pipe's dense peak, its fp32 MFMAs
+                # counted at their 16x pipe time; a pure fp32 kernel on the fp32 peak
+                if ex and ex[1] > 0:
+                    peak = BF16_MFMA_PEAK_TFLOPS
+                    ex_tflops = (ex[1] + 16.0 * ex[0]) / avg_s / 1e12
+                else:
+                    peak = FP32_MFMA_PEAK_TFLOPS
+                    ex_tflops = ex[0] / avg_s / 1e12 if ex else ach
+                roofline = {"bound": "mfma", "kernel": cls, "achieved": round(ex_tflops, 3), "peak": peak,
+                            "unit": "TFLOP/s", "frac": round(ex_tflops / peak, 4), "traffic": traffic,
                             "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
                             "launches_note": ("every 5th launch of the class inside the timed region is bracketed by HIP events on the launch stream "
                                               "(5 is coprime with the 16 launches per step: all blocks sampled equally)") if dom_stride == 5 else
                                              "every launch of the class inside the timed region is bracketed by HIP events on the launch stream",
                             "within_3pct": near,
-                            "flops_per_launch": ex if ex else fl,
+                            "flops_per_launch": (ex[1] + 16.0 * ex[0] if ex[1] > 0 else ex[0]) if ex else fl,
                             "flops": "MFMA FLOPs issued per launch = FLOPs of the algorithm as formulated here (DESIGN.md 4)",
                             "reference_formulation": {"flops_per_launch": fl, "tflops": round(ach, 3),
                                                       "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -467,11 +494,17 @@ def main():
         for k_ in ("edge_fwd", "pw_bwd_main", "pw_fwd", "edge_bwd"):
             if counts.get(k_):
                 e_ = executed_mfma_flops(k_, E, N_local, wpb, pw_rows)
+                q_ = fp32_equivalent_flops(k_, E, N_local, wpb, pw_rows)
                 n_ = counts[k_]
-                tf_ = e_ * n_ / (table[k_] * 1e-3) / 1e12
+                t_ = table[k_] * 1e-3
+                # `frac` = the time the matrix pipes need for the MFMAs issued (fp32 ones at 157.3, bf16 ones at 2516.6 TFLOP/s) over
+                # the kernel's time; `fp32_equivalent` = the FLOPs of the kernel's fp32 formulation over its time, against the fp32
+                # peak (a kernel that forms fp32 products on the bf16 pipe can exceed 1.0 there)
                 mfma_kernels[k_] = {"ms_per_step": round(table[k_], 4), "launches_per_step": n_,
-                                    "mfma_flops_per_step": e_ * n_, "tflops": round(tf_, 2),
-                                    "frac": round(tf_ / FP32_MFMA_PEAK_TFLOPS, 4),
+                                    "mfma_flops_per_step": {"f32": e_[0] * n_, "bf16": e_[1] * n_},
+                                    "frac": round(pipe_seconds(e_) * n_ / t_, 4),
+                                    "fp32_equivalent": {"flops_per_step": q_ * n_, "tflops": round(q_ * n_ / t_ / 1e12, 2),
+                                                        "frac_fp32_mfma_peak": round(q_ * n_ / t_ / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                                     "mfma_busy": pmc.get(k_, {}).get("mfma_busy"),
                                     "valu_per_mfma": pmc.get(k_, {}).get("valu_per_mfma")}
         if roofline is not None:
@@ -480,15 +513,20 @@ def main():
             roofline["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per launch, from the separate rocprofv3 "
                                           "--pmc pass (profiles/r05_traffic.json, same kernel sources); null = no current counters")
         # whole-step executed MFMA FLOPs
-        ex_total = 0.0
+        ex_f32, ex_bf16, eq_total = 0.0, 0.0, 0.0
         for k_, c_ in counts.items():
             e_ = executed_mfma_flops(k_, E, N_local, wpb, pw_rows)
             if e_:
-                ex_total += e_ * c_
+                ex_f32 += e_[0] * c_
+                ex_bf16 += e_[1] * c_
+                eq_total += fp32_equivalent_flops(k_, E, N_local, wpb, pw_rows) * c_
         step_s = elapsed / args.steps
-        executed = {"mfma_tflop_per_step": round(ex_total / 1e12, 4),
-                    "tflops": round(ex_total / step_s / 1e12, 3),
-                    "frac_fp32_mfma_peak": round(ex_total / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        executed = {"mfma_tflop_per_step": {"f32": round(ex_f32 / 1e12, 4), "bf16": round(ex_bf16 / 1e12, 4)},
+                    "mfma_pipe_frac": round(pipe_seconds((ex_f32, ex_bf16)) / step_s, 4),
+                    "mfma_pipe_frac_note": "time the matrix pipes need for the MFMAs issued (fp32 at 157.3, bf16 at 2516.6 TFLOP/s dense) / step time",
+                    "fp32_equivalent_tflops": round(eq_total / step_s / 1e12, 3),
+                    "frac_fp32_mfma_peak": round(eq_total / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "frac_fp32_mfma_peak_note": "FLOPs of the kernels' fp32 formulations (bf16 products counted as the fp32 products they stand for) / step time / 157.3",
                     "winner_rows_per_block_over_E": round(wpb / max(E, 1), 4), "pw_rows_over_E": round(pw_rows / max(E, 1), 4)}
         # HBM-bound classes
         kernels = {}
@@ -570,7 +608,11 @@ def main():
             "metric": "detections/sec Gnet fwd+bwd, N=%d/%d-class" % (args.dets, args.classes),
             "value": round(value, 1), "unit": "detections/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": ("fp32 operands, accumulators and results throughout; edge_fwd_w (and the backward kernels that reproduce its bits) form each "
+                           "fp32 product as six bf16 products of exact three-term splits with fp32 accumulation -- error against fp64 equal to the "
+                           "fp32 MFMA's (profiles/r05_bf16x3_probe.txt), parity bars unchanged"),
+            "data": "synthetic",
             "timing": "one timed pass of K steps between barrier + synchronize on both sides, max over ranks (the driver's contract); "
                       "other_configs report the faster of two such passes each",
             "config": {"workload": "BASELINE configs[2] coco_multiclass 80-way N=2000 (synthetic '%s' preset), "

@@ -105,14 +105,12 @@ __global__ void __launch_bounds__(256) winners_mark(const WinArgs a) {
 // a tied maximum; d_pc already carries the 1 / count split (network.py:387-388, TF SegmentMax gradient).
 // A kernel of its own: its registers must not cost winners_mark its occupancy.
 __global__ void __launch_bounds__(256) winners_ties(const WinArgs a) {
-  __shared__ __attribute__((aligned(16))) float sh_all[4][32 * LD64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   const int nwaves = gridDim.x * 4;
   const int blk = blockIdx.y;
   unsigned long long* ewin = a.ewin + (size_t)blk * a.bm_stride;
   unsigned long long* xmask = a.xmask + (size_t)blk * a.xm_stride;
-  float* sh = sh_all[wave];
   const int* tl = a.tlist + (size_t)blk * a.tl_stride;
   const int n_tied = a.tcount[blk];
   // eight waves share a flagged detection, each taking every eighth 32-edge tile of it: the kernel is a handful of
@@ -130,63 +128,54 @@ __global__ void __launch_bounds__(256) winners_ties(const WinArgs a) {
     const float* rnp = a.rn[blk];
     const float* w1tp = a.w1t[blk]; const float* w2tp = a.w2t[blk];
     const float bias0 = a.b2[blk][col], bias1 = a.b2[blk][32 + col];
-    const float rc0 = rcp[col], rc1 = rcp[32 + col];
     const float mx = __uint_as_float((unsigned)(pv >> 32));
     for (int e0 = eb + 32 * sub; e0 < ee; e0 += 32 * 8) {
       const int nrows = min(32, ee - e0);
       if (lane < nrows) xmask[e0 + lane] = 0ull;            // this tile's masks (every edge belongs to one tile of one wave)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // pw_fc1 / pw_fc2 of the tile with edge_fwd_w's operation sequence: layer 1 transposed (lane = edge, registers = features,
+      // accumulators start from rc + rn), every product as six bf16 products of the split operands in the same k-slot order
+      // (common.hpp: split3_8 / mma6; the slot order is edge_fwd_w's LDS layout)
       f32x16 h1a, h1b;
+      {
+        const int nz = a.edge_nz[min(e0 + col, ee - 1)];
+        const float* rnl = rnp + (size_t)nz * D_P + 4 * half;
+        const float* rcl = rcp + 4 * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int nz = a.edge_nz[min(e0 + crow(r, half), ee - 1)];
-        h1a[r] = rc0 + rnp[(size_t)nz * D_P + col];
-        h1b[r] = rc1 + rnp[(size_t)nz * D_P + 32 + col];
+        for (int g = 0; g < 4; ++g) {
+          const float4 ca = *reinterpret_cast<const float4*>(rcl + 8 * g), cb = *reinterpret_cast<const float4*>(rcl + 32 + 8 * g);
+          const float4 na = *reinterpret_cast<const float4*>(rnl + 8 * g), nb = *reinterpret_cast<const float4*>(rnl + 32 + 8 * g);
+          h1a[4 * g + 0] = ca.x + na.x; h1a[4 * g + 1] = ca.y + na.y; h1a[4 * g + 2] = ca.z + na.z; h1a[4 * g + 3] = ca.w + na.w;
+          h1b[4 * g + 0] = cb.x + nb.x; h1b[4 * g + 1] = cb.y + nb.y; h1b[4 * g + 2] = cb.z + nb.z; h1b[4 * g + 3] = cb.w + nb.w;
+        }
       }
       {
         const float* ap = a.pw + (size_t)min(e0 + col, ee - 1) * D_E + 4 * half;
-        const float* b0 = w1tp + (size_t)col * (D_E + 2 * D_R) + 4 * half;
-        const float* b1 = b0 + 32 * (D_E + 2 * D_R);
+        const float* wl = w1tp + (size_t)col * (D_E + 2 * D_R) + 4 * half;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 8 * k);
-          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
-          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
-          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h1a, 0, 0, 0);
-          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h1b, 0, 0, 0);
-          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h1a, 0, 0, 0);
-          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h1b, 0, 0, 0);
-          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h1a, 0, 0, 0);
-          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h1b, 0, 0, 0);
-          h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h1a, 0, 0, 0);
-          h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h1b, 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          const Bf3 pb = split3_8(*reinterpret_cast<const f32x4*>(ap + 16 * j), *reinterpret_cast<const f32x4*>(ap + 16 * j + 8));
+          const Bf3 wa0 = split3_8(*reinterpret_cast<const f32x4*>(wl + 16 * j), *reinterpret_cast<const f32x4*>(wl + 16 * j + 8));
+          const float* wl1 = wl + 32 * (D_E + 2 * D_R);
+          const Bf3 wa1 = split3_8(*reinterpret_cast<const f32x4*>(wl1 + 16 * j), *reinterpret_cast<const f32x4*>(wl1 + 16 * j + 8));
+          h1a = mma6(h1a, wa0, pb);
+          h1b = mma6(h1b, wa1, pb);
         }
       }
-      wave_lds_sync();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sh[crow(r, half) * LD64 + col] = relu_bits(h1a[r]);
-        sh[crow(r, half) * LD64 + 32 + col] = relu_bits(h1b[r]);
-      }
-      wave_lds_sync();
+      for (int r = 0; r < 16; ++r) { h1a[r] = relu_bits(h1a[r]); h1b[r] = relu_bits(h1b[r]); }
       f32x16 h2a = zero16(), h2b = zero16();
       {
-        const float* ap = sh + col * LD64 + 4 * half;
-        const float* b0 = w2tp + (size_t)col * D_P + 4 * half;
-        const float* b1 = b0 + 32 * D_P;
-#pragma unroll 4
-        for (int k = 0; k < D_P; k += 8) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k);
-          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + k);
-          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + k);
-          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv0.x, h2a, 0, 0, 0);
-          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv1.x, h2b, 0, 0, 0);
-          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv0.y, h2a, 0, 0, 0);
-          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv1.y, h2b, 0, 0, 0);
-          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv0.z, h2a, 0, 0, 0);
-          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv1.z, h2b, 0, 0, 0);
-          h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv0.w, h2a, 0, 0, 0);
-          h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv1.w, h2b, 0, 0, 0);
+        const float* vl = w2tp + (size_t)col * D_P + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x16& hs = j < 2 ? h1a : h1b;
+          const int r0 = 8 * (j & 1), fo = 32 * (j >> 1) + 16 * (j & 1);
+          const Bf3 ha = split3_8(f32x4{hs[r0], hs[r0 + 1], hs[r0 + 2], hs[r0 + 3]}, f32x4{hs[r0 + 4], hs[r0 + 5], hs[r0 + 6], hs[r0 + 7]});
+          const Bf3 wb0 = split3_8(*reinterpret_cast<const f32x4*>(vl + fo), *reinterpret_cast<const f32x4*>(vl + fo + 8));
+          const Bf3 wb1 = split3_8(*reinterpret_cast<const f32x4*>(vl + 32 * D_P + fo), *reinterpret_cast<const f32x4*>(vl + 32 * D_P + fo + 8));
+          h2a = mma6(h2a, ha, wb0);
+          h2b = mma6(h2b, ha, wb1);
         }
       }
       unsigned long long tleft = ties;
@@ -413,19 +402,16 @@ __device__ __forceinline__ void ebw_stage_h1(float* sH, int* sE, const float* sW
   }
   const float* b0 = sWpT + col * (D_E + 4) + 4 * half;
   const float* b1 = b0 + 32 * (D_E + 4);
+  // edge_fwd_w's sequence: per k-step of 16 the six bf16 products of the split operands (common.hpp: mma6), k-slots 0-3 = pf 16 j + 4 half + q,
+  // 4-7 = 8 further.  The weights are split here from their fp32 LDS copy (which the d P product reads as fp32): 32 values per lane and
+  // tile, about what the 24 bf16 MFMAs save over 32 fp32 ones -- the point is the bits, not the time.
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const f32x4 av = pa[k];
-    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
-    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.x, av.x, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.x, av.x, h1b, 0, 0, 0);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.y, av.y, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.y, av.y, h1b, 0, 0, 0);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.z, av.z, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.z, av.z, h1b, 0, 0, 0);
-    h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.w, av.w, h1a, 0, 0, 0);
-    h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.w, av.w, h1b, 0, 0, 0);
+  for (int j = 0; j < 2; ++j) {
+    const Bf3 pb = split3_8(pa[2 * j], pa[2 * j + 1]);
+    const Bf3 wa0 = split3_8(*reinterpret_cast<const f32x4*>(b0 + 16 * j), *reinterpret_cast<const f32x4*>(b0 + 16 * j + 8));
+    const Bf3 wa1 = split3_8(*reinterpret_cast<const f32x4*>(b1 + 16 * j), *reinterpret_cast<const f32x4*>(b1 + 16 * j + 8));
+    h1a = mma6(h1a, wa0, pb);
+    h1b = mma6(h1b, wa1, pb);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) { h1a[r] = relu_bits(h1a[r]); h1b[r] = relu_bits(h1b[r]); }

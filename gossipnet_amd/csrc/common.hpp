@@ -304,6 +304,52 @@ __device__ __forceinline__ float half_fmax(float x) {
 __device__ __forceinline__ unsigned half_add(unsigned x) { unsigned lo, hi; half_bcast(x, lo, hi); return lo + hi; }
 __device__ __forceinline__ int half_min(int x) { unsigned lo, hi; half_bcast((unsigned)x, lo, hi); return min((int)lo, (int)hi); }
 
+// ---- fp32 products on the bf16 pipe (edge_fwd_w and the kernels that must reproduce its bits) -------------------------------
+// x = hi + mid + lo EXACTLY, each term a bf16: hi and mid by truncation to the upper 16 bits, lo the <= 8 significant bits that are
+// left (normal numbers; the activations and weights here are finite).  A product of two fp32 operands is then the six bf16 products
+// hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid (what is dropped is below 2^-24 of |a||b|), accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16: 6 x 32 cycles for K = 16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same K -- measured
+// (tools/bf16x3_probe.hip, profiles/r05_bf16x3_probe.txt): the same error against fp64 as the fp32 MFMA (1.7e-7 of sum |a||b|
+// against 2.1e-7), and an edge_fwd_w-shaped tile loop 1.7x faster with the split's vector instructions included.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Bf3 { u32x4 h, m, l; };       // eight values as three bf16 terms, packed in k-slot order (slot 0 in the low half of word 0)
+
+// the three terms of two values, packed (first value in the low halves)
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
+  const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(m0 & 0xffff0000u), s1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+  ph = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  pm = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+  pl = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ Bf3 split3_8(const f32x4 a, const f32x4 b) {       // slots 0-3 = a, 4-7 = b
+  unsigned h[4], m[4], l[4];
+  split3_pk(a.x, a.y, h[0], m[0], l[0]);
+  split3_pk(a.z, a.w, h[1], m[1], l[1]);
+  split3_pk(b.x, b.y, h[2], m[2], l[2]);
+  split3_pk(b.z, b.w, h[3], m[3], l[3]);
+  Bf3 t;
+  t.h = u32x4{h[0], h[1], h[2], h[3]}; t.m = u32x4{m[0], m[1], m[2], m[3]}; t.l = u32x4{l[0], l[1], l[2], l[3]};
+  return t;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += A . B over 16 k-slots, the six products from the smallest to the largest.  ONE sequence, used by every kernel that has to
+// reproduce another's bits (the tie semantics compare recomputed values for equality).
+__device__ __forceinline__ f32x16 mma6(f32x16 acc, const Bf3& a, const Bf3& b) {
+  acc = mfma_bf16(a.l, b.h, acc);
+  acc = mfma_bf16(a.h, b.l, acc);
+  acc = mfma_bf16(a.m, b.m, acc);
+  acc = mfma_bf16(a.m, b.h, acc);
+  acc = mfma_bf16(a.h, b.m, acc);
+  acc = mfma_bf16(a.h, b.h, acc);
+  return acc;
+}
+
 // relu as a signed-integer max on the bit pattern: one VALU op.  fmaxf() of an MFMA result costs two (the
 // compiler canonicalises a possibly-signalling NaN first); negative floats are negative integers, -0 -> +0.
 __device__ __forceinline__ float relu_bits(float v) {

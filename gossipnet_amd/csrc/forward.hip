@@ -506,7 +506,23 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
 }
 
 constexpr int EFW_WAVES = 4;      // waves per workgroup; 3 workgroups per CU (launch bounds below)
-constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES * 2 * D_P) * sizeof(float);
+// the three terms of a lane's eight k-slots (16 bytes each, one term-stride apart)
+__device__ __forceinline__ Bf3 efw_w3(const unsigned* p, int tstride) {
+  Bf3 t;
+  t.h = *reinterpret_cast<const u32x4*>(p);
+  t.m = *reinterpret_cast<const u32x4*>(p + tstride);
+  t.l = *reinterpret_cast<const u32x4*>(p + 2 * tstride);
+  return t;
+}
+// LDS: the two weight matrices as THREE bf16 terms each (common.hpp: Bf3), stored in the k-slot order of their MFMA operand so that a lane
+// reads its eight slots of a k-step as one 16-byte word group:
+//   sWpT [term][f 64][EFW_LD1]   word h * 8 + j * 4 + w     = slots 2w, 2w+1 of k-step j (of 2), half h:  pf      = 16 j + 8 (s >> 2) + 4 h + (s & 3)
+//   sW2T [term][n 64][EFW_LD2]   word h * 16 + j * 4 + w    = slots 2w, 2w+1 of k-step j (of 4), half h:  feature = 32 (j >> 1) + 16 (j & 1) + 8 (s >> 2) + 4 h + (s & 3)
+// (the slot order is the order of a lane's layer-1 accumulators: register 8 (j & 1) + s of block j >> 1 -- no shuffle between the layers;
+//  row strides of 20 / 36 words: eight lanes' 16-byte reads cover the 32 banks once)
+constexpr int EFW_LD1 = 20, EFW_LD2 = 36;
+constexpr int EFW_T1 = D_P * EFW_LD1, EFW_T2 = D_P * EFW_LD2;         // words per term
+constexpr size_t kEdgeFwdWSmem = (size_t)(3 * EFW_T1 + 3 * EFW_T2 + EFW_WAVES * 2 * D_P) * sizeof(float);
 
 // TRAIN: record the arg-max edge of every (centre, column) for the sparse SegmentMax backward.  The pw_fc1
 // activations are NOT kept: the backward pass recomputes them for the ~26 % of the edges that carry gradient
@@ -515,9 +531,9 @@ constexpr size_t kEdgeFwdWSmem = (size_t)(D_P * E_LD1 + D_P * E_LD2 + EFW_WAVES 
 template <bool TRAIN, bool KEEP>
 __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sWp = smem;                           // [64][36]  Wp^T[f][pf]
-  float* sW2 = sWp + D_P * E_LD1;              // [64][68]  W2^T[j][f]
-  float* sHw = sW2 + D_P * E_LD2;              // per wave: rc rows of the tile's first two centres [2][64]
+  unsigned* sWpT = reinterpret_cast<unsigned*>(smem);      // Wp^T as three bf16 terms (layout above)
+  unsigned* sW2T = sWpT + 3 * EFW_T1;                      // W2^T likewise
+  float* sHw = smem + 3 * EFW_T1 + 3 * EFW_T2;             // per wave: rc rows of the tile's first two centres [2][64]
   GSTAMP(a, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
@@ -570,10 +586,24 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   }
   float4 rcAB = ldg4_b(a.rc, (unsigned)max((lane & 16) ? cB : cA, 0) * (D_P * 4u) + 16u * (lane & 15));
   __builtin_amdgcn_sched_barrier(0);
+  // weights -> three bf16 terms -> LDS in slot order: a thread's four consecutive k are slots 4 (g' & 1) .. + 3 of one (half, k-step)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sWp + (i >> 3) * E_LD1 + 4 * (i & 7)) = wst[j]; }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sW2 + (i >> 4) * E_LD2 + 4 * (i & 15)) = wst[2 + j]; }
+  for (int j = 0; j < 6; ++j) {
+    unsigned ph0, pm0, pl0, ph1, pm1, pl1;
+    split3_pk(wst[j].x, wst[j].y, ph0, pm0, pl0);
+    split3_pk(wst[j].z, wst[j].w, ph1, pm1, pl1);
+    unsigned* dst; int tstride;
+    if (j < 2) {
+      const int i = tid + 256 * j, f = i >> 3, g = i & 7, kq = g >> 1;                    // pf = 8 kq + 4 (g & 1) + q
+      dst = sWpT + f * EFW_LD1 + (g & 1) * 8 + (kq >> 1) * 4 + 2 * (kq & 1); tstride = EFW_T1;
+    } else {
+      const int i = tid + 256 * (j - 2), n = i >> 4, g = i & 15, kq = (g >> 1) & 3;        // feature = 32 (g >> 3) + 8 kq + 4 (g & 1) + q
+      dst = sW2T + n * EFW_LD2 + (g & 1) * 16 + (2 * (g >> 3) + (kq >> 1)) * 4 + 2 * (kq & 1); tstride = EFW_T2;
+    }
+    *reinterpret_cast<uint2*>(dst) = make_uint2(ph0, ph1);
+    *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(pm0, pm1);
+    *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(pl0, pl1);
+  }
   GSTAMP(a, 14);
   __syncthreads();
   GSTAMP(a, 1);
@@ -637,22 +667,13 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       }
     }
     __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note behind layer 2)
-    {
-      const float* b0 = sWp + col * E_LD1 + 4 * half;
-      const float* b1 = b0 + 32 * E_LD1;
+    {                                                   // layer 1 (transposed): A = Wp^T terms from LDS, B = the lane's P row, split here
+      const unsigned* w1p = sWpT + col * EFW_LD1 + half * 8;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x4 av = pa[k];
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * k);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * k);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.x, av.x, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.x, av.x, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.y, av.y, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.y, av.y, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.z, av.z, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.z, av.z, h1b, 0, 0, 0);
-        h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.w, av.w, h1a, 0, 0, 0);
-        h1b = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1.w, av.w, h1b, 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        const Bf3 pb = split3_8(pa[2 * j], pa[2 * j + 1]);
+        h1a = mma6(h1a, efw_w3(w1p + j * 4, EFW_T1), pb);
+        h1b = mma6(h1b, efw_w3(w1p + 32 * EFW_LD1 + j * 4, EFW_T1), pb);
       }
     }
     // ---- prefetch for the next tile: P rows, neighbour rows, the first two centre rows
@@ -682,34 +703,15 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       }
     }
     f32x16 h2a = zero16(), h2b = zero16();
-    {                                                   // layer 2: A = the h1^T registers, B = W2^T from LDS
-      const float* b0 = sW2 + col * E_LD2 + 4 * half;
-      const float* b1 = b0 + 32 * E_LD2;
+    {                                                   // layer 2: A = the h1^T registers (split per k-step), B = W2^T terms from LDS
+      const unsigned* w2p = sW2T + col * EFW_LD2 + half * 16;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * g);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * g);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 0], bv0.x, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 0], bv1.x, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 1], bv0.y, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 1], bv1.y, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 2], bv0.z, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 2], bv1.z, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 3], bv0.w, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[4 * g + 3], bv1.w, h2b, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 32 + 8 * g);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 32 + 8 * g);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 0], bv0.x, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 0], bv1.x, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 1], bv0.y, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 1], bv1.y, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 2], bv0.z, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 2], bv1.z, h2b, 0, 0, 0);
-        h2a = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 3], bv0.w, h2a, 0, 0, 0);
-        h2b = __builtin_amdgcn_mfma_f32_32x32x2f32(h1b[4 * g + 3], bv1.w, h2b, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const f32x16& hs = j < 2 ? h1a : h1b;
+        const int r0 = 8 * (j & 1);
+        const Bf3 ha = split3_8(f32x4{hs[r0], hs[r0 + 1], hs[r0 + 2], hs[r0 + 3]}, f32x4{hs[r0 + 4], hs[r0 + 5], hs[r0 + 6], hs[r0 + 7]});
+        h2a = mma6(h2a, ha, efw_w3(w2p + j * 4, EFW_T2));
+        h2b = mma6(h2b, ha, efw_w3(w2p + 32 * EFW_LD2 + j * 4, EFW_T2));
       }
     }
     // The segment bookkeeping (and the top of the next tile, up to its first MFMA) runs at a raised wave priority: the three

@@ -49,11 +49,14 @@ KINK = 2e-6       # a mask may differ from the oracle's own only where the oracl
 # fma chain with the bias added last to tc[c] + tn[n] + a K = 8 MFMA product (another rounding order: more units of the 0.01-bias
 # cases land within 1e-7 of their kink on the other side); round 5's pw_fwd2 keeps that order for fc1 and changes fc2 / fc3's
 # (bias added to the finished sum, eight K = 32 partial sums for fc3): the floors held.  The count is a REGRESSION GUARD for "most
-# seeds need no pinning at all"; the acceptance criteria are the two asserts on every seed -- worst kink distance <= KINK and
+# seeds need no pinning at all"; round 5's edge_fwd_w forms its fp32 products as six bf16 products of three-term splits (another
+# rounding of the same sums): measured 6 6 6 6 5 6 6 5 5 6 4 5 4 5 4 4 in the order of the table -- three floors went UP (64,80,1,.01: 3 -> 4;
+# 64,80,2,.01: 2 -> 3; 200,1,1,.01: 2 -> 3), two down (64,80,2,.5: 5 -> 4; 150,80,3,.5: 5 -> 3), worst kink distance 2.4e-7 as before.
+# The acceptance criteria are the two asserts on every seed -- worst kink distance <= KINK and
 # pinned gradients <= PINNED -- which no kernel change has ever loosened.
 KINK_FREE_MIN = {(6, 1, 1, 0.01): 5, (6, 1, 1, 0.5): 5, (20, 1, 1, 0.01): 5, (20, 1, 1, 0.5): 5, (33, 1, 2, 0.01): 4, (33, 1, 2, 0.5): 5,
-                 (64, 1, 2, 0.01): 5, (64, 1, 2, 0.5): 4, (64, 80, 1, 0.01): 3, (64, 80, 1, 0.5): 5, (64, 80, 2, 0.01): 2,
-                 (64, 80, 2, 0.5): 5, (200, 1, 1, 0.01): 2, (200, 1, 1, 0.5): 4, (150, 80, 3, 0.01): 3, (150, 80, 3, 0.5): 5}
+                 (64, 1, 2, 0.01): 5, (64, 1, 2, 0.5): 4, (64, 80, 1, 0.01): 4, (64, 80, 1, 0.5): 5, (64, 80, 2, 0.01): 3,
+                 (64, 80, 2, 0.5): 4, (200, 1, 1, 0.01): 3, (200, 1, 1, 0.5): 4, (150, 80, 3, 0.01): 3, (150, 80, 3, 0.5): 3}
 
 
 def kink_report(net, ref, image=None):
