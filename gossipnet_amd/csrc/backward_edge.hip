@@ -15,12 +15,12 @@
 //                   all blocks in one launch each; the OR over the blocks gives the rows of the pw-MLP backward)
 //   winner_positions  list position of every (detection, column)'s arg-max edge
 //   edge_bwd_w      every wave owns whole 32-winner tiles, no workgroup barriers in the tile loop:
-//                     h1   = relu(P.Wp + rc[c] + rn[n])   recomputed (32 MFMAs) -- the forward pass keeps no
+//                     h1   = relu(P.Wp + rc[c] + rn[n])   recomputed with edge_fwd_w's sequence (24 bf16 MFMAs on split operands) -- the forward pass keeps no
 //                            per-edge activations (16 x 0.37 GB of stores and 5.9 GB of workspace gone)
 //                     dW2 += d_pc[c][j] * h1[arg(c,j)]    per (detection, column), lane = column: 64 FMAs
 //                     g1   = (h1 > 0) * (d h2 . W2^T)     64 MFMAs, d h2 built in A-operand registers
 //                     dP   = g1 . Wp^T, dWp += P^T . g1   (32 + 32 MFMAs)
-//                   160 MFMAs per 32 rows instead of 224 for the dense-on-winner-rows formulation.
+//                   24 bf16 + 128 fp32 MFMAs per 32 rows (160 in the fp32 formulation, 224 for the dense-on-winner-rows one).
 //   (d_rc / d_rn -- centre sums over a contiguous range of the compact g1 rows, reversed-pair sums -- are taken
 //   inside the next node kernel, backward.hip blk_bwd_node)
 // No float atomics, static work assignment: gradients stay bitwise reproducible.
@@ -430,7 +430,7 @@ constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_P * LD64 + EBW_WAVES * 
 
 // Every wave owns whole 32-winner tiles of the block's winner list (rows sorted by centre), no workgroup barrier
 // in the tile loop.  Per tile:
-//   h1   = relu(P . Wp + (rc[c] + rn[n]))            32 MFMAs, the forward kernel's operation sequence
+//   h1   = relu(P . Wp + (rc[c] + rn[n]))            24 bf16 MFMAs, the forward kernel's operation sequence (split operands, common.hpp: mma6)
 //   per detection (segment of rows) of the tile, LANE = COLUMN j of the detection:
 //     row_j = apos[c][j] - first list position of the tile;  v_j = d_pc[c][j]  (0 when the winner is not in the tile)
 //     dW2[:, j] += v_j * h1[row_j][:]                64 FMAs on 16 gathered LDS quads, accumulators = registers

@@ -484,8 +484,10 @@ struct EdgeFwdArgs {
   GNET_TRACE_FIELD
 };
 
-// edge_fwd_w: every wave owns whole 32-edge x 64-column tiles (96 MFMAs per tile), no workgroup barriers in
-// the tile loop (h1 goes through a wave-private LDS tile), all gathers prefetched one tile ahead.
+// edge_fwd_w: every wave owns whole 32-edge x 64-column tiles, no workgroup barriers in the tile loop, all gathers prefetched one
+// tile ahead.  Its fp32 products are formed on the bf16 pipe: every operand as three bf16 terms (exact), six products per k-step of 16
+// with fp32 accumulation (common.hpp: split3_8 / mma6) -- 72 v_mfma_f32_32x32x16_bf16 per tile for the 96 v_mfma_f32_32x32x2_f32 of the
+// fp32 formulation (12 288 FLOP per edge), the fp32 MFMA's error against fp64 (DESIGN.md lesson 64).
 // Segment handling is WAVE-UNIFORM: the rows of a tile are sorted by centre, a ballot yields the segment
 // heads, and per segment the wave reduces (max, tie count) over its rows, folds the two half-waves with
 // one cross-lane exchange, and flushes a finished centre ONCE -- by a plain 512-byte store when all of
@@ -609,13 +611,12 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   GSTAMP(a, 1);
   if (!have_tiles) return;
   const int e_begin = t0 * 32, e_end = min(a.n_edge, t1 * 32);         // this wave's edge range
-  // The fp32 MFMA runs on the SIMD's FP32 lanes, i.e. it does NOT overlap with VALU work (measured:
-  // tools/mfma_valu_overlap.hip) -- every vector instruction in this loop is paid in MFMA time.  Hence:
+  // Vector instructions are paid beside the MFMA stream (the fp32 MFMA runs on the SIMD's FP32 lanes: tools/mfma_valu_overlap.hip; on
+  // the bf16 pipe the kernel is bound by them: 8 per MFMA).  Hence:
   //   * LAYER 1 IS COMPUTED TRANSPOSED: h1^T[f][edge] = Wp^T . P^T (the MFMA's operands swapped), so that its
   //     accumulators -- lane = edge, registers = features 8 g + 4 half + q -- ARE the A operand of layer 2
-  //     (lane = row, 4 consecutive k per 16-byte group: the k pairing of mma_abt).  No LDS round trip, no
-  //     barrier and no layout shuffle between the two layers; every element is the same chain of products in the
-  //     same order as before (bit-identical h1 and h2);
+  //     (a k-step's 16 slots may be ANY 16 features as long as both operands agree: the slot order is the register order).  No LDS
+  //     round trip, no barrier and no layout shuffle between the two layers;
   //   * the accumulators start from rc[c] + rn[n] read as the lane's OWN rows (eight 16-byte gathers of rn per
   //     lane and tile instead of 32 4-byte ones; rc rows of the tile's first two centres go through 512 bytes of
   //     LDS and come back as broadcast reads); self pairs and the edge tail are resolved once per batch into
