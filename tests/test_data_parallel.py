@@ -86,3 +86,25 @@ def test_rccl_log_parser(tmp_path):
     assert r["rccl_ranks_seen"] == [{"rank": 3, "nranks": 8}] and r["init_complete"] and r["bus_ids"] == ["busId dc000"]
     assert r["version"].startswith("RCCL version") and len(r["rings"]) == 2
     assert "note" in bench.rccl_evidence(None) and "note" in bench.rccl_evidence(str(tmp_path / "none.%p.log"))
+
+
+def test_bench_prices_the_two_mfma_pipes():
+    """bench.py's accounting of MFMA work: fp32 MFMAs against 157.3 TFLOP/s, bf16 MFMAs against 2516.6, and the FLOPs of a kernel's
+    fp32 formulation beside them (edge_fwd_w: 72 bf16 MFMAs of 32x32x16 stand for 96 fp32 MFMAs of 32x32x2 per 32-edge tile)."""
+    import bench
+    E, N, W, R = 32 * 1000, 2000, 32 * 200, 32 * 700
+    f32, bf16 = bench.executed_mfma_flops("edge_fwd", E, N, W, R)
+    assert f32 == 0.0 and bf16 == 72 * 32768.0 * 1000
+    assert bench.fp32_equivalent_flops("edge_fwd", E, N, W, R) == 96 * 4096.0 * 1000 == 12288.0 * E
+    f32, bf16 = bench.executed_mfma_flops("edge_bwd", E, N, W, R)
+    assert (f32, bf16) == (128 * 4096.0 * 200, 24 * 32768.0 * 200)
+    assert bench.fp32_equivalent_flops("edge_bwd", E, N, W, R) == 160 * 4096.0 * 200
+    # a pure fp32 kernel: its formulation IS what it issues
+    f32, bf16 = bench.executed_mfma_flops("pw_bwd_main", E, N, W, R)
+    assert bf16 == 0.0 and bench.fp32_equivalent_flops("pw_bwd_main", E, N, W, R) == f32 == 294912.0 * R
+    # pipe time: one second of each pipe's peak is one second
+    assert abs(bench.pipe_seconds((bench.FP32_MFMA_PEAK_TFLOPS * 1e12, 0.0)) - 1.0) < 1e-12
+    assert abs(bench.pipe_seconds((0.0, bench.BF16_MFMA_PEAK_TFLOPS * 1e12)) - 1.0) < 1e-12
+    # 72 bf16 MFMAs take 72 x 32 cycles where 96 fp32 MFMAs took 96 x 64: the peaks are 16 x apart per FLOP
+    assert abs(bench.BF16_MFMA_PEAK_TFLOPS / bench.FP32_MFMA_PEAK_TFLOPS - 16.0) < 0.01
+    assert bench.executed_mfma_flops("graph", E, N, W, R) is None and bench.fp32_equivalent_flops("graph", E, N, W, R) is None
