@@ -3,9 +3,19 @@
 //   mode 4: 8-wave workgroups, waves 0-3 MFMA only, waves 4-7 VALU only (two waves per SIMD)
 //   mode 5: 8-wave workgroups, every wave alternates a pure MFMA phase and a pure VALU phase
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o gpurun_out/overlap
+//        (-DBF16PIPE: the same with v_mfma_f32_32x32x16_bf16, 32 cycles, in place of the fp32 MFMA's 64)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef BF16PIPE
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa), __builtin_bit_cast(bf16x8, qb), acc_, 0, 0, 0)
+#define MFMA_CYCLES 32.0
+#else
+#define MFMA(acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc_, 0, 0, 0)
+#define MFMA_CYCLES 64.0
+#endif
 
 #define VALU8(x) \
   asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n" \
@@ -20,6 +30,9 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters, int mode, lo
   float x[8];
   for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
   const float a = 0.999f, b = 0.001f;
+#ifdef BF16PIPE
+  const u32x4 qa = {0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u + threadIdx.x}, qb = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#endif
   const int wave = threadIdx.x >> 6;
   const bool split = mode == 4;
   const bool do_m = mode == 1 || mode == 3 || (split && wave < 4);
@@ -27,7 +40,7 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters, int mode, lo
   if (mode == 5) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int j = 0; j < NM; ++j) { acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0); }
+      for (int j = 0; j < NM; ++j) { MFMA(acc0); }
 #pragma unroll
       for (int j = 0; j < NV; ++j) { VALU8(x); }
     }
@@ -35,7 +48,7 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters, int mode, lo
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int j = 0; j < NM; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        MFMA(acc0);
 #pragma unroll
         for (int q = 0; q < NV / NM; ++q) { VALU8(x); }
       }
@@ -43,7 +56,7 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters, int mode, lo
   } else if (do_m) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int j = 0; j < NM; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+      for (int j = 0; j < NM; ++j) MFMA(acc0);
     }
   } else if (do_v) {
     for (int it = 0; it < iters; ++it) {
@@ -71,7 +84,7 @@ void run(const char* name, int mode, int threads, float* out) {
   long long th = 0; hipMemcpy(&th, ticks, 8, hipMemcpyDeviceToHost);
   // per wave per iteration: NM MFMAs (64 cycles each), NV*8 VALU (4 cycles each)
   printf("%-46s NM=%2d NV8=%2d threads=%d  %.3f ms  -> %.0f ns/iter, %.0f s_memtime ticks/iter (MFMA alone %.0f cyc)\n", name, NM, NV, threads, ms,
-         ms * 1e6 / iters, (double)th / iters, NM * 64.0);
+         ms * 1e6 / iters, (double)th / iters, NM * MFMA_CYCLES);
 }
 
 int main() {
