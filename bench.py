@@ -195,7 +195,7 @@ def cpu_baseline(make, num_classes, num_blocks, budget_s):
             "runs": runs, "cpu": cpu}
 
 
-def rccl_evidence(log_pattern):
+def rccl_evidence(log_pattern, remove=False):
     """What RCCL itself logged about this rank's communicator (NCCL_DEBUG=INFO, INIT / GRAPH subsystems, written to
     NCCL_DEBUG_FILE): the rank / world size / device / bus id it reports, the library version line, the ring or tree lines."""
     import glob
@@ -207,6 +207,8 @@ def rccl_evidence(log_pattern):
     for f in files:
         try:
             text += open(f, errors="replace").read()
+            if remove:                   # a log this run created in the temp directory: parsed once, not left behind
+                os.remove(f)
         except OSError:
             pass
     if not text:
@@ -315,7 +317,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    rccl_log = None
+    rccl_log, rccl_log_own = None, False
     # (GNET_BENCH_FORCE_DIST=1: a process group even for one rank -- the N > 1 code path, RCCL included, exercised on a one-GPU box)
     force_dist = bool(os.environ.get("GNET_BENCH_FORCE_DIST")) and "RANK" in os.environ
     if world > 1 or force_dist:
@@ -325,8 +327,13 @@ def main():
             # self-evidencing N > 1 runs: RCCL's own INIT log of this rank (ranks / devices / rings it set up) goes to a file that
             # rank 0 parses into `distributed.rccl_*` below
             import tempfile
-            os.environ["NCCL_DEBUG"] = "INFO"            # (overrides the image's NCCL_DEBUG=VERSION; the log goes to the file below, not to stdout)
-            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH"
+            # A caller's own NCCL_DEBUG_FILE / NCCL_DEBUG_SUBSYS are respected, and so is an NCCL_DEBUG the caller chose; only the
+            # image's default NCCL_DEBUG=VERSION (or none) is raised to INFO -- the log goes to the file below, not to stdout --
+            # unless GNET_BENCH_KEEP_NCCL_DEBUG=1 says to leave the variable alone (then `distributed.rccl` may have nothing to parse).
+            if not os.environ.get("GNET_BENCH_KEEP_NCCL_DEBUG") and os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN", ""):
+                os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            rccl_log_own = "NCCL_DEBUG_FILE" not in os.environ         # a log this run created (rank 0 removes it once parsed)
             rccl_log = os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(tempfile.gettempdir(), "gnet_rccl_%d.%%p.log" % os.getpid()))
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=dev)
@@ -657,7 +664,7 @@ def main():
                                                 % (net.params.numel(), net.params.numel() * 4 / 1e6),
                                   "allreduce_us_rank0": round(ar_us, 1) if ar_us is not None else None, "allreduce_samples": ar_n,
                                   "allreduce_us_max_over_ranks": max(r_["allreduce_us"] for r_ in per_rank),
-                                  "rccl": rccl_evidence(rccl_log),
+                                  "rccl": rccl_evidence(rccl_log, remove=rccl_log_own),
                                   "hsa_ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(gen, args.classes, args.blocks, args.cpu_seconds)

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 from .build import LIB as LIB_PATH     # libgossipnet_hip.so (a GNET_TRACE / GNET_EXTRA_FLAGS measurement process: its own probe library)
 GNET_MAX_BLOCKS = 64
-ABI_VERSION = 6          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
+ABI_VERSION = 7          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 _ERR = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported configuration",
@@ -60,7 +60,7 @@ EXPORTS = ["gnet_param_count", "gnet_graph_count", "gnet_graph_fill", "gnet_grap
            "gnet_forward", "gnet_loss", "gnet_match_prepare", "gnet_backward", "gnet_backward_prepare", "det_matching_workspace_bytes", "det_matching_f32",
            "roi_pool_fwd_f32", "roi_pool_bwd_f32", "roi_pool_bwd_atomic_f32", "gnet_version", "gnet_profiler_create", "gnet_profiler_read",
            "gnet_profiler_destroy", "gnet_profiler_set_stride", "gnet_profiler_begin", "gnet_profiler_end", "gnet_adam_step", "gnet_momentum_step", "gnet_clip_by_norm",
-           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou", "gnet_abi_version", "gnet_abi_sizes"]
+           "gnet_fc_workspace_bytes", "gnet_fc_forward", "gnet_fc_backward", "gnet_box_iou", "gnet_debug_gemm", "gnet_abi_version", "gnet_abi_sizes"]
 
 KCLASSES = ["graph", "pack", "pw_fwd", "node_fwd", "edge_fwd", "loss", "head_bwd", "winner_lists", "edge_bwd", "gather_winners",
             "node_bwd", "pw_bwd_main", "pw_w1_nodesums", "pw_w1_classrows", "reduce_partials", "edge_geometry"]
@@ -105,6 +105,9 @@ def load():
         # measurement only (A/B of two builds on one box, tools/): load exactly this file, no source-hash check, no rebuild -- the
         # ABI guard below still applies
         LIB_PATH = os.environ["GNET_LIB_AB"]
+        import warnings
+        warnings.warn("GNET_LIB_AB is set: loading %s WITHOUT the source-hash check (A/B measurement only -- results of this "
+                      "process are not those of the library the tree builds)" % LIB_PATH)
         import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         check_abi(lib)
@@ -197,6 +200,8 @@ def _bind(lib):
     lib.gnet_fc_backward.argtypes = [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp, vp, vp, vp, sz, vp]
     lib.gnet_box_iou.restype = C.c_int
     lib.gnet_box_iou.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]
+    lib.gnet_debug_gemm.restype = C.c_int
+    lib.gnet_debug_gemm.argtypes = [vp, vp, i64, i64, i64, C.c_int, vp, vp, vp]
     lib.gnet_version.restype = C.c_char_p
     lib.gnet_version.argtypes = []
     _lib = lib

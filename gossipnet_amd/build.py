@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 # written to -- and, by a process with the same environment, loaded from -- a library of their own
 PROBE_BUILD = bool(os.environ.get("GNET_EXTRA_FLAGS") or os.environ.get("GNET_TRACE"))
 LIB = os.path.join(HERE, "libgossipnet_hip_probe.so" if PROBE_BUILD else "libgossipnet_hip.so")
-SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "fc.hip", "plan.hip"]
+SOURCES = ["graph.hip", "forward.hip", "loss.hip", "backward.hip", "backward_edge.hip", "roi_pool.hip", "optim.hip", "fc.hip", "plan.hip", "debug.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 if os.environ.get("GNET_EXTRA_FLAGS"):    # measurement builds only (probe variants of a kernel: tools/); never shipped

@@ -20,10 +20,10 @@ def get_class_counts(imdb):
         if 'gt_classes' in roi:
             gt = np.asarray(roi['gt_classes']).reshape(-1).astype(np.int64)
             num_pos = gt.size
-            if gt.size and (gt.min() < 0 or gt.max() >= n):
-                # the reference's loop `freq[cls] += 1` (imdb/tools.py:118-120) raises for a class outside the table
-                raise IndexError("gt_classes outside [0, %d]: %d .. %d" % (n - 1, int(gt.min()), int(gt.max())))
-            freq += np.bincount(gt, minlength=n)
+            if gt.size and (gt.min() < -n or gt.max() >= n):
+                # the reference's loop `freq[cls] += 1` (imdb/tools.py:118-120) raises for a class outside [-n, n) ...
+                raise IndexError("gt_classes outside [%d, %d]: %d .. %d" % (-n, n - 1, int(gt.min()), int(gt.max())))
+            np.add.at(freq, gt, 1)        # ... and wraps a negative class the numpy way, like `freq[cls] += 1` does
         if 'det_classes' in roi:
             freq[0] += max(0, int(np.asarray(roi['det_classes']).size) - num_pos)
     return freq

@@ -91,18 +91,19 @@ def cfg_from_file(filename, strict=False):
     subsystems (imdb names, detector, save_iter ...) are ignored unless strict=True."""
     with open(filename, "r") as f:
         y = yaml.safe_load(f)
+    _merge_a_into_b(_prune(y, cfg, strict), cfg)
 
-    def prune(a, b):
-        out = {}
-        for k, v in a.items():
-            if k not in b:
-                if strict:
-                    raise KeyError("{} is not a valid config key".format(k))
-                continue
-            out[k] = prune(v, b[k]) if isinstance(v, dict) and isinstance(b[k], dict) else v
-        return out
 
-    _merge_a_into_b(prune(y, cfg), cfg)
+def _prune(a, b, strict=False):
+    """The part of a (a loaded conf.yaml) whose keys exist in b (the cfg of this build)."""
+    out = {}
+    for k, v in a.items():
+        if k not in b:
+            if strict:
+                raise KeyError("{} is not a valid config key".format(k))
+            continue
+        out[k] = _prune(v, b[k], strict) if isinstance(v, dict) and isinstance(b[k], dict) else v
+    return out
 
 
 def reset_cfg():
@@ -112,24 +113,35 @@ def reset_cfg():
     cfg.update(d)
 
 
-# the Gnet hyper-parameters the two shipped experiments set in their conf.yaml (experiments/coco_multiclass/conf.yaml:18-24,
-# experiments/coco_person/conf.yaml:1-6) -- what a run started with `cfg_from_file(experiments/<name>/conf.yaml)` sees
+# every key the two shipped experiments set in their conf.yaml (experiments/coco_multiclass/conf.yaml:1-24,
+# experiments/coco_person/conf.yaml:1-22), values as written there -- what a run started with
+# `cfg_from_file(experiments/<name>/conf.yaml)` sees on top of the defaults (keys that only steer out-of-scope subsystems --
+# imdb / detector names, val_iter, save_iter, only_class -- are dropped by the same pruning cfg_from_file applies)
 EXPERIMENTS = {
-    "coco_multiclass": {"gnet": {"num_pwfeat_fc": 3, "pwfeat_narrow_dim": 32, "bias_const_init": 0.01, "imfeat_dim": 1024,
-                                 "imfeats": False, "neighbor_feats": False},
-                        "train": {"pos_weight": 0.3, "max_num_detections": 600}},
-    "coco_person": {"gnet": {"num_pwfeat_fc": 3, "pwfeat_narrow_dim": 32, "bias_const_init": 0.1, "num_blocks": 1,
-                             "neighbor_feats": False},
-                    "train": {"pos_weight": 0.1, "max_num_detections": 600}},
+    "coco_multiclass": {"train": {"optimizer": "adam", "weight_decay": 0.0005, "num_iter": 2000000,
+                                  "lr_multi_step": [[800000, 0.0001], [2000000, 0.00001]], "detector": "FRCN_train",
+                                  "imdb": "coco_2014_train", "val_imdb": "coco_2014_minival", "val_iter": 20000, "save_iter": 20000,
+                                  "max_num_detections": 600, "pos_weight": 0.3},
+                        "gnet": {"imfeats": False, "neighbor_feats": False, "num_pwfeat_fc": 3, "bias_const_init": 0.01,
+                                 "imfeat_dim": 1024, "pwfeat_narrow_dim": 32}},
+    "coco_person": {"gnet": {"bias_const_init": 0.1, "neighbor_feats": False, "num_blocks": 1, "num_pwfeat_fc": 3,
+                             "pwfeat_narrow_dim": 32},
+                    "random_seed": 42,
+                    "train": {"detector": "FRCN_train", "imdb": "coco_2014_train", "lr_multi_step": [[1000000, 0.0001], [2000000, 1.0e-05]],
+                              "max_num_detections": 600, "num_iter": 2000000, "only_class": "person", "optimizer": "adam",
+                              "pos_weight": 0.1, "save_iter": 20000, "val_imdb": "coco_2014_minival", "val_iter": 20000,
+                              "weight_decay": 0.0005}},
 }
 
 
 def experiment_cfg(name="coco_multiclass", **gnet_overrides):
     """reset_cfg() + the overrides of a shipped experiment's conf.yaml (+ cfg.gnet overrides of the caller): the configuration
     BASELINE.json's numbers are quoted on.  Tests, bench.py and the tools start from here; `cfg` itself starts from the
-    reference's defaults, as `from nms_net import cfg` does."""
+    reference's defaults, as `from nms_net import cfg` does (num_pwfeat_fc = 0, pwfeat_narrow_dim = 64, bias 0.0 -- a parameter
+    layout WITHOUT the pairwise-feature MLP: a checkpoint of one of the shipped experiments needs experiment_cfg(<its name>) or
+    cfg_from_file(<its conf.yaml>) before the Gnet is built, as with the reference)."""
     reset_cfg()
-    _merge_a_into_b(EXPERIMENTS[name], cfg)
+    _merge_a_into_b(_prune(EXPERIMENTS[name], cfg), cfg)
     for k, v in gnet_overrides.items():
         if k not in cfg.gnet:
             raise KeyError("{} is not a valid cfg.gnet key".format(k))

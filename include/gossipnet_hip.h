@@ -309,6 +309,15 @@ int gnet_profiler_destroy(void* profiler);
 int gnet_profiler_begin(void* profiler, int32_t cls, gnet_stream_t stream);
 int gnet_profiler_end(void* profiler, int32_t idx, gnet_stream_t stream);
 
+/* ---- numerics probe of the FC kernels' product arithmetic (tests only; csrc/debug.hip) -------------------
+ * c[M,N] = a[M,K] . b[K,N], row-major fp32, M and N multiples of 32, K a multiple of 16, a 16-byte aligned.
+ * mode 0: every fp32 product as the six bf16 products of exact three-term splits, fp32 accumulation -- the library's own
+ * split3 / mma6 (csrc/common.hpp), i.e. the arithmetic of edge_fwd_w, pw_fwd2, pw_bwd_main; mode 1: v_mfma_f32_32x32x2_f32.
+ * a_terms (optional, mode 0): [3][M,K] fp32 = the hi / mid / lo bf16 terms of a, widened (hi + mid + lo == a exactly).
+ * Operands must be finite (+/-inf splits into inf - inf = NaN). */
+int gnet_debug_gemm(const float* a, const float* b, int64_t M, int64_t K, int64_t N, int mode, float* c,
+                    float* a_terms, gnet_stream_t stream);
+
 /* Version / build info string (static storage). */
 const char* gnet_version(void);
 
@@ -321,7 +330,7 @@ const char* gnet_version(void);
  * offsetof(gnet_buffers, match_ws_bytes), offsetof(gnet_buffers, start_feat) and returns GNET_KCLASS_COUNT.
  * A binding compares both with its own mirror before the first call and refuses to go on when they differ
  * (a shifted gnet_buffers would hand the kernels wrong device pointers without any error). */
-#define GNET_ABI_VERSION 6
+#define GNET_ABI_VERSION 7
 int gnet_abi_version(void);
 int gnet_abi_sizes(size_t out[8]);
 

@@ -145,6 +145,27 @@ def test_reference_experiment_configs_load():
     experiment_cfg()
 
 
+def test_experiment_cfg_equals_the_reference_conf_files():
+    """experiment_cfg(<name>) == reset + cfg_from_file(the reference's experiments/<name>/conf.yaml), key for key (EXPERIMENTS
+    restates every key of the two files; this container has them, the GPU box does not: skipped there)."""
+    import copy
+    import os
+    from gossipnet_amd.config import cfg, cfg_from_file, experiment_cfg, reset_cfg
+    root = "/root/reference/experiments"
+    if not os.path.isdir(root):
+        pytest.skip("the reference tree is not on this machine")
+
+    def norm(d):
+        return {k: (norm(v) if isinstance(v, dict) else ([list(x) for x in v] if isinstance(v, (list, tuple)) else v)) for k, v in d.items()}
+    for name in ("coco_multiclass", "coco_person"):
+        experiment_cfg(name)
+        a = norm(copy.deepcopy(dict(cfg)))
+        reset_cfg()
+        cfg_from_file(os.path.join(root, name, "conf.yaml"))
+        assert a == norm(copy.deepcopy(dict(cfg))), name
+    experiment_cfg()
+
+
 def test_device_batch_offsets_on_cpu():
     from gossipnet_amd.network import DeviceBatch
     from gossipnet_amd.synthetic import make_image

@@ -87,6 +87,10 @@ def test_learning_rate_table_semantics():
     # stateless: a run resumed at iteration 3 is on the second rate at once
     assert LearningRate().get_lr(3) == 0.01
     experiment_cfg()
+    lr = LearningRate()          # the shipped experiment's table (experiments/coco_multiclass/conf.yaml:5)
+    assert lr.get_lr(800000) == 0.0001 and lr.get_lr(800001) == 0.00001 and lr.get_lr(10 ** 7) == 0.00001
+    from gossipnet_amd.config import reset_cfg
+    reset_cfg()
     lr = LearningRate()          # config.py default table
     assert lr.get_lr(10000) == 0.001 and lr.get_lr(10001) == 0.0001 and lr.get_lr(80001) == 1e-7 and lr.get_lr(10 ** 7) == 1e-7
 

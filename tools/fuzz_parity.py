@@ -1,7 +1,10 @@
 """Differential fuzz: the nasty-but-legal images of tools/fuzz.py, alone or two to four in a step, (sizes at the tile edges, duplicates, no / all-crowd / many
 ground-truth boxes, tied scores, everything-overlaps, no edges) at sizes the CPU oracle handles, compared with
 it the way tests/test_gpu_backward.py does -- neighbour indices / matching bit-exact, activations and loss <= 1e-5, masks
-within 2e-6 of a kink, gradients on the common piece <= 1e-5 (of the tensor's largest element + 0.05).   python tools/fuzz_parity.py [cases] [seed]"""
+within 2e-6 of a kink, gradients on the common piece <= 1e-5 (of the tensor's largest element + 0.05).  The bar is HARD for every
+step of more than four detections; a step of at most four (a tensor's largest gradient entry can be a cancelled sum there) may be
+settled by the one stated exception, oracle/pins.py fp64_rule: the last line prints FP64_SETTLED=<count>, and
+tools/final_validation.sh fails a run in which it exceeds FUZZ_FP64_MAX.   python tools/fuzz_parity.py [cases] [seed] [conf]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +12,7 @@ import torch
 from tests.util import make_pair, gpu_pins
 from oracle import gnet_oracle as go
 from tests.test_gpu_backward import check_outputs, pinned_errors, kink_report, KINK, PINNED
+from oracle.pins import fp64_rule, TINY_STEP_DETS
 from gossipnet_amd.synthetic import make_image
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -122,9 +126,11 @@ for case in range(cases):
             gr = gsum[name].reshape(-1)
             pinned[name] = float(np.abs(g - gr).max() / (np.abs(gr).max() + 5e-2)) if gr.size else 0.0
         if max(pinned.values()) > PINNED:
-            # at the bar: is it the device, or what fp32 can resolve here?  (three overlapping detections: the head's gradients are sums
-            # with heavy cancellation.)  The fp64 twin of the oracle on the same piece decides: the device must be no further from it
-            # than twice the fp32 oracle itself is, and within 2 x the bar.
+            # above the bar: a failure -- unless the step is TINY (<= 4 detections: the head's gradients are sums with heavy
+            # cancellation, one ulp of a summand is 1e-5 of the result) and the one stated exception holds (oracle/pins.py fp64_rule:
+            # device's error against the fp64 twin on the same piece <= the fp32 oracle's own + the bar)
+            n_step = sum(int(im["dets"].shape[0]) for im in imgs)
+            assert n_step <= TINY_STEP_DETS, ("pinned gradient above the bar in a step of %d detections" % n_step, max(pinned.items(), key=lambda kv: kv[1]))
             o64 = go.GnetOracle(NC, NB, params={k: v.detach().numpy() for k, v in orc.params.items()}, dtype=torch.float64,
                                 class_weights=orc.class_weights.numpy(), normalize_loss=orc.normalize_loss,
                                 pw_feat_multiplyer=orc.pw_feat_multiplyer, neighbor_feats=NF, num_pwfeat_fc=NFC)
@@ -135,12 +141,9 @@ for case in range(cases):
             for name, err in pinned.items():
                 if err <= PINNED:
                     continue
-                g = net.gradients[name].detach().cpu().numpy().reshape(-1).astype(np.float64)
-                r64, r32 = g64[name].reshape(-1), gsum[name].reshape(-1)
-                den = np.abs(r64).max() + 5e-2
-                e_dev, e_f32 = np.abs(g - r64).max() / den, np.abs(r32 - r64).max() / den
+                ok, e_dev, e_f32 = fp64_rule(net.gradients[name].detach().cpu().numpy(), gsum[name], g64[name], n_step, PINNED, floor=5e-2)
                 print("case %d %s: %s at %.2e of the fp32 oracle; against the fp64 twin: device %.2e, fp32 oracle %.2e" % (case, desc, name, err, e_dev, e_f32), flush=True)
-                assert e_dev <= 2.0 * e_f32 and err <= 2.0 * PINNED, (name, err, e_dev, e_f32)
+                assert ok, (name, err, e_dev, e_f32)
                 n_fp64 += 1
         worst_pin, worst_kink = max(worst_pin, max(pinned.values())), max(worst_kink, worst)
     except Exception as e:
@@ -149,4 +152,5 @@ for case in range(cases):
     if os.environ.get("FUZZ_VERBOSE"):
         print("case", case, desc, "E", int(net.num_edges), "pinned %.2e" % max(pinned.values()), max(pinned.items(), key=lambda kv: kv[1])[0], flush=True)
 print("parity fuzz: %d cases in %.1f s; worst gradient error on the common piece %.2e, worst kink distance %.2e%s"
-      % (cases, time.time() - t0, worst_pin, worst_kink, "; %d tensor(s) above the bar settled against the fp64 twin" % n_fp64 if n_fp64 else ""))
+      % (cases, time.time() - t0, worst_pin, worst_kink, "; %d tensor(s) of tiny steps settled against the fp64 twin" % n_fp64 if n_fp64 else "")
+      + "  FP64_SETTLED=%d" % n_fp64)
