@@ -424,13 +424,17 @@ def main():
         dist.all_reduce(et)
         e_total, dets_per_step = float(et[0].item()), int(et[1].item())
         # every rank's own edge count and step time (before the max): shows load imbalance directly
+        # (checksum of the bit patterns of the SUMMED gradient this rank holds after the last step's all-reduce: equal on every rank
+        # = the replicas would take the same optimizer step, bit for bit)
+        gsum = int(net.grads.view(torch.int32).to(torch.int64).sum().item()) & ((1 << 52) - 1)
         mine_t = torch.tensor([float(E), float(N_local), own_elapsed / args.steps * 1e3, float(dev_index), float(ar_us or 0.0),
-                               float(torch.cuda.get_device_properties(dev).pci_bus_id)],
+                               float(torch.cuda.get_device_properties(dev).pci_bus_id), float(len(images)), float(gsum)],
                               dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(allr, mine_t)
         per_rank = [{"rank": r_, "edges": int(v[0].item()), "dets": int(v[1].item()), "ms_per_step": round(float(v[2].item()), 4),
-                     "device_index": int(v[3].item()), "pci_bus_id": int(v[5].item()), "allreduce_us": round(float(v[4].item()), 1)}
+                     "device_index": int(v[3].item()), "pci_bus_id": int(v[5].item()), "allreduce_us": round(float(v[4].item()), 1),
+                     "images": int(v[6].item()), "summed_grad_checksum": int(v[7].item())}
                     for r_, v in enumerate(allr)]
     else:
         e_total, dets_per_step = float(E), N_local

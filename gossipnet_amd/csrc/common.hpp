@@ -157,7 +157,23 @@ static inline ParamLayout make_layout(const gnet_config* c) {
 // rows | zeros | centre | neighbour, forward.hip pack_transpose) lives behind the parameters' copies.
 constexpr int64_t W1T_FLOATS = (int64_t)D_P * (D_E + 2 * D_R);
 static inline int64_t packed_w1_off(const ParamLayout& L, int b) { return L.raw ? L.total + (int64_t)(b - 1) * W1T_FLOATS : L.blk[b].w1; }
-static inline int64_t packed_floats(const ParamLayout& L, int nblocks) { return L.total + (L.raw ? (int64_t)nblocks * W1T_FLOATS : 0); }
+// The pw-MLP's fc2 / fc3 weights as bf16 three-term MFMA operand fragments (forward.hip pack_pw_bf16; 32-bit words, every array
+// [term hi | mid | lo][wave 8][k-step][lane 64][4 words]: a lane's eight k-slots of a k-step of 16 = one 16-byte load), behind the
+// transposed copies, 16-byte aligned.  Only with a pw-MLP.
+//   W2A  pw_fwd3's fc2 (transposed: A = W2^T), 16 k-steps   W3B  pw_fwd3's fc3 (B = W3), 2 k-steps per wave
+//   W2D  pw_bwd_bf's d h1 = d2 . W2^T (B = W2^T), 16 k-steps   W3D  pw_bwd_bf's d2 = d3 . W3^T (B = W3^T), 2 k-steps
+constexpr int64_t PWBF_W2A = 0, PWBF_W2A_WORDS = 3ll * 8 * 16 * 64 * 4;
+constexpr int64_t PWBF_W3B = PWBF_W2A + PWBF_W2A_WORDS, PWBF_W3B_WORDS = 3ll * 8 * 2 * 64 * 4;
+constexpr int64_t PWBF_W2D = PWBF_W3B + PWBF_W3B_WORDS, PWBF_W2D_WORDS = PWBF_W2A_WORDS;
+constexpr int64_t PWBF_W3D = PWBF_W2D + PWBF_W2D_WORDS, PWBF_W3D_WORDS = PWBF_W3B_WORDS;
+constexpr int64_t PWBF_WORDS = PWBF_W3D + PWBF_W3D_WORDS;
+static inline int64_t packed_pwbf_off(const ParamLayout& L) { return (L.total + 3) & ~3ll; }
+static inline int64_t packed_floats(const ParamLayout& L, int nblocks) {
+  return L.raw ? L.total + (int64_t)nblocks * W1T_FLOATS : packed_pwbf_off(L) + PWBF_WORDS;
+}
+// feature (within a wave's 32) that k-slot t of the lane's eight holds in k-step q (0 / 1) of the wave's pair: the register order of
+// a 32x32 MFMA accumulator column -- crow(8 q + t, half) -- so that accumulators ARE operands (no shuffle between chained layers)
+__host__ __device__ __forceinline__ int frag_feat(int q, int half, int t) { return (t & 3) + 8 * (2 * q + (t >> 2)) + 4 * half; }
 
 // ---- geometry of the winner maps / lists of the backward edge stage (plan.hip, backward*.hip) ----------
 struct EdgeGeom {

@@ -12,6 +12,7 @@
 //                    + the per-node halves of pw_fc1 of block b+1; after the last block: head (:258-273)
 // All dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -96,6 +97,44 @@ __global__ void __launch_bounds__(256) pack_transpose(const float* __restrict__ 
     const int o = i / in, k = i - o * in;   // packed[o][k] = W[k][o]
     packed[off + i] = params[off + (long long)k * out + o];
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// pack_pw_bf16: the pw-MLP's fc2 / fc3 weights as bf16 three-term operand fragments (common.hpp PWBF_*): every fp32 weight is split
+// once per step -- hi, mid by truncation, lo the remainder: hi + mid + lo == w exactly (split3_pk) -- and stored where the lane that
+// multiplies by it finds its eight k-slots of a k-step as one 16-byte load.  One thread per (array, wave, k-step, lane, slot pair).
+__global__ void __launch_bounds__(256) pack_pw_bf16(const float* __restrict__ w2, const float* __restrict__ w3, unsigned* __restrict__ out) {
+  constexpr int N2 = 8 * 16 * 64 * 4, N3 = 8 * 2 * 64 * 4;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  float x0, x1;
+  unsigned* dst; int n;
+  if (i < 2 * N2) {
+    const bool dgrad = i >= N2;                  // W2D (backward: d h1 = d2 . W2^T) behind W2A (forward: h2^T = W2^T . h1^T)
+    if (dgrad) i -= N2;
+    const int p = i & 3, lane = (i >> 2) & 63, s_ = (i >> 8) & 15, w = i >> 12;
+    const int col = lane & 31, half = lane >> 5;
+    const int k0 = 32 * (s_ >> 1) + frag_feat(s_ & 1, half, 2 * p);          // (slot 2 p + 1 is the next feature)
+    if (!dgrad) { x0 = w2[(size_t)k0 * D_H + 32 * w + col]; x1 = w2[(size_t)(k0 + 1) * D_H + 32 * w + col]; }
+    else { x0 = w2[(size_t)(32 * w + col) * D_H + k0]; x1 = w2[(size_t)(32 * w + col) * D_H + k0 + 1]; }
+    dst = out + (dgrad ? PWBF_W2D : PWBF_W2A); n = N2;
+  } else if (i < 2 * N2 + 2 * N3) {
+    i -= 2 * N2;
+    const bool dgrad = i >= N3;                  // W3D (backward: d2 = d3 . W3^T, either orientation) behind W3B (forward: fc3)
+    if (dgrad) i -= N3;
+    const int p = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 1, w = i >> 9;
+    const int col = lane & 31, half = lane >> 5;
+    if (!dgrad) {
+      const int f0 = 32 * w + frag_feat(q, half, 2 * p);
+      x0 = w3[(size_t)f0 * D_E + col]; x1 = w3[(size_t)(f0 + 1) * D_E + col];
+    } else {
+      const int o0 = 16 * q + 8 * half + 2 * p;
+      x0 = w3[(size_t)(32 * w + col) * D_E + o0]; x1 = w3[(size_t)(32 * w + col) * D_E + o0 + 1];
+    }
+    dst = out + (dgrad ? PWBF_W3D : PWBF_W3B); n = N3;
+  } else return;
+  unsigned ph, pm, pl;
+  split3_pk(x0, x1, ph, pm, pl);
+  dst[i] = ph; dst[n + i] = pm; dst[2 * n + i] = pl;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -459,6 +498,246 @@ __global__ void __launch_bounds__(512) pw_fwd2(const PwFwdArgs a) {
 #undef PW2_FC1
 #undef PW2_HB
 #undef PW2_MMA4
+}
+
+// ------------------------------------------------------------------------------------------
+// pw_fwd3 (round 6): pw_fwd2 ON THE bf16 PIPE.  fc2 and fc3 form every fp32 product as six bf16 products of exact three-term
+// splits (common.hpp mma6: v_mfma_f32_32x32x16_bf16, fp32 accumulation, the fp32 MFMA's error against fp64 -- measured on this
+// kernel's own operands by tests/test_gpu_bf16x3.py): 96 + 12 MFMAs of 32 cycles per wave and tile where pw_fwd2 issues 128 + 16 of 64.
+// Same workgroup shape (one 8-wave workgroup per CU, wave w owns output features [32 w, 32 w + 32) of fc2, persistent over an
+// XCD-aware tile range, ONE LDS-only barrier per tile, the next tile's fc1 formed inside this tile's stream), and:
+//   * W2 as three bf16 terms is 192 registers per lane: the high and middle terms are RESIDENT (128 registers, loaded once per
+//     kernel from pack_pw_bf16's fragment-major copy), the low term -- one product of the six -- streams from L2 through a four-deep
+//     register ring (tools/pw_bf16x3_probe.hip: as fast as all three resident);
+//   * the h1 tile lives in LDS as three bf16 terms in FRAGMENT-MAJOR order [term][k-step 16][lane 64] x 16 bytes: fc1's
+//     accumulators (lane = edge, registers = features) are split in registers by the wave that formed them -- a k-step's slots are
+//     the register order of an accumulator column (frag_feat), as in edge_fwd_w -- and land as six 16-byte stores; every wave's B
+//     operand of k-step s is then ONE contiguous kilobyte per term: no swizzle, no padding, immediate offsets;
+//   * fc2 is still computed transposed, so its rectified accumulators are fc3's A operand after one more in-register split;
+//     fc3's B operand (the wave's 32 x 32 slice of W3, three terms) is re-requested late in every tile's stream;
+//   * fc1 itself stays on the fp32 MFMA (4 per tile): h1 is bit-identical to pw_fwd2's;
+//   * training: h1 and h2 leave straight from the accumulators as 16-byte pieces.
+// LDS: 2 x 48 KB of h1 terms + 2 x 32 KB of fc3 partial sums = 160 KB, all of it.
+// vmcnt is one in-order counter: a ring load issued behind a slow request (the table gathers, a store) returns behind it, so the
+// slow requests of a tile are issued together at two places of the stream and the ring is four k-steps (~1 us) deep.
+constexpr int PW3_TERM = 16 * 64 * 4;            // 32-bit words of one term of an h1 tile: [16 k-steps][64 lanes][4]
+constexpr int PW3_HW = 3 * PW3_TERM;             // one h1 tile (three terms): 48 KB
+constexpr size_t kPwFwd3Smem = (size_t)(2 * PW3_HW + 2 * PW2_PF) * 4;
+static_assert(kPwFwd3Smem == 160 * 1024, "pw_fwd3 uses the whole LDS of a CU");
+
+struct PwFwd3Args {
+  PwFwdArgs p;
+  const unsigned* wbf;     // pack_pw_bf16's arrays (common.hpp PWBF_*)
+};
+
+__device__ __forceinline__ u32x4 lds_q(const unsigned* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 ldg_q(const unsigned* __restrict__ ubase, unsigned byte_off) {
+  return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + byte_off);
+}
+
+template <bool TRAINING>
+__global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
+  const PwFwdArgs& a = aa.p;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem3[];
+  unsigned* sH = smem3;                                               // [2][3][16][64][4]
+  float* sP = reinterpret_cast<float*>(smem3 + 2 * PW3_HW);           // [2][8][32][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int nt = (a.n_edge + PW2_T - 1) / PW2_T, nwg = gridDim.x;
+  const int lb = (nwg & 7) == 0 ? (int)((blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int t0 = range_begin(lb, nt, nwg), t1 = range_begin(lb + 1, nt, nwg);
+  if (t0 >= t1) return;
+  const int last = a.n_edge - 1;
+
+  // ---- resident operands: the high and middle terms of the wave's 256 x 32 slice of W2 (A operand of the transposed product)
+  u32x4 wh[16], wm[16];
+  const unsigned* w2a = aa.wbf + PWBF_W2A + (size_t)wave * (16 * 64 * 4);
+  constexpr unsigned TERM2 = 8u * 16 * 64 * 4 * 4;                     // bytes between the terms of W2A
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) { wh[s_] = ldg_q(w2a + 256 * s_, 16u * lane); wm[s_] = ldg_q(w2a + TERM2 / 4 + 256 * s_, 16u * lane); }
+  // the low term's slice [16 k-steps][64 lanes] x 16 bytes and fc3's operand are read as (kernel-argument base, uniform) + (one lane
+  // offset that carries the wave's slice, made opaque once per tile: the compiler otherwise hoists one 64-bit lane address per
+  // k-step out of the loop and spills them)
+  const unsigned* w2lo = aa.wbf + PWBF_W2A + 2 * (8 * 16 * 64 * 4);
+  const unsigned* w3b = aa.wbf + PWBF_W3B;
+  constexpr unsigned TERM3 = 8u * 2 * 64 * 4 * 4;
+  unsigned ro = 16u * lane + (unsigned)wave * (16u * 64 * 16), ro3 = 16u * lane + (unsigned)wave * (2u * 64 * 16);
+  Bf3 w3q[2];
+  // fc2's bias rides in ONE more MFMA at the head of every tile's chain (sixteen registers of bias pieces do not fit beside the
+  // weights): A = the three terms of b2[32 wave + col] in k-slots 0-2 of the lower half-wave, B = 1.0 in those slots -- the
+  // accumulators start from hi + mid + lo = the bias, exactly
+  u32x4 biasA;
+  {
+    unsigned ph, pm, pl;
+    split3_pk(a.b2[32 * wave + col], 0.f, ph, pm, pl);
+    biasA = half ? u32x4{0u, 0u, 0u, 0u} : u32x4{(ph & 0xffffu) | (pm << 16), pl & 0xffffu, 0u, 0u};
+  }
+  const int geo_row0 = 2 * a.cprime;
+  float wgA[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int k = 4 * half + s_;
+    wgA[s_] = k < 7 ? a.w1[(size_t)(geo_row0 + k) * D_H + 32 * wave + col] : 0.f;
+  }
+  const int er = tid >> 4, j0 = (tid & 15) * 2;   // the (edge, output pair) of a tile this thread reduces
+  const float b3a = a.b3[j0], b3b = a.b3[j0 + 1];
+  unsigned fo = (unsigned)(32 * wave + 4 * half) * 4u;   // the lane's first feature piece in a table row (bytes)
+  unsigned pw_lo = (unsigned)(er * D_E + j0) * 4u;       // the thread's output pair inside a tile of pw
+  unsigned h_lo = (unsigned)(col * D_H + 4 * half) * 4u; // the lane's row and half inside a tile of h1 / h2
+  unsigned hmask = half ? 0u : 0xffffffffu;              // (the lower half-wave carries the bias slots)
+
+#define PW3_EDGE(u_) min(min((u_), nt - 1) * PW2_T + col, last)
+#define PW3_REQUEST(c_, n_)                                                                        \
+  do {                                                                                             \
+    const unsigned oc_ = (unsigned)(c_) * (D_H * 4u) + fo, on_ = (unsigned)(n_) * (D_H * 4u) + fo; \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) { tcv[g] = ldg4_b(a.tc, oc_ + 32u * g); tnv[g] = ldg4_b(a.tn, on_ + 32u * g); } \
+  } while (0)
+  // h1^T piece of this wave (fp32 MFMA, pw_fwd2's bits): table rows + the K = 8 geometry product, rectified; training: the fp32 rows
+  // leave as four 16-byte pieces; then the in-register split and six 16-byte LDS stores: k-steps 2 wave, 2 wave + 1 of the three terms
+#define PW3_FC1(dstH_, e0_)                                                                        \
+  do {                                                                                             \
+    f32x16 h_;                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
+      h_[4 * g + 0] = tcv[g].x + tnv[g].x; h_[4 * g + 1] = tcv[g].y + tnv[g].y;                    \
+      h_[4 * g + 2] = tcv[g].z + tnv[g].z; h_[4 * g + 3] = tcv[g].w + tnv[g].w;                    \
+    }                                                                                              \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[0], gv.x, h_, 0, 0, 0);                          \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[1], gv.y, h_, 0, 0, 0);                          \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gv.z, h_, 0, 0, 0);                          \
+    h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gv.w, h_, 0, 0, 0);                          \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) h_[r] = relu_bits(h_[r]);                       \
+    if (TRAINING) {                                                                                \
+      float* g_ = a.h1 + (size_t)(e0_) * D_H + 32 * wave;                                          \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) pw2_st4(g_, h_lo + 32u * g, make_float4(h_[4 * g], h_[4 * g + 1], h_[4 * g + 2], h_[4 * g + 3])); \
+    }                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                \
+      const Bf3 t_ = split3_8(f32x4{h_[8 * q], h_[8 * q + 1], h_[8 * q + 2], h_[8 * q + 3]},       \
+                              f32x4{h_[8 * q + 4], h_[8 * q + 5], h_[8 * q + 6], h_[8 * q + 7]});  \
+      unsigned* d_ = (dstH_) + ((2 * wave + q) * 64 + lane) * 4;                                   \
+      *reinterpret_cast<u32x4*>(d_) = t_.h;                                                        \
+      *reinterpret_cast<u32x4*>(d_ + PW3_TERM) = t_.m;                                             \
+      *reinterpret_cast<u32x4*>(d_ + 2 * PW3_TERM) = t_.l;                                         \
+    }                                                                                              \
+  } while (0)
+
+  // ---- front: the first tile's h1, the records of the second, the first four pieces of the low-term ring
+  float4 tcv[4], tnv[4];
+  f32x4 gv;
+  int c1, n1;
+  u32x4 ring[4];
+  {
+    const unsigned e = (unsigned)PW3_EDGE(t0);
+    const int c0 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e), n0 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e);
+    { const float4 g_ = ldg4_b(a.geo, 32u * e + 16u * half); gv = f32x4{g_.x, g_.y, g_.z, g_.w}; }
+    const unsigned e1 = (unsigned)PW3_EDGE(t0 + 1);
+    c1 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e1); n1 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e1);
+    PW3_REQUEST(c0, n0);
+    PW3_FC1(sH, t0 * PW2_T);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring[i] = ldg_q(w2lo, ro + 1024u * i);
+  }
+  pw2_barrier();
+
+  for (int t = t0, it = 0; t < t1; ++t, ++it) {
+    const int e0 = t * PW2_T;
+    const unsigned* Hc = sH + (it & 1) * PW3_HW + lane * 4;
+    unsigned* Hn = sH + ((it & 1) ^ 1) * PW3_HW;
+    float* Pc = sP + (it & 1) * PW2_PF;
+    const float* Pp = sP + ((it & 1) ^ 1) * PW2_PF;
+    int c2, n2;
+    // (lane offsets made opaque once per tile: what is derived from them stays inside the loop instead of being hoisted as 64-bit
+    // lane addresses -- and spilled: a scratch reload in this loop is a vmcnt(0), i.e. a drain of the ring)
+    asm volatile("" : "+v"(ro), "+v"(ro3), "+v"(fo), "+v"(pw_lo), "+v"(h_lo), "+v"(hmask));
+    // the h1 operand of a k-step: three 16-byte LDS reads; the high term (read by the first and the last product) is requested a
+    // whole k-step ahead, the low and the middle term into their own registers right behind the last product that reads them
+    u32x4 bh[2], bm, bl;
+    bh[0] = lds_q(Hc); bm = lds_q(Hc + PW3_TERM); bl = lds_q(Hc + 2 * PW3_TERM);
+    f32x16 acc;
+    {
+      const u32x4 ones = u32x4{hmask & 0x3f803f80u, hmask & 0x00003f80u, 0u, 0u};
+      acc = mfma_bf16(biasA, ones, zero16());
+    }
+    // ---- fc2: 16 k-steps of six MFMAs; the h1 operand one k-step ahead, the low weight term four; the rest of the tile's work between
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const u32x4 al = ring[s_ & 3];
+      ring[s_ & 3] = ldg_q(w2lo, ro + 1024u * ((s_ + 4) & 15));          // (the last four: the next tile's first four)
+      if (s_ == 0) {
+        // the slow requests of the tile's first half, together: the next tile's table rows and geometry, the records of the tile
+        // after it, the previous tile's fc3 (sum of the eight waves' partial sums, bias, ReLU, 8 bytes per thread; the first
+        // tile of the range has no predecessor: a slack row takes the store)
+        PW3_REQUEST(c1, n1);
+        const unsigned e1 = (unsigned)PW3_EDGE(t + 1);
+        { const float4 g_ = ldg4_b(a.geo, 32u * e1 + 16u * half); gv = f32x4{g_.x, g_.y, g_.z, g_.w}; }
+        const unsigned e2 = (unsigned)PW3_EDGE(t + 2);
+        c2 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * e2); n2 = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_n), 4u * e2);
+        const float* pp = Pp + er * D_E + j0;
+        float2 r_ = *reinterpret_cast<const float2*>(pp);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); r_.x += v.x; r_.y += v.y; }
+        const int ep = it > 0 ? e0 - PW2_T : a.n_edge + 32;
+        pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(r_.x + b3a, 0.f), fmaxf(r_.y + b3b, 0.f)));
+      }
+      // (s_ == 5: the ring piece requested at step 1, right behind the gathers, is due here as well -- memory returns in order)
+      if (s_ == 5) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
+      if (s_ == 12) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          w3q[q].h = ldg_q(w3b, ro3 + 1024u * q); w3q[q].m = ldg_q(w3b, ro3 + TERM3 + 1024u * q); w3q[q].l = ldg_q(w3b, ro3 + 2 * TERM3 + 1024u * q);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // common.hpp mma6's sequence (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi), A = the weights, B = the h1 terms
+      if (s_ + 1 < 16) bh[(s_ + 1) & 1] = lds_q(Hc + (s_ + 1) * 256);
+      acc = mfma_bf16(al, bh[s_ & 1], acc);
+      acc = mfma_bf16(wh[s_], bl, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ + 1 < 16) bl = lds_q(Hc + 2 * PW3_TERM + (s_ + 1) * 256);
+      acc = mfma_bf16(wm[s_], bm, acc);
+      acc = mfma_bf16(wm[s_], bh[s_ & 1], acc);
+      acc = mfma_bf16(wh[s_], bm, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ + 1 < 16) bm = lds_q(Hc + PW3_TERM + (s_ + 1) * 256);
+      acc = mfma_bf16(wh[s_], bh[s_ & 1], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- ReLU (the bias is in the chain), h2 rows, this wave's K = 32 slice of fc3 (two k-steps of the rectified accumulators, split in registers)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = relu_bits(acc[r]);
+    if (TRAINING) {
+      float* d_ = a.h2 + (size_t)e0 * D_H + 32 * wave;          // (uniform; the lane's row and half: h_lo)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pw2_st4(d_, h_lo + 32u * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+    }
+    {
+      f32x16 pacc = zero16();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const Bf3 ha = split3_8(f32x4{acc[8 * q], acc[8 * q + 1], acc[8 * q + 2], acc[8 * q + 3]},
+                                f32x4{acc[8 * q + 4], acc[8 * q + 5], acc[8 * q + 6], acc[8 * q + 7]});
+        __builtin_amdgcn_sched_barrier(0);
+        pacc = mma6(pacc, ha, w3q[q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float* d_ = Pc + (wave * PW2_T + 4 * half) * D_E + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
+    }
+    c1 = c2; n1 = n2;
+    pw2_barrier();
+  }
+  {
+    // the last tile's fc3
+    const int itl = t1 - t0 - 1;
+    const float* pp = sP + (itl & 1) * PW2_PF + er * D_E + j0;
+    float2 r_ = *reinterpret_cast<const float2*>(pp);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) { const float2 v = *reinterpret_cast<const float2*>(pp + w * (PW2_T * D_E)); r_.x += v.x; r_.y += v.y; }
+    pw2_st2(a.pw + (size_t)((t1 - 1) * PW2_T) * D_E, pw_lo, make_float2(fmaxf(r_.x + b3a, 0.f), fmaxf(r_.y + b3b, 0.f)));
+  }
+#undef PW3_EDGE
+#undef PW3_REQUEST
+#undef PW3_FC1
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1147,6 +1426,9 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
 
   void* prof = buf->profiler;
   GNET_LAUNCH(prof, GNET_K_PACK, s, pack_transpose<<<dim3(PACK_X, (L.raw ? 0 : 3) + (5 + (cfg->neighbor_feats ? 1 : 0)) * B + 2), 256, 0, s>>>(params, pt, L.dpw, B, cfg->neighbor_feats, L.raw));
+  unsigned* pwbf = reinterpret_cast<unsigned*>(pt + packed_pwbf_off(L));
+  if (!L.raw)
+    GNET_LAUNCH(prof, GNET_K_PACK, s, pack_pw_bf16<<<(2 * 8 * 16 * 64 * 4 + 2 * 8 * 2 * 64 * 4 + 255) / 256, 256, 0, s>>>(params + L.pw2, params + L.pw3, pwbf));
 
   if (E > 0) {
     // geometry columns + (row, score) pairs; kept in HBM for the backward pass when training
@@ -1171,12 +1453,24 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
     {
       const int grid2 = min((E + PW2_T - 1) / PW2_T, 256);
-      if (training) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
-        GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd2<true><<<grid2, 512, kPwFwd2Smem, s>>>(a));
+      static const bool fp32_pipe = getenv("GNET_PW_FP32_PIPE") != nullptr;     // measurement only: round 5's pw_fwd2 (fp32 MFMA)
+      if (fp32_pipe) {
+        if (training) {
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
+          GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd2<true><<<grid2, 512, kPwFwd2Smem, s>>>(a));
+        } else {
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
+          GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd2<false><<<grid2, 512, kPwFwd2Smem, s>>>(a));
+        }
       } else {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd2Smem));
-        GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd2<false><<<grid2, 512, kPwFwd2Smem, s>>>(a));
+        PwFwd3Args a3; a3.p = a; a3.wbf = pwbf;
+        if (training) {
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd3Smem));
+          GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd3<true><<<grid2, 512, kPwFwd3Smem, s>>>(a3));
+        } else {
+          HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd3Smem));
+          GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd3<false><<<grid2, 512, kPwFwd3Smem, s>>>(a3));
+        }
       }
     }
   }

@@ -205,6 +205,48 @@ def test_bench_two_ranks_functional(tmp_path):
     assert line["cpu_baseline"] is None and line["roofline"] is None          # rank 0 at N = 1 only / kernel timing off
 
 
+def test_bench_eight_ranks_functional(tmp_path):
+    """BASELINE configs[4]'s SHAPE before an 8-GPU node ever runs it: bench.py as the driver launches it with --gpus 8 -- eight
+    processes (here sharing cuda:0 under gloo), a 64-image global step dealt by the longest-processing-time rule on edge counts,
+    8 images per rank, one all-reduce per step.  Asserts 8 per-rank rows with equal image counts, edge balance max / mean <= 1.1,
+    the summed gradient bitwise equal on every rank, and the whole-job value; then the RCCL log parser on eight synthetic rank
+    files (the format RCCL writes with NCCL_DEBUG=INFO, NCCL_DEBUG_SUBSYS=INIT,GRAPH)."""
+    import json, subprocess, sys, os, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = str(s_.getsockname()[1]); s_.close()
+    env = dict(os.environ, GNET_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--images", "8", "--dets", "150", "--blocks", "2", "--no-kernel-timing"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    pr = line["per_rank"]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp8"
+    assert len(pr) == 8 and [r["rank"] for r in pr] == list(range(8))
+    assert all(r["images"] == 8 and r["dets"] == 8 * 150 and r["ms_per_step"] > 0 for r in pr)
+    edges = [r["edges"] for r in pr]
+    assert sum(edges) == line["config"]["edges_per_step_all_gpus"]
+    assert max(edges) <= 1.1 * (sum(edges) / 8.0), edges                    # LPT by edge count, equal image counts
+    assert len({r["summed_grad_checksum"] for r in pr}) == 1, pr           # every replica holds the same summed gradient, bit for bit
+    d = line["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and d["allreduce_samples"] == 2
+    assert abs(line["value"] - 64 * 150 * 2 / (line["ms_per_step"] * 2e-3)) <= 1e-3 * line["value"]
+    # the RCCL log parser over eight rank files
+    sys.path.insert(0, root)
+    import bench
+    for r in range(8):
+        (tmp_path / ("rccl_%d.log" % r)).write_text(
+            "host:%d:%d [%d] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abc\n"
+            "host:%d:%d [%d] NCCL INFO comm 0x1 rank %d nranks 8 cudaDev %d busId %x000 commId 0xdead - Init START\n"
+            "host:%d:%d [%d] NCCL INFO Channel 00/16 : 0 1 2 3 4 5 6 7\n"
+            "host:%d:%d [%d] NCCL INFO comm 0x1 rank %d nranks 8 cudaDev %d busId %x000 - Init COMPLETE\n"
+            % (100 + r, 200 + r, r, 100 + r, 200 + r, r, r, r, 5 + r, 100 + r, 200 + r, r, 100 + r, 200 + r, r, r, r, 5 + r))
+    ev = bench.rccl_evidence(str(tmp_path / "rccl_%p.log"))
+    assert ev["init_complete"] and "RCCL version" in ev["version"] and len(ev["bus_ids"]) == 8
+    assert ev["rccl_ranks_seen"] == [{"rank": r, "nranks": 8} for r in range(8)] and ev["rings"]
+
+
 def test_bench_one_rank_rccl_evidence_and_kernel_classes(tmp_path):
     """bench.py's N > 1 code path over RCCL with the one rank a one-GPU box has (GNET_BENCH_FORCE_DIST: a process group, the
     side-stream all-reduce launched without a wait, the next backward pass deferred behind it), and what the line then says
