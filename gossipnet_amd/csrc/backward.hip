@@ -24,6 +24,7 @@
 // launch order), so gradients are reproducible run to run.
 #include <type_traits>
 #include "common.hpp"
+#include <stdlib.h>
 #include "backward_edge.hpp"
 
 namespace {
@@ -924,6 +925,348 @@ __global__ void __launch_bounds__(512) pw_bwd_main(const PwBwdArgs a) {
   if (tid < D_E) ar[a.o_b3 + tid] = gb3;
 }
 
+// ------------------------------------------------------------------------------------------
+// pw_bwd_bf (round 6): pw_bwd_main ON THE bf16 PIPE.  Every fp32 product of its four GEMMs -- d2 = d3 . W3^T, dW3 += h2^T . d3,
+// dW2 += h1^T . d2, d h1 = d2 . W2^T -- is six bf16 products of exact three-term splits (common.hpp mma6's sequence,
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation): 216 MFMAs of 32 cycles per wave and tile instead of 288 of 64.  Same decomposition of
+// the row list (32-row tiles, 8 waves, one workgroup per CU walking its tiles; dW2 in 128 accumulator registers per wave across the
+// whole range, dW3 in 16), but the wave now owns COLUMNS [32 w, 32 w + 32) of d2 / W2 and all 256 rows of dW2 (8 blocks), because the
+// B operand of dW2 -- the wave's own d2 piece -- then never leaves its registers.  Operands:
+//   * weight-gradient products contract over the 32 tile rows, i.e. both operands want "lane = feature, eight k-slots = eight rows".
+//     h2 is loaded that way (16 plain loads per lane: lane = column, register r = row crow(r, half) -- as pw_bwd_main) and h1 too: the
+//     tile's rows are copied to an fp32 staging tile by LDS-DMA (no registers while in flight), and wave w reads ITS 32 columns of
+//     it, keeps nothing but splits them into three bf16 terms and publishes them as the A-operand fragments of block w
+//     (H1F[term][k-step][block][lane] x 16 bytes).  d2 (lane = column, registers = rows, masked by h2 > 0) is split in
+//     registers: those ARE the B operand of dW2;
+//   * d h1 = d2 . W2^T contracts over d2's 256 columns: its A operand wants "lane = row, eight k-slots = eight columns", the
+//     transpose of what the wave holds -- the three terms are scattered into D2F[term][k-step][row] x 16 bytes as 48 two-byte
+//     LDS stores per lane (the slot order of a k-step is frag_feat's, as in pw_fwd3), the B operand (W2 rows, three terms,
+//     pack_pw_bf16's W2D) streams from L2 through a two-deep ring that is reloaded in place;
+//   * d3 (32 x 32 per tile) is staged once in both fragment shapes (lane = row for d2, lane = column for dW3).
+// TWO LDS-only barriers per tile: phase A (d2, dW3, dW2: reads H1F, writes D2F) | phase B (d h1: reads D2F; stages d3 and H1F of
+// the next tile).  Every request with HBM latency (the h1 copies, h2, the d3 sources, row ids) is issued in phase A, whose operands
+// come from LDS; phase B's W2 stream has nothing slow in front of it.
+// The ReLU mask of d h1 comes from the high terms of the wave's own h1 fragments (h1 >= 0: positive <=> high term non-zero).
+constexpr int PBB_H1F = 0;                              // 32-bit words: [3][2][8][64][4]
+constexpr int PBB_H1F_T = 2 * 8 * 64 * 4;               //   words between the terms
+constexpr int PBB_D2F = PBB_H1F + 3 * PBB_H1F_T;        // bytes: term * 17408 + k-step * 1088 + half * 544 + row * 16 (+ slot * 2): the pads
+constexpr int PBB_D2F_TB = 16 * 1088;                   //   spread the two-byte scatter over the banks, the 16-byte reads stay aligned
+constexpr int PBB_S = PBB_D2F + 3 * PBB_D2F_TB / 4;     // fp32 [32][260]: the next tile's h1 rows (LDS-DMA)
+constexpr int PBB_D3A = PBB_S + 32 * LD256;             // [3][2][64][4]: d3, lane = row, slots = columns
+constexpr int PBB_D3B = PBB_D3A + 3 * 2 * 64 * 4;       // [3][2][64][4]: d3, lane = column, slots = rows
+constexpr int PBB_ROWS = PBB_D3B + 3 * 2 * 64 * 4;      // int [4][64]: list entries | the same with the slack row past the list
+constexpr int PBB_RED = PBB_ROWS + 4 * 64;              // fp32 [32][32]: d b3 partials (epilogue)
+constexpr size_t kPwBwdBfSmem = (size_t)(PBB_RED + 32 * 32) * 4;
+static_assert(kPwBwdBfSmem <= 160 * 1024, "pw_bwd_bf LDS");
+
+struct PwBwdBfArgs {
+  PwBwdArgs p;
+  const unsigned* wbf;       // pack_pw_bf16's arrays (common.hpp PWBF_*): W2D, W3D
+};
+
+template <bool BIG>
+__global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
+  const PwBwdArgs& a = aa.p;
+  extern __shared__ __attribute__((aligned(16))) unsigned smb[];
+  float* sS = reinterpret_cast<float*>(smb + PBB_S);
+  int* sRows = reinterpret_cast<int*>(smb + PBB_ROWS);
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x16 aW2[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) aW2[m] = zero16();
+  f32x16 aW3 = zero16();
+  float gb2 = 0.f, g3x = 0.f, g3y = 0.f;
+  const int n_rows = *a.n_rows;
+  const int ntiles = (n_rows + 31) / 32;
+  const int G = (int)gridDim.x;
+  int rs = 0;
+  float h2r[16];
+  float2 pq = make_float2(0.f, 0.f), dq = make_float2(0.f, 0.f);
+  const unsigned* w2d = aa.wbf + PWBF_W2D;               // [3][8][16][64][4]
+  const unsigned* w3d = aa.wbf + PWBF_W3D;               // [3][8][2][64][4]
+  constexpr unsigned W2D_T = 8u * 16 * 64 * 16, W3D_T = 8u * 2 * 64 * 16;      // bytes between the terms
+
+  // every piece derives its offsets from an opaque copy of the lane id: nothing address-like is hoisted out of the tile loop (and spilled)
+#define PBB_LANE()                                                                                       \
+  int lane = lane0; asm volatile("" : "+v"(lane));                                                       \
+  const int tid = lane + 64 * wave, col = lane & 31, half = lane >> 5; (void)tid; (void)col; (void)half
+#define PBB_LDQ(base_, off_) (*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base_) + (off_)))
+#define PBB_LDS_Q(word_) (*reinterpret_cast<const u32x4*>(smb + (word_)))
+#define PBB_LOAD_IDS(tile_) do { PBB_LANE(); rs = PB_ROW(tile_, tid & 31); } while (0)
+#define PBB_STAGE_IDS(tile_, q_)                                                                         \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    sRows[(q_) * 64 + (tid & 31)] = rs; sRows[(q_) * 64 + 32 + (tid & 31)] = (tile_) * 32 + (tid & 31) < n_rows ? rs : a.n_edge;   \
+  } while (0)
+  // d3 sources of a tile: thread (row = tid >> 4, column pair = tid & 15); the row id comes from the staged list
+#define PBB_REQUEST_D3(rows_)                                                                            \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    const unsigned o_ = (unsigned)(rows_)[tid >> 4] * (D_E * 4u) + 8u * (tid & 15);                      \
+    pq = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.pw) + o_);                     \
+    dq = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.d_pw) + o_);                   \
+  } while (0)
+  // d3 = d_pw where fc3's output is positive (rows past the list: zero), split, both fragment shapes -> LDS; d b3 partials
+#define PBB_STAGE_D3(tile_)                                                                              \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    const int row_ = tid >> 4, op_ = tid & 15;                                                           \
+    const bool in_ = (tile_) * 32 + row_ < n_rows;                                                       \
+    const float v0_ = (in_ && pq.x > 0.f) ? dq.x : 0.f, v1_ = (in_ && pq.y > 0.f) ? dq.y : 0.f;          \
+    g3x += v0_; g3y += v1_;                                                                              \
+    unsigned ph_, pm_, pl_; split3_pk(v0_, v1_, ph_, pm_, pl_);                                          \
+    unsigned* da_ = smb + PBB_D3A + (((op_ >> 3) * 64 + ((op_ >> 2) & 1) * 32 + row_) * 4 + (op_ & 3));  \
+    da_[0] = ph_; da_[2 * 64 * 4] = pm_; da_[2 * 2 * 64 * 4] = pl_;                                      \
+    unsigned short* db_ = reinterpret_cast<unsigned short*>(smb + PBB_D3B) +                             \
+        (((row_ >> 4) * 64 + ((row_ >> 2) & 1) * 32 + 2 * op_) * 8 + (row_ & 3) + 4 * ((row_ >> 3) & 1)); \
+    db_[0] = (unsigned short)ph_; db_[8] = (unsigned short)(ph_ >> 16);                                  \
+    db_[2 * 64 * 8] = (unsigned short)pm_; db_[2 * 64 * 8 + 8] = (unsigned short)(pm_ >> 16);            \
+    db_[2 * 2 * 64 * 8] = (unsigned short)pl_; db_[2 * 2 * 64 * 8 + 8] = (unsigned short)(pl_ >> 16);    \
+  } while (0)
+  // the wave's 32 columns of a tile's h2 rows: lane = column, register r = tile row crow(r, half)
+#define PBB_REQUEST_H2(rows_)                                                                            \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    const int* rp_ = (rows_) + 4 * half;                                                                 \
+    const unsigned lo_ = (unsigned)(32 * wave + col) * 4u;                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                  \
+      const unsigned rid_ = (unsigned)rp_[crow(r_, 0)];                                                  \
+      if (BIG) h2r[r_] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.h2) + ((unsigned long long)rid_ << 10) + lo_);   \
+      else h2r[r_] = ldg_b(a.h2, (rid_ << 10) + lo_);                                                    \
+    }                                                                                                    \
+  } while (0)
+  // the four h1 rows of a tile this wave copies into the staging tile (one 1 KB row per wave-instruction)
+#define PBB_DMA_H1(rows_)                                                                                \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    const int4 drv_ = *reinterpret_cast<const int4*>((rows_) + 4 * wave);                                \
+    const int dr_[4] = {drv_.x, drv_.y, drv_.z, drv_.w};                                                 \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                   \
+      const int rq_ = __builtin_amdgcn_readfirstlane(dr_[k_]);                                           \
+      const char* src_ = reinterpret_cast<const char*>(a.h1 + (size_t)rq_ * D_H) + 16u * (unsigned)lane; \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
+                                       (__attribute__((address_space(3))) void*)(sS + (wave * 4 + k_) * LD256), 16, 0, 0);   \
+    }                                                                                                    \
+  } while (0)
+  // the wave's 32 columns of the staged h1 tile -> three bf16 terms -> its block of H1F (k-step q = registers 8 q .. 8 q + 7)
+#define PBB_STAGE_H1()                                                                                   \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    const float* sp_ = sS + (4 * half) * LD256 + 32 * wave + col;                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                   \
+      float v_[8];                                                                                       \
+      _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) v_[t_] = sp_[crow(8 * q_ + t_, 0) * LD256];       \
+      const Bf3 f_ = split3_8(f32x4{v_[0], v_[1], v_[2], v_[3]}, f32x4{v_[4], v_[5], v_[6], v_[7]});     \
+      unsigned* d_ = smb + PBB_H1F + ((q_ * 8 + wave) * 64 + lane) * 4;                                  \
+      *reinterpret_cast<u32x4*>(d_) = f_.h; *reinterpret_cast<u32x4*>(d_ + PBB_H1F_T) = f_.m;            \
+      *reinterpret_cast<u32x4*>(d_ + 2 * PBB_H1F_T) = f_.l;                                              \
+    }                                                                                                    \
+  } while (0)
+#define PBB_STORE_DH1(rows_)                                                                             \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    const int* rp_ = (rows_) + 4 * half;                                                                 \
+    const unsigned lo_ = (unsigned)(32 * wave + col) * 4u;                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                  \
+      if (BIG) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.d_h1) + ((unsigned long long)(unsigned)rp_[crow(r_, 0)] << 10) + lo_) = acc[r_];   \
+      else stg_b(a.d_h1, ((unsigned)rp_[crow(r_, 0)] << 10) + lo_, acc[r_]);                             \
+    }                                                                                                    \
+  } while (0)
+#define PBB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  if ((int)blockIdx.x < ntiles) {
+    const int t0 = (int)blockIdx.x;
+    // ---- prologue: row ids of the first two tiles, d3(t0), h1(t0) as fragments, h2(t0) on its way
+    PBB_LOAD_IDS(t0);
+    PBB_STAGE_IDS(t0, 0);
+    PBB_LOAD_IDS(t0 + G);
+    PBB_STAGE_IDS(t0 + G, 1);
+    PBB_LOAD_IDS(t0 + 2 * G);
+    __syncthreads();
+    PBB_DMA_H1(sRows);
+    PBB_REQUEST_D3(sRows);
+    PBB_REQUEST_H2(sRows);
+    PBB_STAGE_D3(t0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    PBB_STAGE_H1();
+    drain_vmem_before_loop();
+    __syncthreads();
+
+    int it = 0;
+    for (int t = t0; t < ntiles; t += G, ++it) {
+      const int* rowsC = sRows + (it & 3) * 64 + 32;          // this tile's rows, the slack row past the list (d h1 stores)
+      const int* rowsN = sRows + ((it + 1) & 3) * 64;         // the next tile's rows
+      // ======== phase A ========
+      // the slow requests of the next tile, first: its four h1 rows (LDS-DMA) and its d3 sources
+      PBB_DMA_H1(rowsN);
+      PBB_REQUEST_D3(rowsN);
+      PBB_STAGE_IDS(t + 2 * G, (it + 2) & 3);
+      PBB_LOAD_IDS(t + 3 * G);
+      Bf3 bd2[2];
+      bool hm[16];
+      {
+        PBB_LANE();
+        // ---- d2 = d3 . W3^T (this wave's 32 columns), masked by h2 > 0; d b2; its three terms = the B operand of dW2
+        f32x16 d2 = zero16();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          Bf3 da, wb;
+          da.h = PBB_LDS_Q(PBB_D3A + (q * 64 + lane) * 4); da.m = PBB_LDS_Q(PBB_D3A + 2 * 64 * 4 + (q * 64 + lane) * 4);
+          da.l = PBB_LDS_Q(PBB_D3A + 2 * 2 * 64 * 4 + (q * 64 + lane) * 4);
+          const unsigned o_ = (unsigned)((wave * 2 + q) * 64 + lane) * 16u;
+          wb.h = PBB_LDQ(w3d, o_); wb.m = PBB_LDQ(w3d, W3D_T + o_); wb.l = PBB_LDQ(w3d, 2 * W3D_T + o_);
+          d2 = mma6(d2, da, wb);
+        }
+        float p_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d2[r] = h2r[r] > 0.f ? d2[r] : 0.f; p_ += d2[r]; }
+        gb2 += p_;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          bd2[q] = split3_8(f32x4{d2[8 * q], d2[8 * q + 1], d2[8 * q + 2], d2[8 * q + 3]}, f32x4{d2[8 * q + 4], d2[8 * q + 5], d2[8 * q + 6], d2[8 * q + 7]});
+        // ---- its transpose for phase B: the terms of (row, column 32 w + col) go to D2F[term][k-step][row] slot frag^-1(col)
+        {
+          unsigned short* d_ = reinterpret_cast<unsigned short*>(smb + PBB_D2F) +
+              ((2 * wave + (col >> 4)) * 1088 + ((col >> 2) & 1) * 544 + half * 64) / 2 + (col & 3) + 4 * ((col >> 3) & 1);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+              const int ro = (((2 * p2) & 3) + 8 * (2 * q + ((2 * p2) >> 2))) * 8;      // (row crow(8 q + 2 p2, 0)) * 16 bytes, in shorts
+              d_[ro] = (unsigned short)bd2[q].h[p2]; d_[ro + 8] = (unsigned short)(bd2[q].h[p2] >> 16);
+              d_[PBB_D2F_TB / 2 + ro] = (unsigned short)bd2[q].m[p2]; d_[PBB_D2F_TB / 2 + ro + 8] = (unsigned short)(bd2[q].m[p2] >> 16);
+              d_[PBB_D2F_TB + ro] = (unsigned short)bd2[q].l[p2]; d_[PBB_D2F_TB + ro + 8] = (unsigned short)(bd2[q].l[p2] >> 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dW3 += h2^T . d3 (rows [32 w, 32 w + 32) of W3): A = the h2 registers' terms, B = d3 with lane = column
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const Bf3 ha = split3_8(f32x4{h2r[8 * q], h2r[8 * q + 1], h2r[8 * q + 2], h2r[8 * q + 3]},
+                                  f32x4{h2r[8 * q + 4], h2r[8 * q + 5], h2r[8 * q + 6], h2r[8 * q + 7]});
+          Bf3 db;
+          db.h = PBB_LDS_Q(PBB_D3B + (q * 64 + lane) * 4); db.m = PBB_LDS_Q(PBB_D3B + 2 * 64 * 4 + (q * 64 + lane) * 4);
+          db.l = PBB_LDS_Q(PBB_D3B + 2 * 2 * 64 * 4 + (q * 64 + lane) * 4);
+          aW3 = mma6(aW3, ha, db);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      PBB_REQUEST_H2(rowsN);                                  // (the registers of h2(t) are free: the next tile's, a whole tile ahead)
+      {
+        // ---- dW2 += h1^T . d2: 8 blocks x 2 k-steps of six products; the A fragments from LDS (high term a step ahead, the low and
+        // the middle term reloaded in place behind their last product); the ReLU mask of d h1 from the high terms of block `wave`
+        PBB_LANE();
+        const unsigned* hf = smb + PBB_H1F + lane * 4;
+        u32x4 ah[2], am, al;
+        ah[0] = *reinterpret_cast<const u32x4*>(hf); am = *reinterpret_cast<const u32x4*>(hf + PBB_H1F_T); al = *reinterpret_cast<const u32x4*>(hf + 2 * PBB_H1F_T);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = i >> 3, m = i & 7;
+          const int qn = (i + 1) >> 3, mn = (i + 1) & 7;
+          const unsigned* hn = hf + (qn * 8 + mn) * 256;
+          __builtin_amdgcn_sched_barrier(0);
+          aW2[m] = mfma_bf16(al, bd2[q].h, aW2[m]);
+          if (i + 1 < 16) al = *reinterpret_cast<const u32x4*>(hn + 2 * PBB_H1F_T);
+          aW2[m] = mfma_bf16(ah[i & 1], bd2[q].l, aW2[m]);
+          if (i + 1 < 16) ah[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(hn);
+          aW2[m] = mfma_bf16(am, bd2[q].m, aW2[m]);
+          aW2[m] = mfma_bf16(am, bd2[q].h, aW2[m]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < 16) am = *reinterpret_cast<const u32x4*>(hn + PBB_H1F_T);
+          aW2[m] = mfma_bf16(ah[i & 1], bd2[q].m, aW2[m]);
+          aW2[m] = mfma_bf16(ah[i & 1], bd2[q].h, aW2[m]);
+          if (m == wave) {       // (uniform: the wave's own block) positive h1 <=> its high term is non-zero; slot t of step q = row crow(8 q + t, half)
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+              hm[8 * q + 2 * w4] = (ah[i & 1][w4] & 0xffffu) != 0u;
+              hm[8 * q + 2 * w4 + 1] = (ah[i & 1][w4] >> 16) != 0u;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- end of phase A: the DMA copies have landed (everything older than them too), the W2 ring is primed, the workgroup meets
+      u32x4 rh[2], rm[2], rl[2];
+      {
+        PBB_LANE();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned o_ = (unsigned)(wave * 16 * 64 + lane) * 16u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { rh[k] = PBB_LDQ(w2d, o_ + 1024u * k); rm[k] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * k); rl[k] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * k); }
+      }
+      PBB_BARRIER();
+      // ======== phase B ========
+      f32x16 acc = zero16();
+      {
+        // ---- d h1 = d2 . W2^T (columns [32 w, 32 w + 32)): 16 k-steps; A = D2F (lane = row), B = the ring
+        PBB_LANE();
+        const unsigned* df = smb + PBB_D2F + (half * 544 + col * 16) / 4;
+        const unsigned o_ = (unsigned)(wave * 16 * 64 + lane) * 16u;
+        u32x4 dh[2], dm, dl;
+        dh[0] = *reinterpret_cast<const u32x4*>(df); dm = *reinterpret_cast<const u32x4*>(df + PBB_D2F_TB / 4); dl = *reinterpret_cast<const u32x4*>(df + 2 * (PBB_D2F_TB / 4));
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const unsigned* dn = df + (s + 1) * (1088 / 4);
+          if (s == 3) PBB_STAGE_D3(t + G);
+          if (s == 6) PBB_STAGE_H1();
+          __builtin_amdgcn_sched_barrier(0);
+          acc = mfma_bf16(dl, rh[s & 1], acc);
+          if (s + 1 < 16) dl = *reinterpret_cast<const u32x4*>(dn + 2 * (PBB_D2F_TB / 4));
+          acc = mfma_bf16(dh[s & 1], rl[s & 1], acc);
+          if (s + 2 < 16) rl[s & 1] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * (s + 2));
+          if (s + 1 < 16) dh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(dn);
+          acc = mfma_bf16(dm, rm[s & 1], acc);
+          acc = mfma_bf16(dm, rh[s & 1], acc);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < 16) dm = *reinterpret_cast<const u32x4*>(dn + PBB_D2F_TB / 4);
+          acc = mfma_bf16(dh[s & 1], rm[s & 1], acc);
+          if (s + 2 < 16) rm[s & 1] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * (s + 2));
+          acc = mfma_bf16(dh[s & 1], rh[s & 1], acc);
+          if (s + 2 < 16) rh[s & 1] = PBB_LDQ(w2d, o_ + 1024u * (s + 2));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- the ReLU mask of d h1, its stores, the workgroup meets
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = hm[r] ? acc[r] : 0.f;
+      PBB_STORE_DH1(rowsC);
+      PBB_BARRIER();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#undef PBB_LDQ
+#undef PBB_LDS_Q
+#undef PBB_LOAD_IDS
+#undef PBB_STAGE_IDS
+#undef PBB_REQUEST_D3
+#undef PBB_STAGE_D3
+#undef PBB_REQUEST_H2
+#undef PBB_DMA_H1
+#undef PBB_STAGE_H1
+#undef PBB_STORE_DH1
+  // ---- epilogue: the partial weight gradients of this workgroup
+  __syncthreads();
+  const int lane = lane0, tid = threadIdx.x, col = lane & 31;
+  float* ar = a.arena + (size_t)blockIdx.x * a.stride;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) store_acc(ar + a.o_w2 + (size_t)(32 * m) * D_H + 32 * wave, D_H, aW2[m], lane);
+  store_acc(ar + a.o_w3 + (size_t)(32 * wave) * D_E, D_E, aW3, lane);
+  { unsigned lo_, hi_; half_bcast(__float_as_uint(gb2), lo_, hi_); gb2 = __uint_as_float(lo_) + __uint_as_float(hi_); }
+  if (lane < 32) ar[a.o_b2 + 32 * wave + col] = gb2;
+  float* red = reinterpret_cast<float*>(smb + PBB_RED);
+  red[(tid >> 4) * 32 + 2 * (tid & 15)] = g3x; red[(tid >> 4) * 32 + 2 * (tid & 15) + 1] = g3y;
+  __syncthreads();
+  if (tid < D_E) {
+    float p_ = red[tid];
+#pragma unroll 8
+    for (int r = 1; r < 32; ++r) p_ += red[r * 32 + tid];
+    ar[a.o_b3 + tid] = p_;
+  }
+#undef PBB_LANE
+#undef PBB_BARRIER
+}
+
 // fc1 of the pw-MLP: d W1 = X^T . d_h1 with X = [one-hot(c) * s_c | one-hot(n) * s_n | geo(7)].
 // The score columns factor through per-detection sums (deterministic, no class table in LDS):
 //   d W1[class k        ] = sum_{i : class_i = k} s_i * S[i],  S[i] = sum over i's own pairs of d_h1
@@ -1263,6 +1606,8 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
   // dynamic-LDS limits are per device and cheap to set: no process-global "done" flag
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_main<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_bf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdBfSmem));
+  HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_bwd_bf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwBwdBfSmem));
   { const int st = edge_stage_set_attributes(); if (st != GNET_OK) return st; }
 
   if (E > 0 && !prepared) {
@@ -1350,11 +1695,19 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     p.w2 = params + L.pw2; p.w3 = params + L.pw3; p.d_h1 = buf->d_h1;
     p.arena = buf->arena; p.stride = stride; p.o_w2 = L.pw2; p.o_b2 = L.pb2; p.o_w3 = L.pw3; p.o_b3 = L.pb3;
     GNET_TRACE_SET(p, "PW_BWD", true);
+    static const bool fp32_pipe = getenv("GNET_PW_FP32_PIPE") != nullptr;     // measurement only: round 5's pw_bwd_main (fp32 MFMA)
+    bool big = (long long)E + 64 > (1ll << 22);
 #ifdef PW_BWD_FORCE_BIG      /* verification builds: the 64-bit addressing variant on shapes the tests can afford */
-    if (true) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<true><<<g_pw, 512, kPwBwdSmem, s>>>(p)); } else
+    big = true;
 #endif
-    if ((long long)E + 64 > (1ll << 22)) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<true><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
-    else { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<false><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
+    if (fp32_pipe) {
+      if (big) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<true><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
+      else { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_main<false><<<g_pw, 512, kPwBwdSmem, s>>>(p)); }
+    } else {
+      PwBwdBfArgs pb; pb.p = p; pb.wbf = reinterpret_cast<const unsigned*>(buf->packed_t + packed_pwbf_off(L));
+      if (big) { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_bf<true><<<g_pw, 512, kPwBwdBfSmem, s>>>(pb)); }
+      else { GNET_LAUNCH(prof, GNET_K_PW_BWD, s, pw_bwd_bf<false><<<g_pw, 512, kPwBwdBfSmem, s>>>(pb)); }
+    }
     PwW1Args w;
     w.n_det = N; w.cprime = L.cprime; w.multiclass = cfg->num_classes > 1;
     w.row_ptr = buf->row_ptr; w.edge_t = buf->edge_t; w.geo = buf->geo; w.d_h1 = buf->d_h1;
