@@ -964,6 +964,12 @@ struct PwBwdBfArgs {
   const unsigned* wbf;       // pack_pw_bf16's arrays (common.hpp PWBF_*): W2D, W3D
 };
 
+#ifndef PBB_RD
+#define PBB_RD 2     /* depth of the W2 ring of phase B in k-steps (3 measured equal, 4 spills) */
+#endif
+#ifndef PBB_X
+#define PBB_X 0      /* ablation mask of measurement builds (tools/pw_ablate.sh): the shipped kernel is PBB_X == 0 */
+#endif
 template <bool BIG>
 __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
   const PwBwdArgs& a = aa.p;
@@ -971,6 +977,7 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
   float* sS = reinterpret_cast<float*>(smb + PBB_S);
   int* sRows = reinterpret_cast<int*>(smb + PBB_ROWS);
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  GSTAMP(a, 0);
   f32x16 aW2[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) aW2[m] = zero16();
@@ -981,6 +988,7 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
   const int G = (int)gridDim.x;
   int rs = 0;
   float h2r[16];
+  Bf3 w3q[2];                                            // the wave's W3^T fragments (B operand of d2): re-requested at the end of every phase B
   float2 pq = make_float2(0.f, 0.f), dq = make_float2(0.f, 0.f);
   const unsigned* w2d = aa.wbf + PWBF_W2D;               // [3][8][16][64][4]
   const unsigned* w3d = aa.wbf + PWBF_W3D;               // [3][8][2][64][4]
@@ -1072,6 +1080,14 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
       else stg_b(a.d_h1, ((unsigned)rp_[crow(r_, 0)] << 10) + lo_, acc[r_]);                             \
     }                                                                                                    \
   } while (0)
+#define PBB_LOAD_W3()                                                                                    \
+  do {                                                                                                   \
+    PBB_LANE();                                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                   \
+      const unsigned o_ = (unsigned)((wave * 2 + q_) * 64 + lane) * 16u;                                 \
+      w3q[q_].h = PBB_LDQ(w3d, o_); w3q[q_].m = PBB_LDQ(w3d, W3D_T + o_); w3q[q_].l = PBB_LDQ(w3d, 2 * W3D_T + o_);   \
+    }                                                                                                    \
+  } while (0)
 #define PBB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
   if ((int)blockIdx.x < ntiles) {
@@ -1090,6 +1106,7 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PBB_STAGE_H1();
+    PBB_LOAD_W3();
     drain_vmem_before_loop();
     __syncthreads();
 
@@ -1097,6 +1114,7 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
     for (int t = t0; t < ntiles; t += G, ++it) {
       const int* rowsC = sRows + (it & 3) * 64 + 32;          // this tile's rows, the slack row past the list (d h1 stores)
       const int* rowsN = sRows + ((it + 1) & 3) * 64;         // the next tile's rows
+      if (it == 5) { GSTAMP(a, 1); GSTAMP_W(a, 8, 256); }
       // ======== phase A ========
       // the slow requests of the next tile, first: its four h1 rows (LDS-DMA) and its d3 sources
       PBB_DMA_H1(rowsN);
@@ -1107,16 +1125,15 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
       bool hm[16];
       {
         PBB_LANE();
-        // ---- d2 = d3 . W3^T (this wave's 32 columns), masked by h2 > 0; d b2; its three terms = the B operand of dW2
+        // ---- d2 = d3 . W3^T (this wave's 32 columns; W3's fragments were requested at the end of the previous phase B), masked by
+        // h2 > 0; d b2; its three terms = the B operand of dW2
         f32x16 d2 = zero16();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          Bf3 da, wb;
+          Bf3 da;
           da.h = PBB_LDS_Q(PBB_D3A + (q * 64 + lane) * 4); da.m = PBB_LDS_Q(PBB_D3A + 2 * 64 * 4 + (q * 64 + lane) * 4);
           da.l = PBB_LDS_Q(PBB_D3A + 2 * 2 * 64 * 4 + (q * 64 + lane) * 4);
-          const unsigned o_ = (unsigned)((wave * 2 + q) * 64 + lane) * 16u;
-          wb.h = PBB_LDQ(w3d, o_); wb.m = PBB_LDQ(w3d, W3D_T + o_); wb.l = PBB_LDQ(w3d, 2 * W3D_T + o_);
-          d2 = mma6(d2, da, wb);
+          d2 = mma6(d2, da, w3q[q]);
         }
         float p_ = 0.f;
 #pragma unroll
@@ -1125,39 +1142,19 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           bd2[q] = split3_8(f32x4{d2[8 * q], d2[8 * q + 1], d2[8 * q + 2], d2[8 * q + 3]}, f32x4{d2[8 * q + 4], d2[8 * q + 5], d2[8 * q + 6], d2[8 * q + 7]});
-        // ---- its transpose for phase B: the terms of (row, column 32 w + col) go to D2F[term][k-step][row] slot frag^-1(col)
-        {
-          unsigned short* d_ = reinterpret_cast<unsigned short*>(smb + PBB_D2F) +
-              ((2 * wave + (col >> 4)) * 1088 + ((col >> 2) & 1) * 544 + half * 64) / 2 + (col & 3) + 4 * ((col >> 3) & 1);
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int p2 = 0; p2 < 4; ++p2) {
-              const int ro = (((2 * p2) & 3) + 8 * (2 * q + ((2 * p2) >> 2))) * 8;      // (row crow(8 q + 2 p2, 0)) * 16 bytes, in shorts
-              d_[ro] = (unsigned short)bd2[q].h[p2]; d_[ro + 8] = (unsigned short)(bd2[q].h[p2] >> 16);
-              d_[PBB_D2F_TB / 2 + ro] = (unsigned short)bd2[q].m[p2]; d_[PBB_D2F_TB / 2 + ro + 8] = (unsigned short)(bd2[q].m[p2] >> 16);
-              d_[PBB_D2F_TB + ro] = (unsigned short)bd2[q].l[p2]; d_[PBB_D2F_TB + ro + 8] = (unsigned short)(bd2[q].l[p2] >> 16);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dW3 += h2^T . d3 (rows [32 w, 32 w + 32) of W3): A = the h2 registers' terms, B = d3 with lane = column
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const Bf3 ha = split3_8(f32x4{h2r[8 * q], h2r[8 * q + 1], h2r[8 * q + 2], h2r[8 * q + 3]},
-                                  f32x4{h2r[8 * q + 4], h2r[8 * q + 5], h2r[8 * q + 6], h2r[8 * q + 7]});
-          Bf3 db;
-          db.h = PBB_LDS_Q(PBB_D3B + (q * 64 + lane) * 4); db.m = PBB_LDS_Q(PBB_D3B + 2 * 64 * 4 + (q * 64 + lane) * 4);
-          db.l = PBB_LDS_Q(PBB_D3B + 2 * 2 * 64 * 4 + (q * 64 + lane) * 4);
-          aW3 = mma6(aW3, ha, db);
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      PBB_REQUEST_H2(rowsN);                                  // (the registers of h2(t) are free: the next tile's, a whole tile ahead)
+      if (it == 5) { GSTAMP(a, 2); GSTAMP_W(a, 9, 256); }
       {
         // ---- dW2 += h1^T . d2: 8 blocks x 2 k-steps of six products; the A fragments from LDS (high term a step ahead, the low and
-        // the middle term reloaded in place behind their last product); the ReLU mask of d h1 from the high terms of block `wave`
+        // the middle term reloaded in place behind their last product); the ReLU mask of d h1 from the high terms of block `wave`.
+        // Woven into its 16 steps, six of the 48 two-byte stores of d2's TRANSPOSE per step in the first eight (phase B's A operand:
+        // the terms of (row, column 32 w + col) go to D2F[term][k-step][row], slot frag^-1(col)), then dW3 += h2^T . d3 (rows
+        // [32 w, 32 w + 32) of W3: A = the h2 registers' terms, B = d3 with lane = column) and the next tile's h2 requests
         PBB_LANE();
         const unsigned* hf = smb + PBB_H1F + lane * 4;
+        unsigned short* sc_ = reinterpret_cast<unsigned short*>(smb + PBB_D2F) +
+            ((2 * wave + (col >> 4)) * 1088 + ((col >> 2) & 1) * 544 + half * 64) / 2 + (col & 3) + 4 * ((col >> 3) & 1);
         u32x4 ah[2], am, al;
         ah[0] = *reinterpret_cast<const u32x4*>(hf); am = *reinterpret_cast<const u32x4*>(hf + PBB_H1F_T); al = *reinterpret_cast<const u32x4*>(hf + 2 * PBB_H1F_T);
 #pragma unroll
@@ -1165,6 +1162,24 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
           const int q = i >> 3, m = i & 7;
           const int qn = (i + 1) >> 3, mn = (i + 1) & 7;
           const unsigned* hn = hf + (qn * 8 + mn) * 256;
+          if (i < 8 && !(PBB_X & 1)) {
+            const int sq = i >> 2, p2 = i & 3;
+            const int ro = (((2 * p2) & 3) + 8 * (2 * sq + ((2 * p2) >> 2))) * 8;      // (row crow(8 sq + 2 p2, 0)) * 16 bytes, in shorts
+            sc_[ro] = (unsigned short)bd2[sq].h[p2]; sc_[ro + 8] = (unsigned short)(bd2[sq].h[p2] >> 16);
+            sc_[PBB_D2F_TB / 2 + ro] = (unsigned short)bd2[sq].m[p2]; sc_[PBB_D2F_TB / 2 + ro + 8] = (unsigned short)(bd2[sq].m[p2] >> 16);
+            sc_[PBB_D2F_TB + ro] = (unsigned short)bd2[sq].l[p2]; sc_[PBB_D2F_TB + ro + 8] = (unsigned short)(bd2[sq].l[p2] >> 16);
+          }
+          if ((i == 8 || i == 10) && !(PBB_X & 2)) {
+            const int q3 = (i - 8) >> 1;
+            const Bf3 ha = split3_8(f32x4{h2r[8 * q3], h2r[8 * q3 + 1], h2r[8 * q3 + 2], h2r[8 * q3 + 3]},
+                                    f32x4{h2r[8 * q3 + 4], h2r[8 * q3 + 5], h2r[8 * q3 + 6], h2r[8 * q3 + 7]});
+            Bf3 db;
+            db.h = PBB_LDS_Q(PBB_D3B + (q3 * 64 + lane) * 4); db.m = PBB_LDS_Q(PBB_D3B + 2 * 64 * 4 + (q3 * 64 + lane) * 4);
+            db.l = PBB_LDS_Q(PBB_D3B + 2 * 2 * 64 * 4 + (q3 * 64 + lane) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+            aW3 = mma6(aW3, ha, db);
+          }
+          if (i == 11 && !(PBB_X & 32)) PBB_REQUEST_H2(rowsN);   // (the registers of h2(t) are free: the next tile's, a whole tile ahead)
           __builtin_amdgcn_sched_barrier(0);
           aW2[m] = mfma_bf16(al, bd2[q].h, aW2[m]);
           if (i + 1 < 16) al = *reinterpret_cast<const u32x4*>(hn + 2 * PBB_H1F_T);
@@ -1186,16 +1201,20 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (it == 5) { GSTAMP(a, 3); GSTAMP_W(a, 10, 256); }
       // ---- end of phase A: the DMA copies have landed (everything older than them too), the W2 ring is primed, the workgroup meets
-      u32x4 rh[2], rm[2], rl[2];
+      constexpr int RD = PBB_RD;                              // depth of the W2 ring in k-steps
+      u32x4 rh[RD], rm[RD], rl[RD];
       {
         PBB_LANE();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (it == 5) { GSTAMP(a, 4); GSTAMP_W(a, 11, 256); }
         const unsigned o_ = (unsigned)(wave * 16 * 64 + lane) * 16u;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { rh[k] = PBB_LDQ(w2d, o_ + 1024u * k); rm[k] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * k); rl[k] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * k); }
+        for (int k = 0; k < RD; ++k) { rh[k] = PBB_LDQ(w2d, o_ + 1024u * k); rm[k] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * k); rl[k] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * k); }
       }
       PBB_BARRIER();
+      if (it == 5) { GSTAMP(a, 5); GSTAMP_W(a, 12, 256); }
       // ======== phase B ========
       f32x16 acc = zero16();
       {
@@ -1208,30 +1227,33 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const unsigned* dn = df + (s + 1) * (1088 / 4);
-          if (s == 3) PBB_STAGE_D3(t + G);
-          if (s == 6) PBB_STAGE_H1();
+          if (s == 3 && !(PBB_X & 8)) PBB_STAGE_D3(t + G);
+          if (s == 6 && !(PBB_X & 4)) PBB_STAGE_H1();
+          if (s == 13) PBB_LOAD_W3();                          // (behind the ring's last requests)
           __builtin_amdgcn_sched_barrier(0);
-          acc = mfma_bf16(dl, rh[s & 1], acc);
+          acc = mfma_bf16(dl, rh[s % RD], acc);
           if (s + 1 < 16) dl = *reinterpret_cast<const u32x4*>(dn + 2 * (PBB_D2F_TB / 4));
-          acc = mfma_bf16(dh[s & 1], rl[s & 1], acc);
-          if (s + 2 < 16) rl[s & 1] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * (s + 2));
+          acc = mfma_bf16(dh[s & 1], rl[s % RD], acc);
+          if (s + RD < 16) rl[s % RD] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * (s + RD));
           if (s + 1 < 16) dh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(dn);
-          acc = mfma_bf16(dm, rm[s & 1], acc);
-          acc = mfma_bf16(dm, rh[s & 1], acc);
+          acc = mfma_bf16(dm, rm[s % RD], acc);
+          acc = mfma_bf16(dm, rh[s % RD], acc);
           __builtin_amdgcn_sched_barrier(0);
           if (s + 1 < 16) dm = *reinterpret_cast<const u32x4*>(dn + PBB_D2F_TB / 4);
-          acc = mfma_bf16(dh[s & 1], rm[s & 1], acc);
-          if (s + 2 < 16) rm[s & 1] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * (s + 2));
-          acc = mfma_bf16(dh[s & 1], rh[s & 1], acc);
-          if (s + 2 < 16) rh[s & 1] = PBB_LDQ(w2d, o_ + 1024u * (s + 2));
+          acc = mfma_bf16(dh[s & 1], rm[s % RD], acc);
+          if (s + RD < 16) rm[s % RD] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * (s + RD));
+          acc = mfma_bf16(dh[s & 1], rh[s % RD], acc);
+          if (s + RD < 16) rh[s % RD] = PBB_LDQ(w2d, o_ + 1024u * (s + RD));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (it == 5) { GSTAMP(a, 6); GSTAMP_W(a, 13, 256); }
       // ---- the ReLU mask of d h1, its stores, the workgroup meets
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = hm[r] ? acc[r] : 0.f;
-      PBB_STORE_DH1(rowsC);
+      for (int r = 0; r < 16; ++r) acc[r] = (hm[r] || (PBB_X & 64)) ? acc[r] : 0.f;
+      if (!(PBB_X & 16)) PBB_STORE_DH1(rowsC);
       PBB_BARRIER();
+      if (it == 5) { GSTAMP(a, 7); GSTAMP_W(a, 14, 256); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1245,8 +1267,10 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
 #undef PBB_DMA_H1
 #undef PBB_STAGE_H1
 #undef PBB_STORE_DH1
+#undef PBB_LOAD_W3
   // ---- epilogue: the partial weight gradients of this workgroup
   __syncthreads();
+  GSTAMP(a, 15);
   const int lane = lane0, tid = threadIdx.x, col = lane & 31;
   float* ar = a.arena + (size_t)blockIdx.x * a.stride;
 #pragma unroll

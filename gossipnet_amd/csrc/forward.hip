@@ -264,6 +264,17 @@ __device__ __forceinline__ void pw2_barrier() {
 // global accesses of pw_fwd2 as (wave-uniform 64-bit base, SGPRs) + (32-bit per-lane byte offset, one loop-invariant VGPR): the
 // `saddr + voffset` form costs no vector instruction per access (base[row * ld + lane] costs three to five 64-bit ones)
 __device__ __forceinline__ void pw2_st4(float* ubase, unsigned off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + off) = v; }
+// the same as a non-temporal (streaming) store: activations kept for the backward pass are read once, a whole forward pass later --
+// they should not evict the table rows and weight fragments the kernel gathers from L2
+#ifndef PW3_NT
+#define PW3_NT 0      /* measured on MI355X: streaming stores of h1 / h2 make the training kernel 10 % SLOWER (1.34 -> 1.48 ms) */
+#endif
+__device__ __forceinline__ void pw3_st4(float* ubase, unsigned off, const float4& v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  f4v* p = reinterpret_cast<f4v*>(reinterpret_cast<char*>(ubase) + off);
+  const f4v x = {v.x, v.y, v.z, v.w};
+  if (PW3_NT) __builtin_nontemporal_store(x, p); else *p = x;
+}
 __device__ __forceinline__ void pw2_st2(float* ubase, unsigned off, const float2& v) { *reinterpret_cast<float2*>(reinterpret_cast<char*>(ubase) + off) = v; }
 
 template <bool TRAINING>
@@ -528,6 +539,7 @@ static_assert(kPwFwd3Smem == 160 * 1024, "pw_fwd3 uses the whole LDS of a CU");
 struct PwFwd3Args {
   PwFwdArgs p;
   const unsigned* wbf;     // pack_pw_bf16's arrays (common.hpp PWBF_*)
+  GNET_TRACE_FIELD
 };
 
 __device__ __forceinline__ u32x4 lds_q(const unsigned* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -548,6 +560,7 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
   const int t0 = range_begin(lb, nt, nwg), t1 = range_begin(lb + 1, nt, nwg);
   if (t0 >= t1) return;
   const int last = a.n_edge - 1;
+  GSTAMP(aa, 0);
 
   // ---- resident operands: the high and middle terms of the wave's 256 x 32 slice of W2 (A operand of the transposed product)
   u32x4 wh[16], wm[16];
@@ -608,7 +621,7 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
     _Pragma("unroll") for (int r = 0; r < 16; ++r) h_[r] = relu_bits(h_[r]);                       \
     if (TRAINING) {                                                                                \
       float* g_ = a.h1 + (size_t)(e0_) * D_H + 32 * wave;                                          \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) pw2_st4(g_, h_lo + 32u * g, make_float4(h_[4 * g], h_[4 * g + 1], h_[4 * g + 2], h_[4 * g + 3])); \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) pw3_st4(g_, h_lo + 32u * g, make_float4(h_[4 * g], h_[4 * g + 1], h_[4 * g + 2], h_[4 * g + 3])); \
     }                                                                                              \
     _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                \
       const Bf3 t_ = split3_8(f32x4{h_[8 * q], h_[8 * q + 1], h_[8 * q + 2], h_[8 * q + 3]},       \
@@ -645,6 +658,7 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
     float* Pc = sP + (it & 1) * PW2_PF;
     const float* Pp = sP + ((it & 1) ^ 1) * PW2_PF;
     int c2, n2;
+    if (it == 5) { GSTAMP(aa, 1); GSTAMP_W(aa, 8, 256); }
     // (lane offsets made opaque once per tile: what is derived from them stays inside the loop instead of being hoisted as 64-bit
     // lane addresses -- and spilled: a scratch reload in this loop is a vmcnt(0), i.e. a drain of the ring)
     asm volatile("" : "+v"(ro), "+v"(ro3), "+v"(fo), "+v"(pw_lo), "+v"(h_lo), "+v"(hmask));
@@ -679,7 +693,10 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
         pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(r_.x + b3a, 0.f), fmaxf(r_.y + b3b, 0.f)));
       }
       // (s_ == 5: the ring piece requested at step 1, right behind the gathers, is due here as well -- memory returns in order)
+      if (s_ == 5 && it == 5) { GSTAMP(aa, 2); GSTAMP_W(aa, 9, 256); }
       if (s_ == 5) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
+      if (s_ == 6 && it == 5) { GSTAMP(aa, 3); GSTAMP_W(aa, 10, 256); }
+      if (s_ == 12 && it == 5) { GSTAMP(aa, 4); GSTAMP_W(aa, 11, 256); }
       if (s_ == 12) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -701,13 +718,14 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
       acc = mfma_bf16(wh[s_], bh[s_ & 1], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (it == 5) { GSTAMP(aa, 5); GSTAMP_W(aa, 12, 256); }
     // ---- ReLU (the bias is in the chain), h2 rows, this wave's K = 32 slice of fc3 (two k-steps of the rectified accumulators, split in registers)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = relu_bits(acc[r]);
     if (TRAINING) {
       float* d_ = a.h2 + (size_t)e0 * D_H + 32 * wave;          // (uniform; the lane's row and half: h_lo)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pw2_st4(d_, h_lo + 32u * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+      for (int g = 0; g < 4; ++g) pw3_st4(d_, h_lo + 32u * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
     }
     {
       f32x16 pacc = zero16();
@@ -724,7 +742,9 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
       for (int r = 0; r < 16; ++r) d_[crow(r, 0) * D_E] = pacc[r];
     }
     c1 = c2; n1 = n2;
+    if (it == 5) { GSTAMP(aa, 6); GSTAMP_W(aa, 13, 256); }
     pw2_barrier();
+    if (it == 5) { GSTAMP(aa, 7); GSTAMP_W(aa, 14, 256); }
   }
   {
     // the last tile's fc3
@@ -1464,6 +1484,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
         }
       } else {
         PwFwd3Args a3; a3.p = a; a3.wbf = pwbf;
+        GNET_TRACE_SET(a3, "PW_FWD", true);
         if (training) {
           HIP_CHECK_RET(hipFuncSetAttribute((const void*)pw_fwd3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwFwd3Smem));
           GNET_LAUNCH(prof, GNET_K_PW_FWD, s, pw_fwd3<true><<<grid2, 512, kPwFwd3Smem, s>>>(a3));
