@@ -21,7 +21,7 @@ The JSON line also carries
                 `fp32_equivalent` = FLOPs of the fp32 formulation / time against the fp32 peak; `reference_formulation`
                 = the same with the FLOPs of the reference's dense per-edge formulation, which a kernel can
                 exceed 1.0 on by not executing them; `traffic` = HBM bytes per launch from the separate rocprofv3
-                --pmc passes (profiles/r05_traffic.json), reported only while that file was collected from the same
+                --pmc passes (profiles/r06_traffic.json), reported only while that file was collected from the same
                 kernel sources (hash), else null; `mfma_busy` (per MFMA kernel, same file and gate) =
                 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the launch's GRBM_GUI_ACTIVE cycles) of the --pmc pass
   roi_pool      the RoiPool / RoiPoolGrad ops at the reference's shape (R=2000 rois, 38x63x1024 map, 7x7 bins):
@@ -50,7 +50,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (64 FLOP / clk / SIMD x 1024 SIMDs x 2.4 GHz)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # dense v_mfma_f32_32x32x16_bf16: 32768 FLOP in 32 clk per SIMD (the guide's ~2.5 PFLOP/s)
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
+PW_FP32_PIPE = bool(os.environ.get("GNET_PW_FP32_PIPE"))     # measurement only: round 5's fp32-MFMA pw_fwd2 / pw_bwd_main instead of pw_fwd3 / pw_bwd_bf
 
 
 def kernel_source_hash():
@@ -83,13 +84,15 @@ def executed_mfma_flops(cls, E, N, winners_per_block, pw_rows):
     v_mfma_f32_32x32x16_bf16), from the kernels' tile loops:
     edge_fwd_w forms its fp32 products as six bf16 products of three-term splits: 72 bf16 MFMAs per 32 edges (the fp32 formulation
     it replaces: 96 fp32 MFMAs, see `fp32_equivalent_flops`); edge_bwd_w 24 bf16 MFMAs (h1, the forward's sequence) + 128 fp32 MFMAs
-    per 32 winner rows; pw_fwd2 fc2 + fc3 + fc1's K = 8 geometry product (the 2C score columns are two table rows per edge);
-    pw_bwd_main 4 GEMMs per listed row."""
+    per 32 winner rows; pw_fwd3 (round 6) per 32 edges and wave 96 (fc2) + 12 (fc3) + 1 (fc2's bias) bf16 MFMAs and 4 fp32 MFMAs
+    (fc1's K = 8 geometry product; the 2C score columns are two table rows per edge), eight waves; pw_bwd_bf (round 6) per 32
+    listed rows and wave 216 bf16 MFMAs (d2 12, dW3 12, dW2 96, d h1 96), eight waves.  (GNET_PW_FP32_PIPE: round 5's fp32 kernels.)"""
     table = {
         "edge_fwd": (0.0, 72 * 32768.0 * E / 32),
         "edge_bwd": (128 * 4096.0 * winners_per_block / 32, 24 * 32768.0 * winners_per_block / 32),
-        "pw_fwd": (2.0 * E * (8 * 256 + 256 * 256 + 256 * 32), 0.0),      # fc1's geometry term (K = 8 incl. the zero pad) + fc2 + fc3
-        "pw_bwd_main": (2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32), 0.0),
+        "pw_fwd": (2.0 * E * (8 * 256 + 256 * 256 + 256 * 32), 0.0) if PW_FP32_PIPE else
+                  (8 * 4 * 4096.0 * E / 32, 8 * 109 * 32768.0 * E / 32),
+        "pw_bwd_main": (2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32), 0.0) if PW_FP32_PIPE else (0.0, 8 * 216 * 32768.0 * pw_rows / 32),
         "node_fwd": (2.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128), 0.0),
         "node_bwd": (4.0 * N * (128 * 32 + 32 * 128 + 64 * 64 + 64 * 128), 0.0),
         "head_bwd": (4.0 * N * (2 * 128 * 128), 0.0),
@@ -102,7 +105,9 @@ def fp32_equivalent_flops(cls, E, N, winners_per_block, pw_rows):
     ex = executed_mfma_flops(cls, E, N, winners_per_block, pw_rows)
     if ex is None:
         return None
-    return {"edge_fwd": 96 * 4096.0 * E / 32, "edge_bwd": 160 * 4096.0 * winners_per_block / 32}.get(cls, ex[0])
+    return {"edge_fwd": 96 * 4096.0 * E / 32, "edge_bwd": 160 * 4096.0 * winners_per_block / 32,
+            "pw_fwd": 2.0 * E * (8 * 256 + 256 * 256 + 256 * 32),                 # fc1's geometry term (K = 8 incl. the zero pad) + fc2 + fc3
+            "pw_bwd_main": 2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32)}.get(cls, ex[0])
 
 
 def pipe_seconds(ex):
@@ -472,7 +477,7 @@ def main():
                         traffic = tf["kernels"].get(cls, {}).get("hbm_bytes")
                         pmc = tf["kernels"]
                     else:
-                        note = "profiles/r05_traffic.json was collected from other kernel sources / another workload: not reported"
+                        note = "profiles/r06_traffic.json was collected from other kernel sources / another workload: not reported"
                 # `achieved` counts the FLOPs the algorithm needs in this kernel's formulation (= the MFMA FLOPs it issues:
                 # e.g. edge_fwd computes P.Wp + rc[c] + rn[n] per edge, the per-node products r.Wc / r.Wn live in
                 # node_fwd); the reference's dense per-edge formulation is reported beside it -- a kernel
@@ -522,7 +527,7 @@ def main():
             roofline["mfma_kernels"] = mfma_kernels
             roofline["mfma_busy"] = pmc.get(roofline["kernel"], {}).get("mfma_busy")
             roofline["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per launch, from the separate rocprofv3 "
-                                          "--pmc pass (profiles/r05_traffic.json, same kernel sources); null = no current counters")
+                                          "--pmc pass (profiles/r06_traffic.json, same kernel sources); null = no current counters")
         # whole-step executed MFMA FLOPs
         ex_f32, ex_bf16, eq_total = 0.0, 0.0, 0.0
         for k_, c_ in counts.items():
@@ -620,9 +625,10 @@ def main():
             "value": round(value, 1), "unit": "detections/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": ("fp32 operands, accumulators and results throughout; edge_fwd_w (and the backward kernels that reproduce its bits) form each "
-                           "fp32 product as six bf16 products of exact three-term splits with fp32 accumulation -- error against fp64 equal to the "
-                           "fp32 MFMA's (profiles/r05_bf16x3_probe.txt), parity bars unchanged"),
+            "dtype_note": ("fp32 operands, accumulators and results throughout; the four edge-sized FC kernels (edge_fwd_w, pw_fwd3, pw_bwd_bf, and "
+                           "edge_bwd_w's h1 recomputation) form each fp32 product as six bf16 products of exact three-term splits with fp32 "
+                           "accumulation -- error against fp64 at the fp32 MFMA's level, measured on the kernels' own operands by "
+                           "tests/test_gpu_bf16x3.py (gnet_debug_gemm) and profiles/r05_bf16x3_probe.txt; parity bars unchanged"),
             "data": "synthetic",
             "timing": "one timed pass of K steps between barrier + synchronize on both sides, max over ranks (the driver's contract); "
                       "other_configs report the faster of two such passes each",

@@ -547,6 +547,10 @@ __device__ __forceinline__ u32x4 ldg_q(const unsigned* __restrict__ ubase, unsig
   return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + byte_off);
 }
 
+#ifndef PW3_S_FC1
+#define PW3_S_FC1 9       /* k-step in front of which the next tile's fc1 is formed (5 / 9 / 12 / 13 measured: 1.38 / 1.35 / 1.40 / 1.41 ms) */
+#define PW3_S_W3 13       /* k-step in front of which fc3's weight fragments are re-requested (behind fc1: its registers are free then) */
+#endif
 template <bool TRAINING>
 __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
   const PwFwdArgs& a = aa.p;
@@ -692,12 +696,11 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
         const int ep = it > 0 ? e0 - PW2_T : a.n_edge + 32;
         pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(r_.x + b3a, 0.f), fmaxf(r_.y + b3b, 0.f)));
       }
-      // (s_ == 5: the ring piece requested at step 1, right behind the gathers, is due here as well -- memory returns in order)
-      if (s_ == 5 && it == 5) { GSTAMP(aa, 2); GSTAMP_W(aa, 9, 256); }
-      if (s_ == 5) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
-      if (s_ == 6 && it == 5) { GSTAMP(aa, 3); GSTAMP_W(aa, 10, 256); }
-      if (s_ == 12 && it == 5) { GSTAMP(aa, 4); GSTAMP_W(aa, 11, 256); }
-      if (s_ == 12) {
+      if (s_ == PW3_S_FC1 && it == 5) { GSTAMP(aa, 2); GSTAMP_W(aa, 9, 256); }
+      if (s_ == PW3_S_FC1) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
+      if (s_ == PW3_S_FC1 + 1 && it == 5) { GSTAMP(aa, 3); GSTAMP_W(aa, 10, 256); }
+      if (s_ == PW3_S_W3 && it == 5) { GSTAMP(aa, 4); GSTAMP_W(aa, 11, 256); }
+      if (s_ == PW3_S_W3) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           w3q[q].h = ldg_q(w3b, ro3 + 1024u * q); w3q[q].m = ldg_q(w3b, ro3 + TERM3 + 1024u * q); w3q[q].l = ldg_q(w3b, ro3 + 2 * TERM3 + 1024u * q);

@@ -99,9 +99,15 @@ def test_bench_prices_the_two_mfma_pipes():
     f32, bf16 = bench.executed_mfma_flops("edge_bwd", E, N, W, R)
     assert (f32, bf16) == (128 * 4096.0 * 200, 24 * 32768.0 * 200)
     assert bench.fp32_equivalent_flops("edge_bwd", E, N, W, R) == 160 * 4096.0 * 200
-    # a pure fp32 kernel: its formulation IS what it issues
+    # round 6: the pw-MLP kernels on the bf16 pipe -- pw_bwd_bf 216 bf16 MFMAs per wave and 32 listed rows (8 waves) for the 294 912
+    # FLOPs per row of its four fp32 GEMMs; pw_fwd3 109 bf16 + 4 fp32 MFMAs per wave and 32 edges for 151 552 FLOPs per edge
     f32, bf16 = bench.executed_mfma_flops("pw_bwd_main", E, N, W, R)
-    assert bf16 == 0.0 and bench.fp32_equivalent_flops("pw_bwd_main", E, N, W, R) == f32 == 294912.0 * R
+    assert f32 == 0.0 and bf16 == 8 * 216 * 32768.0 * 700 and bench.fp32_equivalent_flops("pw_bwd_main", E, N, W, R) == 294912.0 * R
+    f32, bf16 = bench.executed_mfma_flops("pw_fwd", E, N, W, R)
+    assert (f32, bf16) == (8 * 4 * 4096.0 * 1000, 8 * 109 * 32768.0 * 1000) and bench.fp32_equivalent_flops("pw_fwd", E, N, W, R) == 151552.0 * E
+    # a pure fp32 kernel: its formulation IS what it issues
+    f32, bf16 = bench.executed_mfma_flops("node_fwd", E, N, W, R)
+    assert bf16 == 0.0 and bench.fp32_equivalent_flops("node_fwd", E, N, W, R) == f32
     # pipe time: one second of each pipe's peak is one second
     assert abs(bench.pipe_seconds((bench.FP32_MFMA_PEAK_TFLOPS * 1e12, 0.0)) - 1.0) < 1e-12
     assert abs(bench.pipe_seconds((0.0, bench.BF16_MFMA_PEAK_TFLOPS * 1e12)) - 1.0) < 1e-12

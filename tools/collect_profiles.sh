@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun) from the repo root: refreshes the round's measurement artefacts under
 # gpurun_out/prof/ (copy the summaries into profiles/ afterwards):
 #   pmc_fetch.txt / pmc_write.txt / pmc_sq.txt   separate --pmc passes, per-kernel per-launch averages
-#   traffic.json              HBM bytes + MFMA-busy fraction per launch and kernel (bench.py reads profiles/r05_traffic.json:
+#   traffic.json              HBM bytes + MFMA-busy fraction per launch and kernel (bench.py reads profiles/r06_traffic.json:
 #                             copied there ON THE BOX before the bench line is taken, so that the line carries the counters of
 #                             the same kernel sources)
 #   bench.json                default bench.py line (with other_configs and cpu_baseline)
@@ -16,7 +16,7 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_BUSY_CYCLES SQ_WAVE_CYC
   python tools/pmc_sum.py $R/pmc_$name.csv > $R/pmc_$name.txt 2>&1
 done
 python tools/make_traffic.py $R/pmc_fetch.csv $R/pmc_write.csv $R/pmc_sq.csv $R/traffic.json > $R/traffic.log 2>&1
-cp $R/traffic.json profiles/r05_traffic.json
+cp $R/traffic.json profiles/r06_traffic.json
 python bench.py > $R/bench.log 2>&1; tail -1 $R/bench.log > $R/bench.json
 rocprofv3 --kernel-trace --stats -d $R/kt -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --cpu-seconds 0 --no-kernel-timing --no-other-configs > $R/kt.log 2>&1
 cp $(find $R/kt -name "*kernel_stats.csv" | head -1) $R/kernel_stats.csv

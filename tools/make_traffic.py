@@ -36,7 +36,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* GRBM_GUI_ACTIV
        "units": "per launch; hbm_bytes = (2 x FETCH_SIZE[KB] + WRITE_SIZE[KB]) x 1024 -- MI355X_MICROARCH.md (HBM): on gfx950 "
                 "FETCH_SIZE reports half of the bytes of wide coalesced reads (double it); other access widths and WRITE_SIZE "
                 "are uncalibrated; Infinity-Cache hits are counted, not excluded.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES (64 per "
-                "v_mfma_f32_32x32x2_f32, summed over the SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE of the launch); valu_per_mfma = "
+                "v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_32x32x16_bf16, summed over the SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE of the launch); valu_per_mfma = "
                 "(SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA (INSTS_VALU includes the MFMAs: rounds 1-3 printed the ratio one too high)",
        "kernels": kernels}
 json.dump(out, open(sys.argv[4], "w"), indent=1)

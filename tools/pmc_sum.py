@@ -5,7 +5,7 @@ import json
 import sys
 
 # substring of the kernel symbol -> name used in the profile summaries / profiles/*_traffic.json (bench.py kernel classes)
-NAMES = [("edge_bwd_w", "edge_bwd"), ("edge_fwd_w", "edge_fwd"), ("pw_bwd_main", "pw_bwd_main"), ("pw_w1_nodesums", "pw_w1_nodesums"),
+NAMES = [("edge_bwd_w", "edge_bwd"), ("edge_fwd_w", "edge_fwd"), ("pw_bwd_bf", "pw_bwd_main"), ("pw_bwd_main", "pw_bwd_main"), ("pw_w1_nodesums", "pw_w1_nodesums"),
          ("pw_w1_classrows", "pw_w1_classrows"), ("pw_fwd", "pw_fwd"), ("gather_winners", "gather_winners"),
          ("winners_mark", "winners_mark"), ("winners_ties", "winners_ties"), ("winner_positions", "winner_positions"),
          ("list_fill", "list_fill"), ("list_count", "list_count"), ("blk_bwd_node", "node_bwd"), ("node_fwd", "node_fwd"),
