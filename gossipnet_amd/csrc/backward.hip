@@ -967,6 +967,24 @@ struct PwBwdBfArgs {
 #ifndef PBB_RD
 #define PBB_RD 2     /* depth of the W2 ring of phase B in k-steps (3 measured equal, 4 spills) */
 #endif
+#ifdef PBB_TRACE2
+#define PBB_T2(slot_) do { if (it == 5) GSTAMP(a, slot_); } while (0)
+#define PBB_W(slot_) ((void)0)
+#else
+#define PBB_T2(slot_) ((void)0)
+#define PBB_W(slot_) GSTAMP_W(a, slot_, 256)
+#endif
+#ifdef PBB_NOSB
+#define PBB_SB() ((void)0)
+#else
+#define PBB_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef PBB_DB
+#define PBB_DB 0         /* 1: the dW2 loop's A fragments fully double-buffered (measurement) */
+#endif
+#ifndef PBB_PRIME
+#define PBB_PRIME 16     /* step of the dW2 loop in front of which phase B's W2 ring is primed (16 = behind the loop) */
+#endif
 #ifndef PBB_X
 #define PBB_X 0      /* ablation mask of measurement builds (tools/pw_ablate.sh): the shipped kernel is PBB_X == 0 */
 #endif
@@ -1114,15 +1132,34 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
     for (int t = t0; t < ntiles; t += G, ++it) {
       const int* rowsC = sRows + (it & 3) * 64 + 32;          // this tile's rows, the slack row past the list (d h1 stores)
       const int* rowsN = sRows + ((it + 1) & 3) * 64;         // the next tile's rows
-      if (it == 5) { GSTAMP(a, 1); GSTAMP_W(a, 8, 256); }
+      if (it == 5) { GSTAMP(a, 1); PBB_W(8); }
       // ======== phase A ========
       // the slow requests of the next tile, first: its four h1 rows (LDS-DMA) and its d3 sources
       PBB_DMA_H1(rowsN);
+      PBB_T2(8);
       PBB_REQUEST_D3(rowsN);
+      PBB_T2(9);
       PBB_STAGE_IDS(t + 2 * G, (it + 2) & 3);
       PBB_LOAD_IDS(t + 3 * G);
+      PBB_T2(10);
       Bf3 bd2[2];
-      bool hm[16];
+      unsigned long long hm[16];                              // lane masks (scalar registers), one per accumulator register of phase B
+      {
+        PBB_LANE();
+        // the ReLU mask of d h1: positive h1 <=> its high term is non-zero (h1 >= 0); the wave's own block of H1F, slot t of k-step q = row
+        // crow(8 q + t, half) -- the register order of phase B's accumulators.  Sixteen lane masks in scalar registers for the length of
+        // the tile, applied by one v_cndmask each.  (Taken from the loop's own operand registers under `if (m == wave)` this
+        // compiled to ~400 scalar mask merges per tile; as sixteen `bool`s the compiler kept the eight fragment words in vector
+        // registers instead and spilled four of them.)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x4 hh = *reinterpret_cast<const u32x4*>(smb + PBB_H1F + lane * 4 + (q * 8 + wave) * 256);
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) { hm[8 * q + 2 * w4] = __ballot((hh[w4] & 0xffffu) != 0u); hm[8 * q + 2 * w4 + 1] = __ballot((hh[w4] >> 16) != 0u); }
+        }
+      }
+      constexpr int RD = PBB_RD;                              // depth of the W2 ring in k-steps
+      u32x4 rh[RD], rm[RD], rl[RD];
       {
         PBB_LANE();
         // ---- d2 = d3 . W3^T (this wave's 32 columns; W3's fragments were requested at the end of the previous phase B), masked by
@@ -1135,19 +1172,21 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
           da.l = PBB_LDS_Q(PBB_D3A + 2 * 2 * 64 * 4 + (q * 64 + lane) * 4);
           d2 = mma6(d2, da, w3q[q]);
         }
+        PBB_T2(11);
         float p_ = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d2[r] = h2r[r] > 0.f ? d2[r] : 0.f; p_ += d2[r]; }
         gb2 += p_;
+        PBB_T2(12);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           bd2[q] = split3_8(f32x4{d2[8 * q], d2[8 * q + 1], d2[8 * q + 2], d2[8 * q + 3]}, f32x4{d2[8 * q + 4], d2[8 * q + 5], d2[8 * q + 6], d2[8 * q + 7]});
-        __builtin_amdgcn_sched_barrier(0);
+        PBB_SB();
       }
-      if (it == 5) { GSTAMP(a, 2); GSTAMP_W(a, 9, 256); }
+      if (it == 5) { GSTAMP(a, 2); PBB_W(9); }
       {
         // ---- dW2 += h1^T . d2: 8 blocks x 2 k-steps of six products; the A fragments from LDS (high term a step ahead, the low and
-        // the middle term reloaded in place behind their last product); the ReLU mask of d h1 from the high terms of block `wave`.
+        // the middle term reloaded in place behind their last product).
         // Woven into its 16 steps, six of the 48 two-byte stores of d2's TRANSPOSE per step in the first eight (phase B's A operand:
         // the terms of (row, column 32 w + col) go to D2F[term][k-step][row], slot frag^-1(col)), then dW3 += h2^T . d3 (rows
         // [32 w, 32 w + 32) of W3: A = the h2 registers' terms, B = d3 with lane = column) and the next tile's h2 requests
@@ -1155,8 +1194,13 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
         const unsigned* hf = smb + PBB_H1F + lane * 4;
         unsigned short* sc_ = reinterpret_cast<unsigned short*>(smb + PBB_D2F) +
             ((2 * wave + (col >> 4)) * 1088 + ((col >> 2) & 1) * 544 + half * 64) / 2 + (col & 3) + 4 * ((col >> 3) & 1);
+#if PBB_DB
+        u32x4 ah[2], amv[2], alv[2];
+        ah[0] = *reinterpret_cast<const u32x4*>(hf); amv[0] = *reinterpret_cast<const u32x4*>(hf + PBB_H1F_T); alv[0] = *reinterpret_cast<const u32x4*>(hf + 2 * PBB_H1F_T);
+#else
         u32x4 ah[2], am, al;
         ah[0] = *reinterpret_cast<const u32x4*>(hf); am = *reinterpret_cast<const u32x4*>(hf + PBB_H1F_T); al = *reinterpret_cast<const u32x4*>(hf + 2 * PBB_H1F_T);
+#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int q = i >> 3, m = i & 7;
@@ -1176,45 +1220,62 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
             Bf3 db;
             db.h = PBB_LDS_Q(PBB_D3B + (q3 * 64 + lane) * 4); db.m = PBB_LDS_Q(PBB_D3B + 2 * 64 * 4 + (q3 * 64 + lane) * 4);
             db.l = PBB_LDS_Q(PBB_D3B + 2 * 2 * 64 * 4 + (q3 * 64 + lane) * 4);
-            __builtin_amdgcn_sched_barrier(0);
+            PBB_SB();
             aW3 = mma6(aW3, ha, db);
           }
           if (i == 11 && !(PBB_X & 32)) PBB_REQUEST_H2(rowsN);   // (the registers of h2(t) are free: the next tile's, a whole tile ahead)
-          __builtin_amdgcn_sched_barrier(0);
+          if (i == PBB_PRIME) {
+            // phase B's W2 ring is primed HERE, behind every slow request of the tile: the s_waitcnt in front of barrier A then
+            // allows exactly these 3 RD loads to be outstanding -- the h1 copies, h2 and the d3 sources, all older, have landed
+            const unsigned o_ = (unsigned)(wave * 16 * 64 + lane) * 16u;
+#pragma unroll
+            for (int k2 = 0; k2 < RD; ++k2) { rh[k2] = PBB_LDQ(w2d, o_ + 1024u * k2); rm[k2] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * k2); rl[k2] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * k2); }
+          }
+          PBB_SB();
+#if PBB_DB
+          if (i + 1 < 16) {
+            alv[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(hn + 2 * PBB_H1F_T); ah[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(hn);
+            amv[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(hn + PBB_H1F_T);
+          }
+          const u32x4 al = alv[i & 1], am = amv[i & 1];
+          aW2[m] = mfma_bf16(al, bd2[q].h, aW2[m]);
+          aW2[m] = mfma_bf16(ah[i & 1], bd2[q].l, aW2[m]);
+          aW2[m] = mfma_bf16(am, bd2[q].m, aW2[m]);
+          aW2[m] = mfma_bf16(am, bd2[q].h, aW2[m]);
+          aW2[m] = mfma_bf16(ah[i & 1], bd2[q].m, aW2[m]);
+          aW2[m] = mfma_bf16(ah[i & 1], bd2[q].h, aW2[m]);
+#else
           aW2[m] = mfma_bf16(al, bd2[q].h, aW2[m]);
           if (i + 1 < 16) al = *reinterpret_cast<const u32x4*>(hn + 2 * PBB_H1F_T);
           aW2[m] = mfma_bf16(ah[i & 1], bd2[q].l, aW2[m]);
           if (i + 1 < 16) ah[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(hn);
           aW2[m] = mfma_bf16(am, bd2[q].m, aW2[m]);
           aW2[m] = mfma_bf16(am, bd2[q].h, aW2[m]);
-          __builtin_amdgcn_sched_barrier(0);
+          PBB_SB();
           if (i + 1 < 16) am = *reinterpret_cast<const u32x4*>(hn + PBB_H1F_T);
           aW2[m] = mfma_bf16(ah[i & 1], bd2[q].m, aW2[m]);
           aW2[m] = mfma_bf16(ah[i & 1], bd2[q].h, aW2[m]);
-          if (m == wave) {       // (uniform: the wave's own block) positive h1 <=> its high term is non-zero; slot t of step q = row crow(8 q + t, half)
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-              hm[8 * q + 2 * w4] = (ah[i & 1][w4] & 0xffffu) != 0u;
-              hm[8 * q + 2 * w4 + 1] = (ah[i & 1][w4] >> 16) != 0u;
-            }
-          }
+#endif
         }
-        __builtin_amdgcn_sched_barrier(0);
+        PBB_SB();
       }
-      if (it == 5) { GSTAMP(a, 3); GSTAMP_W(a, 10, 256); }
-      // ---- end of phase A: the DMA copies have landed (everything older than them too), the W2 ring is primed, the workgroup meets
-      constexpr int RD = PBB_RD;                              // depth of the W2 ring in k-steps
-      u32x4 rh[RD], rm[RD], rl[RD];
-      {
+      if (it == 5) { GSTAMP(a, 3); PBB_W(10); }
+      // ---- end of phase A: the DMA copies have landed (vmcnt counts in order: at most the ring's 3 RD loads, the youngest
+      // requests, may still be on their way), the workgroup meets
+      if (PBB_PRIME < 16) {
+        static_assert(PBB_RD == 2 || PBB_RD == 3, "s_waitcnt immediate below");
+        if (PBB_RD == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        if (it == 5) { GSTAMP(a, 4); PBB_W(11); }
+      } else {
         PBB_LANE();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (it == 5) { GSTAMP(a, 4); GSTAMP_W(a, 11, 256); }
+        if (it == 5) { GSTAMP(a, 4); PBB_W(11); }
         const unsigned o_ = (unsigned)(wave * 16 * 64 + lane) * 16u;
 #pragma unroll
         for (int k = 0; k < RD; ++k) { rh[k] = PBB_LDQ(w2d, o_ + 1024u * k); rm[k] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * k); rl[k] = PBB_LDQ(w2d, 2 * W2D_T + o_ + 1024u * k); }
       }
       PBB_BARRIER();
-      if (it == 5) { GSTAMP(a, 5); GSTAMP_W(a, 12, 256); }
+      if (it == 5) { GSTAMP(a, 5); PBB_W(12); }
       // ======== phase B ========
       f32x16 acc = zero16();
       {
@@ -1230,7 +1291,7 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
           if (s == 3 && !(PBB_X & 8)) PBB_STAGE_D3(t + G);
           if (s == 6 && !(PBB_X & 4)) PBB_STAGE_H1();
           if (s == 13) PBB_LOAD_W3();                          // (behind the ring's last requests)
-          __builtin_amdgcn_sched_barrier(0);
+          PBB_SB();
           acc = mfma_bf16(dl, rh[s % RD], acc);
           if (s + 1 < 16) dl = *reinterpret_cast<const u32x4*>(dn + 2 * (PBB_D2F_TB / 4));
           acc = mfma_bf16(dh[s & 1], rl[s % RD], acc);
@@ -1238,22 +1299,29 @@ __global__ void __launch_bounds__(512) pw_bwd_bf(const PwBwdBfArgs aa) {
           if (s + 1 < 16) dh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(dn);
           acc = mfma_bf16(dm, rm[s % RD], acc);
           acc = mfma_bf16(dm, rh[s % RD], acc);
-          __builtin_amdgcn_sched_barrier(0);
+          PBB_SB();
           if (s + 1 < 16) dm = *reinterpret_cast<const u32x4*>(dn + PBB_D2F_TB / 4);
           acc = mfma_bf16(dh[s & 1], rm[s % RD], acc);
           if (s + RD < 16) rm[s % RD] = PBB_LDQ(w2d, W2D_T + o_ + 1024u * (s + RD));
           acc = mfma_bf16(dh[s & 1], rh[s % RD], acc);
           if (s + RD < 16) rh[s % RD] = PBB_LDQ(w2d, o_ + 1024u * (s + RD));
-          __builtin_amdgcn_sched_barrier(0);
+          PBB_SB();
         }
       }
-      if (it == 5) { GSTAMP(a, 6); GSTAMP_W(a, 13, 256); }
+      if (it == 5) { GSTAMP(a, 6); PBB_W(13); }
       // ---- the ReLU mask of d h1, its stores, the workgroup meets
+      // (inline asm is opaque to the hazard recogniser: the wait states between the last MFMA's write of the accumulators and a vector
+      // read of them -- the compiler puts s_nop 11 there for this MFMA -- are spelled out)
+      PBB_SB();
+      asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = (hm[r] || (PBB_X & 64)) ? acc[r] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        if (!(PBB_X & 64)) { float o_; asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(o_) : "v"(acc[r]), "s"(hm[r])); acc[r] = o_; }
+      }
+      PBB_SB();
       if (!(PBB_X & 16)) PBB_STORE_DH1(rowsC);
       PBB_BARRIER();
-      if (it == 5) { GSTAMP(a, 7); GSTAMP_W(a, 14, 256); }
+      if (it == 5) { GSTAMP(a, 7); PBB_W(14); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }

@@ -547,6 +547,9 @@ __device__ __forceinline__ u32x4 ldg_q(const unsigned* __restrict__ ubase, unsig
   return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ubase) + byte_off);
 }
 
+#ifndef PW3_X
+#define PW3_X 0           /* ablation mask of measurement builds: 1 = no h1 stores, 2 = no h2 stores (wrong results, durations only) */
+#endif
 #ifndef PW3_S_FC1
 #define PW3_S_FC1 9       /* k-step in front of which the next tile's fc1 is formed (5 / 9 / 12 / 13 measured: 1.38 / 1.35 / 1.40 / 1.41 ms) */
 #define PW3_S_W3 13       /* k-step in front of which fc3's weight fragments are re-requested (behind fc1: its registers are free then) */
@@ -623,7 +626,7 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
     h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[2], gv.z, h_, 0, 0, 0);                          \
     h_ = __builtin_amdgcn_mfma_f32_32x32x2f32(wgA[3], gv.w, h_, 0, 0, 0);                          \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) h_[r] = relu_bits(h_[r]);                       \
-    if (TRAINING) {                                                                                \
+    if (TRAINING && !(PW3_X & 1)) {                                                                \
       float* g_ = a.h1 + (size_t)(e0_) * D_H + 32 * wave;                                          \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) pw3_st4(g_, h_lo + 32u * g, make_float4(h_[4 * g], h_[4 * g + 1], h_[4 * g + 2], h_[4 * g + 3])); \
     }                                                                                              \
@@ -725,7 +728,7 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
     // ---- ReLU (the bias is in the chain), h2 rows, this wave's K = 32 slice of fc3 (two k-steps of the rectified accumulators, split in registers)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = relu_bits(acc[r]);
-    if (TRAINING) {
+    if (TRAINING && !(PW3_X & 2)) {
       float* d_ = a.h2 + (size_t)e0 * D_H + 32 * wave;          // (uniform; the lane's row and half: h_lo)
 #pragma unroll
       for (int g = 0; g < 4; ++g) pw3_st4(d_, h_lo + 32u * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));

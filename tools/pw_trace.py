@@ -44,3 +44,11 @@ for base, who in ((1, "wave 0"), (8, "wave 4")):
         print("   %-28s -> %-28s median %6.2f  p90 %6.2f us" % (nf[k], nf[k + 1], np.median(dt), np.percentile(dt, 90)))
     tot = d[:, base + 6] - d[:, base]
     print("   tile: median %.2f p90 %.2f us" % (np.median(tot), np.percentile(tot, 90)))
+if os.environ.get("PBB_TRACE2"):
+    d = buf.cpu().numpy().reshape(8192, 16).astype(np.float64) / 100.0
+    d = d[d[:, 0] > 0]
+    seq = [(1, "tile top"), (8, "DMA issued"), (9, "d3 sources requested"), (10, "ids staged / loaded"), (11, "d2 MFMAs issued"), (12, "mask + sums done"), (2, "split done (prep done)")]
+    print("phase A front, wave 0 (PBB_TRACE2):")
+    for (sa, na), (sb, nb) in zip(seq[:-1], seq[1:]):
+        dt = d[:, sb] - d[:, sa]
+        print("   %-26s -> %-26s median %6.2f p90 %6.2f us" % (na, nb, np.median(dt), np.percentile(dt, 90)))
