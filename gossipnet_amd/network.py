@@ -10,6 +10,7 @@ Same constructor, same input names (`get_batch_spec`), same output attribute nam
 device memory and streams.  There is no CPU fallback.
 """
 import ctypes as C
+import os
 import math
 import weakref
 
@@ -262,6 +263,9 @@ class Gnet(object):
         self.keep_edge_activations = False
         self._profiler = None
         self.transpose_after_forward = False     # (measurement switch: see _prepare_matching)
+        # the 280 MB of zeroing for the backward pass (d_pw, winner maps): beside the forward pass (False) or behind it, in front of
+        # the winner lists on the side stream (True).  GNET_ZERO_AFTER_FWD overrides (A/B runs).
+        self.zero_after_forward = os.environ.get("GNET_ZERO_AFTER_FWD", "0") == "1"
         self._batch = batch
         if batch is not None:
             self.feed(batch)
@@ -420,7 +424,7 @@ class Gnet(object):
                 if backward and not self.transpose_after_forward:
                     _lib.check(self._scoped("graph", ss, self._lib.gnet_graph_transpose, buf.row_ptr, buf.edge_c, buf.edge_n,
                                             shape.n_edge, buf.edge_t, ss), "gnet_graph_transpose")
-                if backward:     # the zeroing half of the backward preparation does not need the forward pass
+                if backward and not self.zero_after_forward:     # the zeroing half of the backward preparation does not need the forward pass
                     _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                                                C.byref(buf), 1, ss), "gnet_backward_prepare")
 
@@ -437,6 +441,9 @@ class Gnet(object):
             if self.transpose_after_forward and shape.n_edge > 0:
                 _lib.check(self._scoped("graph", ss, self._lib.gnet_graph_transpose, buf.row_ptr, buf.edge_c, buf.edge_n,
                                         shape.n_edge, buf.edge_t, ss), "gnet_graph_transpose")
+            if self.zero_after_forward and shape.n_edge > 0:
+                _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
+                                                           C.byref(buf), 1, ss), "gnet_backward_prepare")
             _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                                        C.byref(buf), 2, ss), "gnet_backward_prepare")
             self._bprep_done.record(self._side)

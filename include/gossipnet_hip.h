@@ -68,7 +68,11 @@ typedef struct gnet_shape {
   int64_t n_anno;
 } gnet_shape;
 
-/* Inputs = Gnet.get_batch_spec (network.py:131-146), concatenated over images. */
+/* Inputs = Gnet.get_batch_spec (network.py:131-146), concatenated over images.
+ * Precondition (the reference's data path checks the same: imdb/tools.py:99-110 validate_boxes): finite coordinates and scores,
+ * x2 > x1 and y2 > y1.  A zero-width or zero-height detection makes log(n_w / c_w) infinite; the FC kernels form their fp32
+ * products from exact three-term bf16 splits, and the split of +-inf is inf - inf = NaN -- the outputs of that image are
+ * then NaN (no fault). */
 typedef struct gnet_inputs {
   const float* dets;          /* [n_det,4] xyxy                        */
   const float* det_scores;    /* [n_det]                               */

@@ -431,3 +431,32 @@ def test_roi_pool_hostile_rois_do_not_fault(C):
     for det in (True, False):
         roi_pool_grad(torch.tensor(data, device=d), torch.tensor(rois, device=d), wild, g, P, P, 1.0, det)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("num_pwfeat_fc", [3, 0])
+def test_degenerate_boxes_do_not_fault(num_pwfeat_fc):
+    """Detections outside the stated precondition (include/gossipnet_hip.h gnet_inputs: positive width and height): a zero-width and a
+    zero-height box among ordinary ones, with the pw-MLP (3) and with the reference's default configuration (0: the raw geometry
+    columns -- log(n_w / c_w) = +-inf -- feed edge_fwd_w's three-term split directly: inf - inf = NaN).  Asserted: no fault, the step
+    completes, integer results stay in range, and an ordinary image run right afterwards on the same Gnet is untouched (bit for bit the
+    result of a fresh run)."""
+    from tests.util import make_pair, make_image
+    net, _ = make_pair(80, 2, num_pwfeat_fc=num_pwfeat_fc)
+    good = make_image(96, 80, seed=3)
+    net.run(good)
+    torch.cuda.synchronize()
+    want_pred, want_grads = net.prediction.clone(), net.grads.clone()
+    bad = make_image(96, 80, seed=4)
+    bad["dets"][5, 2] = bad["dets"][5, 0]            # zero width
+    bad["dets"][17, 3] = bad["dets"][17, 1]          # zero height
+    net.run(bad)
+    torch.cuda.synchronize()
+    E = int(net.num_edges)
+    pairs = net.neighbor_pair_idxs.cpu().numpy()
+    assert pairs.shape == (E, 2) and pairs.min() >= 0 and pairs.max() < 96
+    m = net.det_gt_matching.cpu().numpy()
+    assert m.min() >= -1 and m.max() < bad["gt_boxes"].shape[0]
+    assert net.prediction.shape[0] == 96                        # (values may be NaN: stated, and the reference's too)
+    net.run(good)
+    torch.cuda.synchronize()
+    assert torch.equal(net.prediction, want_pred) and torch.equal(net.grads, want_grads)
