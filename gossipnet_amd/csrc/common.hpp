@@ -200,8 +200,12 @@ static inline EdgeGeom edge_geom(int64_t E, int64_t N) {
 // ---- balanced contiguous ranges: n_items dealt to n_parts so that every part gets floor or ceil of the mean --------
 // part g owns [range_begin(g), range_begin(g + 1)); range_owner() is its inverse.  (Equal ceil-sized ranges leave the last
 // parts empty -- with the XCD-aware part numbering all of them on one XCD: edge_bwd_w ran on seven XCDs.)
+// floor(g n / parts) = g q + floor(g r / parts) with n = q parts + r: the same value in 32-bit arithmetic (0 <= g <= parts < 2^16 at every
+// call site).  A 64-bit division is a subroutine of ~150 scalar instructions here -- edge_fwd_w's front ran ~900 of them (2.2 us of every
+// launch) before its first request.
 __host__ __device__ __forceinline__ int range_begin(int g, int n_items, int n_parts) {
-  return (int)(((long long)g * n_items) / n_parts);
+  const unsigned q = (unsigned)n_items / (unsigned)n_parts, r = (unsigned)n_items - q * (unsigned)n_parts;
+  return (int)((unsigned)g * q + ((unsigned)g * r) / (unsigned)n_parts);
 }
 __host__ __device__ __forceinline__ int range_owner(int item, int n_items, int n_parts) {
   return (int)((((long long)item + 1) * n_parts - 1) / n_items);
@@ -222,9 +226,9 @@ __host__ __device__ __forceinline__ int efw_begin(int gw, int n_tiles, int n_wav
   if (!efw_layered(n_tiles, n_waves)) return range_begin(gw, n_tiles, n_waves);
   if (gw >= n_waves) return n_tiles;
   const int wpx = n_waves / 8, tw = wpx / 3;                 // waves per XCD, per layer of an XCD
-  const int x = gw / wpx, jx = gw - x * wpx, k = jx / tw, j = jx - k * tw;
+  const int x = (int)((unsigned)gw / (unsigned)wpx), jx = gw - x * wpx, k = (int)((unsigned)jx / (unsigned)tw), j = jx - k * tw;
   const int x0 = range_begin(x, n_tiles, 8), tx = range_begin(x + 1, n_tiles, 8) - x0;
-  const int b0 = x0 + (int)((long long)tx * efw_layer_cut(k) / 1000), b1 = x0 + (int)((long long)tx * efw_layer_cut(k + 1) / 1000);
+  const int b0 = x0 + (int)((unsigned)tx * (unsigned)efw_layer_cut(k) / 1000u), b1 = x0 + (int)((unsigned)tx * (unsigned)efw_layer_cut(k + 1) / 1000u);   // (tx < 2^17 at the edge limit)
   return b0 + range_begin(j, b1 - b0, tw);
 }
 __host__ __device__ __forceinline__ int efw_owner(int tile, int n_tiles, int n_waves) {
@@ -232,7 +236,7 @@ __host__ __device__ __forceinline__ int efw_owner(int tile, int n_tiles, int n_w
   const int wpx = n_waves / 8, tw = wpx / 3;
   const int x = range_owner(tile, n_tiles, 8);
   const int x0 = range_begin(x, n_tiles, 8), tx = range_begin(x + 1, n_tiles, 8) - x0;
-  const int c1 = x0 + (int)((long long)tx * efw_layer_cut(1) / 1000), c2 = x0 + (int)((long long)tx * efw_layer_cut(2) / 1000);
+  const int c1 = x0 + (int)((unsigned)tx * (unsigned)efw_layer_cut(1) / 1000u), c2 = x0 + (int)((unsigned)tx * (unsigned)efw_layer_cut(2) / 1000u);
   const int k = tile >= c2 ? 2 : tile >= c1 ? 1 : 0;
   const int b0 = k == 0 ? x0 : k == 1 ? c1 : c2, b1 = k == 0 ? c1 : k == 1 ? c2 : x0 + tx;
   return x * wpx + k * tw + range_owner(tile - b0, b1 - b0, tw);
@@ -332,11 +336,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Bf3 { u32x4 h, m, l; };       // eight values as three bf16 terms, packed in k-slot order (slot 0 in the low half of word 0)
 
 // the three terms of two values, packed (first value in the low halves)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef SPLIT3_PACKED
+#define SPLIT3_PACKED 0      /* the two remainders of a pair as ONE v_pk_add_f32 each (the same arithmetic: 9 instead of 11 instructions per pair) */
+#endif
 __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
   const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+#if SPLIT3_PACKED
+  const f32x2 r = f32x2{x0, x1} - f32x2{__uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+  const unsigned m0 = __float_as_uint(r.x), m1 = __float_as_uint(r.y);
+  const f32x2 q = r - f32x2{__uint_as_float(m0 & 0xffff0000u), __uint_as_float(m1 & 0xffff0000u)};
+  const float s0 = q.x, s1 = q.y;
+#else
   const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
   const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
   const float s0 = r0 - __uint_as_float(m0 & 0xffff0000u), s1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+#endif
   ph = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
   pm = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
   pl = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);

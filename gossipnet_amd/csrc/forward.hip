@@ -813,6 +813,12 @@ __device__ __forceinline__ void segmax_merge(float& m, unsigned& k, float m2, un
 }
 
 constexpr int EFW_WAVES = 4;      // waves per workgroup; 3 workgroups per CU (launch bounds below)
+#ifndef EFW_X
+#define EFW_X 0   /* ablation mask of measurement builds (WRONG results, durations only): 1 = no split of P, 2 = no split of h1, 4 = no hit bits, 8 = no ReLU / bias adds, 32 = no segment bookkeeping */
+#endif
+__device__ __forceinline__ Bf3 efw_fake3(const f32x4 a, const f32x4 b) {
+  Bf3 t; t.h = __builtin_bit_cast(u32x4, a); t.m = __builtin_bit_cast(u32x4, b); t.l = t.h; return t;
+}
 // the three terms of a lane's eight k-slots (16 bytes each, one term-stride apart)
 __device__ __forceinline__ Bf3 efw_w3(const unsigned* p, int tstride) {
   Bf3 t;
@@ -862,11 +868,17 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   //       and the rc rows of the first two centres;
   //   (3) weights -> LDS, barrier.  The gathers of (2) land during (3).
   int nx_c = -1, nx_nz = 0, c_before = -1;
+  int n2_c = -1, n2_nz = 0;                                            // the records of the tile after the next one (see the loop)
   f32x4 pa[4];
   const bool have_tiles = t0 < t1;
   if (have_tiles) {
     { const int e = t0 * 32 + col; if (e < a.n_edge) nx_c = a.edge_c[e]; }
     nx_nz = a.edge_nz[t0 * 32 + col];                                  // (the tail of edge_nz is padded)
+    {
+      const int e = t0 * 32 + 32 + col;
+      n2_c = a.edge_c[min(e, a.n_edge - 1)];
+      n2_nz = a.edge_nz[min(e, a.n_edge + 63)];
+    }
     if (t0 > 0) c_before = a.edge_c[t0 * 32 - 1];
     const float* ap = a.pw + (size_t)min(t0 * 32 + col, a.n_edge - 1) * D_E + 4 * half;
 #pragma unroll
@@ -933,10 +945,14 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
   bool head_shared = e_begin > 0 && c_before == cA;
   drain_vmem_before_loop();
   GSTAMP(a, 2);
+  // (trace builds: the phases of wave 0's FIFTH tile -- slot 3 top, 4 accumulator start (the rn / rc rows have arrived), 5 the next
+  //  tile's row requests issued (the P rows have arrived), 6 layer 1, 7 ReLU + layer 2, 8 bias / stores, 9 segment bookkeeping)
+#define EFW_STAMP(slot_) do { if (t - t0 == 4) GSTAMP(a, slot_); } while (0)
   for (int t = t0; t < t1; ++t) {
     const int e0 = t * 32;
     const int my_c = nx_c;
     const int nrows = min(32, a.n_edge - e0);
+    EFW_STAMP(3);
     const int thiA = hiA;
     // segment heads of THIS tile (bit r set = row r starts a new centre)
     unsigned heads;
@@ -948,9 +964,13 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     // rc rows of centres A / B -> LDS (this wave's 512 bytes), read back as the lane's own centre row
     if (lane < 32) *reinterpret_cast<float4*>(sRC + 4 * lane) = rcAB;
     // (uniform base + 32-bit byte offset: a 64-bit vector instruction per address is dear beside the MFMA stream)
-    nx_c = -1;
-    if (t + 1 < t1) { const int e = e0 + 32 + col; if (e < a.n_edge) nx_c = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * (unsigned)e); }
-    nx_nz = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_nz), 4u * (unsigned)(e0 + 32 + col));
+    // The edge records run TWO tiles ahead: the rows they address (rn, rc) are requested for the next tile right behind this tile's
+    // accumulator start, a whole tile before they are read.  (One tile ahead, the records were requested here and consumed by the
+    // gathers behind layer 1: a full memory round trip -- s_waitcnt vmcnt(0) -- in the middle of every tile's MFMA stream.)
+    // (the loads of the tile after that sit behind layer 1, in front of the P rows: unconditional -- clamped indices, the range test
+    // applied here -- so that the compiler's in-order vmcnt arithmetic is exact and no wait covers a request younger than its operand)
+    nx_c = (t + 1 < t1 && e0 + 32 + col < a.n_edge) ? n2_c : -1;
+    nx_nz = n2_nz;
     wave_lds_sync();
     f32x16 h1a, h1b;                                   // h1^T: lane = edge, register r = feature 8 (r >> 2) + 4 half + (r & 3) [+ 32]
     if (nseg <= 2) {                                   // centre rows were prefetched (A below thiA, B from it)
@@ -972,22 +992,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         h1b[4 * g + 0] = cb.x + rnv[4 + g].x; h1b[4 * g + 1] = cb.y + rnv[4 + g].y; h1b[4 * g + 2] = cb.z + rnv[4 + g].z; h1b[4 * g + 3] = cb.w + rnv[4 + g].w;
       }
     }
-    __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note behind layer 2)
-    {                                                   // layer 1 (transposed): A = Wp^T terms from LDS, B = the lane's P row, split here
-      const unsigned* w1p = sWpT + col * EFW_LD1 + half * 8;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const Bf3 pb = split3_8(pa[2 * j], pa[2 * j + 1]);
-        h1a = mma6(h1a, efw_w3(w1p + j * 4, EFW_T1), pb);
-        h1b = mma6(h1b, efw_w3(w1p + 32 * EFW_LD1 + j * 4, EFW_T1), pb);
-      }
-    }
-    // ---- prefetch for the next tile: P rows, neighbour rows, the first two centre rows
-    {
-      const unsigned po = (unsigned)min(e0 + 32 + col, a.n_edge - 1) * (D_E * 4u) + 16u * half;    // [E,32] fp32: < 2^31 bytes at the edge limit
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const float4 v_ = ldg4_b(a.pw, po + 32u * k); pa[k] = f32x4{v_.x, v_.y, v_.z, v_.w}; }
-    }
+    EFW_STAMP(4);
+    // ---- the next tile's neighbour rows and first two centre rows (their registers are free again)
 #pragma unroll
     for (int g = 0; g < 8; ++g) rnv[g] = ldg4_b(a.rn, (unsigned)nx_nz * (D_P * 4u) + 32u * g + 16u * half);
     {
@@ -997,6 +1003,33 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       if (hm) { hiA = __builtin_ctz(hm); cB = __builtin_amdgcn_readlane(nx_c, hiA); }
       rcAB = ldg4_b(a.rc, (unsigned)max((lane & 16) ? cB : cA, 0) * (D_P * 4u) + 16u * (lane & 15));
     }
+    EFW_STAMP(5);
+    __builtin_amdgcn_s_setprio(0);     // (the MFMA section: see the note behind layer 2)
+    {                                                   // layer 1 (transposed): A = Wp^T terms from LDS, B = the lane's P row, split here
+      const unsigned* w1p = sWpT + col * EFW_LD1 + half * 8;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const Bf3 pb = (EFW_X & 1) ? efw_fake3(pa[2 * j], pa[2 * j + 1]) : split3_8(pa[2 * j], pa[2 * j + 1]);
+        h1a = mma6(h1a, efw_w3(w1p + j * 4, EFW_T1), pb);
+        h1b = mma6(h1b, efw_w3(w1p + 32 * EFW_LD1 + j * 4, EFW_T1), pb);
+      }
+    }
+    // ---- the records of the tile after the next one, the next tile's P rows (pinned here: the scheduler otherwise sinks the requests
+    // to the end of layer 2 -- half a tile less for the P rows to arrive)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const unsigned e2 = (unsigned)(e0 + 64 + col);
+      n2_c = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_c), 4u * min(e2, (unsigned)(a.n_edge - 1)));
+      n2_nz = (int)ldg_b(reinterpret_cast<const unsigned*>(a.edge_nz), 4u * min(e2, (unsigned)(a.n_edge + 63)));   // (padded: 64 rows of n_det)
+    }
+    {
+      const unsigned po = (unsigned)min(e0 + 32 + col, a.n_edge - 1) * (D_E * 4u) + 16u * half;    // [E,32] fp32: < 2^31 bytes at the edge limit
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float4 v_ = ldg4_b(a.pw, po + 32u * k); pa[k] = f32x4{v_.x, v_.y, v_.z, v_.w}; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    EFW_STAMP(6);
+    if (!(EFW_X & 8))
 #pragma unroll
     for (int r = 0; r < 16; ++r) { h1a[r] = relu_bits(h1a[r]); h1b[r] = relu_bits(h1b[r]); }
     if (KEEP) {
@@ -1015,7 +1048,8 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       for (int j = 0; j < 4; ++j) {
         const f32x16& hs = j < 2 ? h1a : h1b;
         const int r0 = 8 * (j & 1);
-        const Bf3 ha = split3_8(f32x4{hs[r0], hs[r0 + 1], hs[r0 + 2], hs[r0 + 3]}, f32x4{hs[r0 + 4], hs[r0 + 5], hs[r0 + 6], hs[r0 + 7]});
+        const Bf3 ha = (EFW_X & 2) ? efw_fake3(f32x4{hs[r0], hs[r0 + 1], hs[r0 + 2], hs[r0 + 3]}, f32x4{hs[r0 + 4], hs[r0 + 5], hs[r0 + 6], hs[r0 + 7]})
+                                   : split3_8(f32x4{hs[r0], hs[r0 + 1], hs[r0 + 2], hs[r0 + 3]}, f32x4{hs[r0 + 4], hs[r0 + 5], hs[r0 + 6], hs[r0 + 7]});
         h2a = mma6(h2a, ha, efw_w3(w2p + j * 4, EFW_T2));
         h2b = mma6(h2b, ha, efw_w3(w2p + 32 * EFW_LD2 + j * 4, EFW_T2));
       }
@@ -1023,13 +1057,14 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
     // The segment bookkeeping (and the top of the next tile, up to its first MFMA) runs at a raised wave priority: the three
     // waves of a SIMD are at unrelated points of their tiles, and a wave in its vector section that gets its issue slots
     // ahead of the others' MFMA streams is back in its own MFMA section sooner (-1 %; raising the MFMA section instead: +-0).
+    EFW_STAMP(7);
     __builtin_amdgcn_s_setprio(1);
     // pre-activations; relu is monotone, so max(relu(v)) = relu(max(v)): rectify once per segment.  The
     // tie count is the number of rows equal to the maximum (when the maximum is <= 0 every gradient through
     // it is zero and only count >= 1 matters).
     // (forward only: rounding is monotone, so max_r fl(h_r + b) = fl(max_r h_r + b) -- the bias is added to the segment's maximum;
     //  a training pass counts ties on the biased values, which two different raw values can share)
-    if (TRAIN) {
+    if (TRAIN && !(EFW_X & 8)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { h2a[r] += bias0; h2b[r] += bias1; }
     }
@@ -1039,9 +1074,11 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dst[crow(r, half) * D_P] = h2a[r]; dst[crow(r, half) * D_P + 32] = h2b[r]; }
     }
+    EFW_STAMP(8);
     // ---- wave-uniform segment loop
     unsigned hleft = heads;
     const bool whole = nseg == 1 && nrows == 32;       // one centre fills the tile: no row masks
+    if (EFW_X & 32) { asm volatile("" :: "v"(h2a), "v"(h2b)); hleft = 0; }
     while (hleft) {
       const int lo = __builtin_ctz(hleft);
       hleft &= hleft - 1;
@@ -1051,14 +1088,14 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
       // hits of this lane's rows, one bit per accumulator slot (bit r = slot r attains the segment maximum): built
       // by b = 2 b + hit from slot 15 down (one compare + one add-with-carry per element); the tie count is its
       // population count, the arg-max slot its lowest set bit
-      unsigned b0 = 0, b1 = 0;
+      unsigned b0 = (EFW_X & 4) ? 1u : 0u, b1 = b0;
       if (whole) {
         s0 = h2a[0]; s1 = h2b[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) { s0 = fmaxf(s0, h2a[r]); s1 = fmaxf(s1, h2b[r]); }
         s0 = half_fmax(s0);
         s1 = half_fmax(s1);
-        if (TRAIN) {                                    // (forward only: nobody reads the tie count or the arg-max)
+        if (TRAIN && !(EFW_X & 4)) {                    // (forward only: nobody reads the tie count or the arg-max)
 #pragma unroll
           for (int r = 15; r >= 0; --r) {
             hit_bit(b0, h2a[r], s0);
@@ -1090,7 +1127,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         }
         s0 = half_fmax(s0);
         s1 = half_fmax(s1);
-        if (TRAIN)
+        if (TRAIN && !(EFW_X & 4))
 #pragma unroll
         for (int g = 3; g >= 0; --g) {
           if (8 * g + 8 <= lo || 8 * g >= hi) { b0 <<= 4; b1 <<= 4; continue; }
@@ -1121,6 +1158,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         a1 = b1 ? ebase + r1 + (r1 & 12) : a1;
         a0 = half_min(a0);
         a1 = half_min(a1);
+        if (EFW_X) { a0 = min(a0, a.n_edge - 1); a1 = min(a1, a.n_edge - 1); }   // (measurement builds: garbage maxima may have no hit)
       }
       if (!TRAIN) { s0 += bias0; s1 += bias1; }
       s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
@@ -1149,7 +1187,7 @@ __global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArg
         cur = cseg; m0 = s0; k0 = q0; m1 = s1; k1 = q1; g0 = a0; g1 = a1;
       }
     }
-    GSTAMP(a, 3 + (t - t0));
+    EFW_STAMP(9);
   }
   if (cur >= 0) {
     // the last centre may continue in the next wave's range

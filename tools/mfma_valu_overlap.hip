@@ -2,6 +2,9 @@
 //   mode 1: MFMA only      mode 2: VALU only      mode 3: both in one wave's loop
 //   mode 4: 8-wave workgroups, waves 0-3 MFMA only, waves 4-7 VALU only (two waves per SIMD)
 //   mode 5: 8-wave workgroups, every wave alternates a pure MFMA phase and a pure VALU phase
+//   mode 6: as 5, with a bare s_barrier behind every phase and waves 4-7 started ONE PHASE LATE: the two waves of a SIMD are
+//           held in anti-phase (one in its MFMA phase while the other is in its vector phase); mode 7: the same with the
+//           MFMA phase at wave priority 3; mode 8: barriers but NO offset (both waves of a SIMD in the same phase: the control)
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o gpurun_out/overlap
 //        (-DBF16PIPE: the same with v_mfma_f32_32x32x16_bf16, 32 cycles, in place of the fp32 MFMA's 64)
 #include <hip/hip_runtime.h>
@@ -37,7 +40,21 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters, int mode, lo
   const bool split = mode == 4;
   const bool do_m = mode == 1 || mode == 3 || (split && wave < 4);
   const bool do_v = mode == 2 || mode == 3 || (split && wave >= 4);
-  if (mode == 5) {
+  if (mode >= 6) {
+    const bool late = mode != 8 && wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < iters; ++it) {
+      if (mode == 7) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int j = 0; j < NM; ++j) { MFMA(acc0); }
+      if (mode == 7) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { VALU8(x); }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (mode != 8 && wave < 4) __builtin_amdgcn_s_barrier();
+  } else if (mode == 5) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int j = 0; j < NM; ++j) { MFMA(acc0); }
@@ -98,8 +115,16 @@ int main() {
   run<16, 16>("3 interleaved, 2 waves/SIMD", 3, 512, out);
   run<16, 16>("4 split: waves 0-3 MFMA, 4-7 VALU", 4, 512, out);
   run<16, 16>("5 phases MFMA then VALU, 2 waves/SIMD", 5, 512, out);
+  run<16, 16>("6 anti-phase by barriers, 2 waves/SIMD", 6, 512, out);
+  run<16, 16>("7 anti-phase + MFMA phase at priority 3", 7, 512, out);
+  run<16, 16>("8 barriers, same phase (control)", 8, 512, out);
   run<16, 32>("3 interleaved, 2 waves/SIMD", 3, 512, out);
   run<16, 32>("4 split: waves 0-3 MFMA, 4-7 VALU", 4, 512, out);
   run<16, 32>("5 phases MFMA then VALU, 2 waves/SIMD", 5, 512, out);
+  run<16, 32>("6 anti-phase by barriers, 2 waves/SIMD", 6, 512, out);
+  run<16, 32>("7 anti-phase + MFMA phase at priority 3", 7, 512, out);
+  run<16, 32>("8 barriers, same phase (control)", 8, 512, out);
+  run<16, 8>("5 phases MFMA then VALU, 2 waves/SIMD", 5, 512, out);
+  run<16, 8>("6 anti-phase by barriers, 2 waves/SIMD", 6, 512, out);
   return 0;
 }
