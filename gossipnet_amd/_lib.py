@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 from .build import LIB as LIB_PATH     # libgossipnet_hip.so (a GNET_TRACE / GNET_EXTRA_FLAGS measurement process: its own probe library)
 GNET_MAX_BLOCKS = 64
-ABI_VERSION = 7          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
+ABI_VERSION = 8          # include/gossipnet_hip.h GNET_ABI_VERSION: the struct mirrors below belong to this version
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = 0, -1, -2, -3, -4
 _ERR = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported configuration",
@@ -161,7 +161,7 @@ def _bind(lib):
     lib.gnet_match_prepare.restype = C.c_int
     lib.gnet_match_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), P(gnet_buffers), vp]
     lib.gnet_backward.restype = C.c_int
-    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, C.c_int32, vp, vp]
+    lib.gnet_backward.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), vp, C.c_int32, vp, vp, vp]
     lib.gnet_backward_prepare.restype = C.c_int
     lib.gnet_backward_prepare.argtypes = [P(gnet_config), P(gnet_shape), P(gnet_inputs), vp, P(gnet_buffers), C.c_int32, vp]
     lib.det_matching_workspace_bytes.restype = sz

@@ -1653,12 +1653,13 @@ extern "C" int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* s
   }
   if (phase == 1) return GNET_OK;
   // winner maps / lists of ALL blocks (they depend on the forward pass only: off the backward chain)
-  return edge_stage_prepare(cfg, shape, make_layout(cfg), params, buf, s);
+  if (phase < 0 || phase > 3) return GNET_ERR_INVALID;
+  return edge_stage_prepare(cfg, shape, make_layout(cfg), params, buf, s, phase == 2 ? 1 : phase == 3 ? 2 : 0);
 }
 
 extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                              const float* params, gnet_buffers* buf, float* grads, int32_t prepared,
-                             void* prepared_event, gnet_stream_t stream) {
+                             void* prepared_event, void* positions_event, gnet_stream_t stream) {
   clear_hip_error();
   if (!config_supported(cfg)) return GNET_ERR_UNSUPPORTED;
   if (!shape || !in || !params || !buf || !grads) return GNET_ERR_INVALID;
@@ -1724,6 +1725,10 @@ extern "C" int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, co
     BlkNodeArgs n;
     n.n_det = N; n.do_pre = b <= B; n.do_post = b >= 2; n.want_dx0 = (b == 1 && buf->start_feat) ? 1 : 0;
     n.d_rc = E > 0 ? buf->d_rc : nullptr; n.d_rn = E > 0 ? buf->d_rn : nullptr;
+    if (b == B && E > 0 && prepared && positions_event) {
+      // first use of the reversed pairs' list positions (phase 3 of the preparation: it ran beside the first edge_bwd_w)
+      HIP_CHECK_RET(hipStreamWaitEvent(s, (hipEvent_t)positions_event, 0));
+    }
     if (b <= B && E > 0) {
       GNET_LAUNCH(prof, GNET_K_GATHER, s, gather_winners<<<(N + 3) / 4, 256, 0, s>>>(
           buf->d_g1, buf->row_ptr, buf->wrow + (size_t)(b - 1) * G.tf_stride, buf->tpos + (size_t)(b - 1) * G.wl_stride, N,

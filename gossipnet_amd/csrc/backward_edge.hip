@@ -498,8 +498,12 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   } while (0)
   // bias rows rc[c], rn[n] as the lane's own sixteen 16-byte pieces (lane = row, features 8 g + 4 half .. + 3 and + 32) and its
   // P row (B layout) of the tile whose records are in nx_e / nx_c / nx_nz: all twenty requests in flight together
+#ifndef EBW_X
+#define EBW_X 0   /* measurement builds (WRONG results, durations only): 1 = every tile gathers the rows of the wave's FIRST tile (cache hits: what a perfect prefetch of the bias / P rows would buy) */
+#endif
 #define EBW_LOAD_TILE(bx, by, bpa)                                                                      \
   do {                                                                                                  \
+    if (EBW_X & 1) { nx_e = first_e; nx_c = first_c; nx_nz = first_nz; }                                \
     const unsigned po_ = (unsigned)nx_e * (D_E * 4u) + 16u * half;                                      \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { const float4 v_ = ldg4_b(a.pw, po_ + 32u * k_); bpa[k_] = f32x4{v_.x, v_.y, v_.z, v_.w}; } \
     const unsigned oc_ = (unsigned)max(nx_c, 0) * (D_P * 4u) + 16u * half, on_ = (unsigned)nx_nz * (D_P * 4u) + 16u * half; \
@@ -527,6 +531,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   float4 fx[8], fy[8];
   f32x4 fpa[4];
   const int first_e = nx_e;
+  const int first_c = nx_c, first_nz = nx_nz;      // (measurement builds only: EBW_X)
   if (have_tiles) { EBW_LOAD_TILE(fx, fy, fpa); EBW_LOAD_BIAS(); }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -855,8 +860,10 @@ int edge_stage_clear(const gnet_config* cfg, const gnet_shape* shape, gnet_buffe
   return GNET_OK;
 }
 
+// part 0 = everything; 1 = what the edge kernels read (maps, lists, arg-max positions); 2 = what only gather_winners reads (the
+// reversed pairs' list positions): the second part is off the chain in front of the first edge_bwd_w (80 of 275 us at the bench batch)
 int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const ParamLayout& L, const float* params,
-                       gnet_buffers* buf, hipStream_t s) {
+                       gnet_buffers* buf, hipStream_t s, int part) {
   const int B = cfg->num_blocks, N = shape->n_det, E = (int)shape->n_edge;
   const EdgeGeom G = edge_geom(E, N);
   void* prof = buf->profiler;
@@ -874,14 +881,17 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
     w.rc[b - 1] = buf->blk_rc[b]; w.rn[b - 1] = buf->blk_rn[b];
     w.w1t[b - 1] = pt + packed_w1_off(L, b); w.w2t[b - 1] = pt + L.blk[b].w2; w.b2[b - 1] = params + L.blk[b].b2;
   }
+  if (part != 2) {
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_mark<<<dim3(min((N + 3) / 4, 1024), B), 256, 0, s>>>(w));
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winners_ties<<<dim3(16, B), 256, 0, s>>>(w));
+  }
   ListArgs l;
   l.n_words = (int)G.n_words; l.n_edge = E; l.n_wg = (int)G.n_wg; l.n_lists = B + 1;
   l.bm_stride = (long long)G.bm_stride; l.wl_stride = (long long)G.wl_stride;
   l.bits = (const unsigned long long*)buf->ewin;
   l.wg_count = buf->rl_scratch; l.wg_off = buf->rl_scratch + (size_t)(B + 1) * G.n_wg;
   l.rows = buf->wlist; l.rows_any = buf->pw_rows; l.wprefix = buf->wprefix;
+  if (part != 2) {
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, ewin_or<<<(int)((G.n_words + 255) / 256), 256, 0, s>>>((unsigned long long*)buf->ewin, (long long)G.bm_stride, B, (int)G.n_words));
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, list_count<<<dim3((unsigned)G.n_wg, B + 1), 256, 0, s>>>(l));
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, list_scan<<<B + 1, 1024, 0, s>>>(l));
@@ -892,6 +902,8 @@ int edge_stage_prepare(const gnet_config* cfg, const gnet_shape* shape, const Pa
   p.tflag = (const unsigned char*)buf->tflag; p.tf_stride = (long long)G.tf_stride;
   for (int b = 1; b <= B; ++b) p.parg[b - 1] = (const unsigned long long*)buf->blk_parg[b];
   GNET_LAUNCH(prof, GNET_K_WINNERS, s, winner_positions<<<dim3(min((N * D_P + 255) / 256, 1024), B), 256, 0, s>>>(p));
+  }
+  if (part == 1) return GNET_OK;
   TposArgs t;
   t.n_det = N; t.n_edge = E; t.bm_stride = (long long)G.bm_stride; t.wl_stride = (long long)G.wl_stride; t.tf_stride = (long long)G.tf_stride;
   t.ewin = (const unsigned long long*)buf->ewin; t.wprefix = buf->wprefix;

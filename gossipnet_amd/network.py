@@ -433,7 +433,7 @@ class Gnet(object):
         side stream while the main stream runs the matching, the loss and the head's backward."""
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_bprep_done", None) is None:
-            self._fwd_done, self._bprep_done = torch.cuda.Event(), torch.cuda.Event()
+            self._fwd_done, self._bprep_done, self._bpos_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self._fwd_done.record(main)
         self._side.wait_event(self._fwd_done)
         with torch.cuda.stream(self._side):
@@ -444,9 +444,14 @@ class Gnet(object):
             if self.zero_after_forward and shape.n_edge > 0:
                 _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                                            C.byref(buf), 1, ss), "gnet_backward_prepare")
+            # two pieces, an event behind each: what the edge kernels read (awaited in front of the first edge_bwd_w), then the
+            # reversed pairs' list positions (awaited in front of the first gather_winners: they are built beside that edge kernel)
             _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                                        C.byref(buf), 2, ss), "gnet_backward_prepare")
             self._bprep_done.record(self._side)
+            _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
+                                                       C.byref(buf), 3, ss), "gnet_backward_prepare")
+            self._bpos_done.record(self._side)
 
     def _mode(self, training):
         """`training` argument of the C ABI: 0 inference, 1 training, 2 training + per-block pw_fc1 activations kept."""
@@ -514,7 +519,8 @@ class Gnet(object):
                     self._grads_busy = None
                 # (the main stream waits for the winner lists inside gnet_backward, where they are first needed)
                 _lib.check(lib.gnet_backward(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
-                                             C.byref(buf), _vp(self.grads), 1, C.c_void_p(self._bprep_done.cuda_event), s),
+                                             C.byref(buf), _vp(self.grads), 1, C.c_void_p(self._bprep_done.cuda_event),
+                                             C.c_void_p(self._bpos_done.cuda_event), s),
                            "gnet_backward")
                 if self._imfeats:
                     if db.empty:

@@ -227,10 +227,14 @@ int gnet_match_prepare(const gnet_config* cfg, const gnet_shape* shape, const gn
  * Limits: n_edge <= 2^24 - 128 (32-bit byte offsets into [E,64] fp32 arrays; GNET_ERR_UNSUPPORTED beyond). */
 int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                   const float* params, gnet_buffers* buf, float* grads, int32_t prepared, void* prepared_event,
-                  gnet_stream_t stream);
+                  void* positions_event, gnet_stream_t stream);
 /* prepared_event (hipEvent_t or NULL, only with prepared = 1): recorded by the caller behind gnet_backward_prepare on
  * its stream.  gnet_backward makes `stream` wait for it where the prepared data is first needed -- after the head's
- * and the last block's node kernels, which need none of it -- instead of the caller waiting before the call. */
+ * and the last block's node kernels, which need none of it -- instead of the caller waiting before the call.
+ * positions_event (hipEvent_t or NULL, only with prepared = 1): for a caller that ran the preparation in two pieces -- phase 2,
+ * prepared_event recorded behind it, then phase 3, positions_event behind that.  gnet_backward waits for it in front of the
+ * first gather_winners, the first reader of phase 3's output: phase 3 then runs beside the last block's edge kernel instead of
+ * in front of it.  NULL: prepared_event covers everything (phases 0 or 2 + 3 in front of it). */
 
 /* The part of gnet_backward that depends on the forward pass only, not on the loss: the SegmentMax winner maps and
  * row lists of every block, and the zeroed d_pw accumulator.  A caller may run it on another stream once
@@ -239,8 +243,9 @@ int gnet_backward(const gnet_config* cfg, const gnet_shape* shape, const gnet_in
 int gnet_backward_prepare(const gnet_config* cfg, const gnet_shape* shape, const gnet_inputs* in,
                           const float* params, gnet_buffers* buf, int32_t phase, gnet_stream_t stream);
 /* phase 0 = everything (after gnet_forward); 1 = only the fills (d_pw and the winner maps zeroed, tpos set to -1:
- * independent of the forward pass, may run beside it); 2 = only the forward-dependent part (after gnet_forward and
- * after phase 1). */
+ * independent of the forward pass, may run beside it); 2 = the forward-dependent part the edge kernels read (winner maps, row
+ * lists, arg-max list positions; after gnet_forward and after phase 1); 3 = the rest of the forward-dependent part (the reversed
+ * pairs' list positions, read by gather_winners only; after phase 2).  0 = 1 + 2 + 3. */
 
 /* ---- training step around the path (train.py:64-77: slim create_train_op with Adam / Momentum) --------
  * All buffers are flat fp32 of n = gnet_param_count elements (device).  grad_scale multiplies the
@@ -334,7 +339,7 @@ const char* gnet_version(void);
  * offsetof(gnet_buffers, match_ws_bytes), offsetof(gnet_buffers, start_feat) and returns GNET_KCLASS_COUNT.
  * A binding compares both with its own mirror before the first call and refuses to go on when they differ
  * (a shifted gnet_buffers would hand the kernels wrong device pointers without any error). */
-#define GNET_ABI_VERSION 7
+#define GNET_ABI_VERSION 8
 int gnet_abi_version(void);
 int gnet_abi_sizes(size_t out[8]);
 
