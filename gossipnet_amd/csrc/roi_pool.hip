@@ -21,6 +21,7 @@
 //              not always: its in-ROI / feasible-bin tests (:405-431) drop a pooled element whose arg-max pixel lies one
 //              past the rounded ROI end (ceil((pw + 1) * bin) can exceed the ROI width in float) -- the default kernel
 //              reproduces the reference bit for bit, the atomic one does not in those cases.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -130,6 +131,9 @@ __global__ void __launch_bounds__(256) roi_pool_fwd(const float* __restrict__ da
 // Pixels of a bin are visited in the reference's order (h, then w; strict >: the first maximum wins): top / argmax bit-exact.
 // (C = 256, 512, 1024, 2048 -- the usual trunk widths: 8 / C256 XCDs per 256-channel slice, C a compile-time constant of the
 //  address arithmetic)
+#ifndef ROI_X
+#define ROI_X 0   /* ablation mask of measurement builds (WRONG results, durations only): 1 = no arg-max tracking (values only), 2 = no loads (the window walk and compares on a constant), 4 = no stores, 8 = no compares at all */
+#endif
 template <int C>
 __global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict__ data, int B, int H, int W,
                                                          const float* __restrict__ rois, int nrows, int PH, int PW,
@@ -173,21 +177,133 @@ __global__ void __launch_bounds__(256) roi_pool_fwd_rows(const float* __restrict
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           pb[q] = p + q < npix ? (hq[q] * W + wq[q]) * C : last;
-          v[q] = ldg4_b(img + pb[q], lane_b);
+          if (ROI_X & 2) { const float f_ = __int_as_float(pb[q] + lane); v[q] = make_float4(f_, f_, f_, f_); }
+          else v[q] = ldg4_b(img + pb[q], lane_b);
           wq[q] += 4;
           while (wq[q] >= wend) { wq[q] -= bw; ++hq[q]; }     // (scalar; measured: a branch-free select chain here is slower -- the kernel is issue-bound)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if (ROI_X & 8) { mv.x += v[q].x; mv.y += v[q].y; mv.z += v[q].z; mv.w += v[q].w; }
+          else if (ROI_X & 1) { mv.x = fmaxf(mv.x, v[q].x); mv.y = fmaxf(mv.y, v[q].y); mv.z = fmaxf(mv.z, v[q].z); mv.w = fmaxf(mv.w, v[q].w); }
+          else {
           if (v[q].x > mv.x) { mv.x = v[q].x; mi.x = pb[q]; }
           if (v[q].y > mv.y) { mv.y = v[q].y; mi.y = pb[q]; }
           if (v[q].z > mv.z) { mv.z = v[q].z; mi.z = pb[q]; }
           if (v[q].w > mv.w) { mv.w = v[q].w; mi.w = pb[q]; }
+          }
         }
       }
       mi.x = mi.x < 0 ? -1 : mi.x + cbase; mi.y = mi.y < 0 ? -1 : mi.y + cbase + 1;
       mi.z = mi.z < 0 ? -1 : mi.z + cbase + 2; mi.w = mi.w < 0 ? -1 : mi.w + cbase + 3;
     }
+    if ((ROI_X & 4) && mv.x != 12345.f) continue;
+    *reinterpret_cast<float4*>(top + out) = mv;
+    *reinterpret_cast<int4*>(argmax + out) = mi;
+  }
+}
+
+// roi_pool_fwd_rows2 (round 6): the same decomposition with the SCALAR unit taken out of the pixel loop.  A CU has ONE scalar ALU for
+// its four SIMDs, and roi_pool_fwd_rows spent ~15 scalar instructions per window pixel on its four (h, w) walkers, tail tests and address
+// arithmetic: measured (tools/roi_ablate.sh), the kernel without its loads AND without its stores still took 250 of 368 us -- 115 k scalar
+// instructions per SIMD = 460 k per CU at one per cycle.  Here a bin's window is walked row by row with the row's width a COMPILE-TIME
+// constant (a wave-uniform switch per bin, widths 1-8; wider windows in steps of eight with a clamped tail): the loads of a row are buffer
+// loads whose per-pixel offsets are the constants k * 4 C in the scalar-offset operand, the row's position is ONE vector add into the lane
+// offset and the arg-max candidates are one vector add each -- per row one scalar add and the loop test.  Pixels in the reference's order
+// (h, then w; strict >): top / argmax bit-exact.
+template <int C, int BW>
+__device__ __forceinline__ void roi_row_steps(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int idx, int rows, unsigned row_bytes, int row_idx, float4& mv, int4& mi) {
+  for (int h = 0; h < rows; ++h, voff += row_bytes, idx += row_idx) {
+    float4 v[BW];
+#pragma unroll
+    for (int k = 0; k < BW; ++k) {
+      if (ROI_X & 2) { const float f_ = __int_as_float((int)voff + k); v[k] = make_float4(f_, f_, f_, f_); continue; }
+      const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, k * C * 4, 0);
+      v[k] = __builtin_bit_cast(float4, q);
+    }
+#pragma unroll
+    for (int k = 0; k < BW; ++k) {
+      const int cand = idx + k * C;
+      if (ROI_X & 8) { mv.x += v[k].x; mv.y += v[k].y; mv.z += v[k].z; mv.w += v[k].w; continue; }
+      if (ROI_X & 1) { mv.x = fmaxf(mv.x, v[k].x); mv.y = fmaxf(mv.y, v[k].y); mv.z = fmaxf(mv.z, v[k].z); mv.w = fmaxf(mv.w, v[k].w); continue; }
+      if (v[k].x > mv.x) { mv.x = v[k].x; mi.x = cand; }
+      if (v[k].y > mv.y) { mv.y = v[k].y; mi.y = cand; }
+      if (v[k].z > mv.z) { mv.z = v[k].z; mi.z = cand; }
+      if (v[k].w > mv.w) { mv.w = v[k].w; mi.w = cand; }
+    }
+  }
+  // (the 16-byte stores behind the loop want four consecutive registers: without this the allocator keeps a SECOND, consecutive copy of
+  //  the running maxima up to date inside the loop -- four more selects per pixel)
+  asm volatile("" : "+v"(mv.x), "+v"(mv.y), "+v"(mv.z), "+v"(mv.w));
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) roi_pool_fwd_rows2(const float* __restrict__ data, int B, int H, int W,
+                                                          const float* __restrict__ rois, int nrows, int PH, int PW,
+                                                          float scale, float* __restrict__ top, int* __restrict__ argmax) {
+  constexpr int XPS = 8 / (C / 256);                          // XCDs per slice
+  static_assert(C % 256 == 0 && XPS >= 1 && XPS * (C / 256) == 8, "1, 2, 4 or 8 slices");
+  const int lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, slice = xcd / XPS;
+  const int row = ((int)(blockIdx.x >> 3) * XPS + (xcd % XPS)) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (row >= nrows) return;
+  const int ph = row % PH, r = row / PH;
+  const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
+  int hstart = (int)floorf(ph * b.bin_h), hend = (int)ceilf((ph + 1) * b.bin_h);
+  hstart = min(max(hstart + b.start_h, 0), H); hend = min(max(hend + b.start_h, 0), H);
+  // (the window bounds come out of float instructions, i.e. vector registers: made provably uniform here, or the row loop's counter and
+  //  exit test stay in vector registers and the compiler keeps a second copy of the running maxima for the "divergent" exit)
+  hstart = __builtin_amdgcn_readfirstlane(hstart); hend = __builtin_amdgcn_readfirstlane(hend);
+  const bool no_image = b.batch < 0 || b.batch >= B;     // (undefined in the reference; here such a ROI pools nothing)
+  if (no_image) hend = hstart;
+  // the image's channel slice as a buffer: wave-uniform base (two readfirstlanes make that provable: no waterfall loop around the loads)
+  const float* img = data + (size_t)(no_image ? 0 : b.batch) * C * H * W + 256 * slice;
+  const unsigned long long ib = reinterpret_cast<unsigned long long>(img);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ib), hi = __builtin_amdgcn_readfirstlane((unsigned)(ib >> 32));
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                                        (int)(((unsigned)H * W * C - 256u * slice) * 4u), 0x00020000);
+  const unsigned lane_b = 16u * lane;
+  const int cbase = 256 * slice + 4 * lane;
+  const unsigned row_bytes = (unsigned)W * C * 4u;
+  const int row_idx = W * C;
+  const int rows = hend - hstart;
+  size_t out = ((size_t)row * PW) * C + cbase;
+  for (int pw = 0; pw < PW; ++pw, out += C) {
+    int wstart = (int)floorf(pw * b.bin_w), wend = (int)ceilf((pw + 1) * b.bin_w);
+    wstart = min(max(wstart + b.start_w, 0), W); wend = min(max(wend + b.start_w, 0), W);
+    wstart = __builtin_amdgcn_readfirstlane(wstart); wend = __builtin_amdgcn_readfirstlane(wend);
+    const int bw = wend - wstart;
+    const bool is_empty = rows <= 0 || bw <= 0;
+    const float init = is_empty ? 0.f : -3.402823466e+38f;
+    float4 mv = make_float4(init, init, init, init); int4 mi = make_int4(-1, -1, -1, -1);
+    if (!is_empty) {
+      const int idx0 = (hstart * W + wstart) * C;                // (float index of the window's first pixel inside the image)
+      const unsigned voff = lane_b + (unsigned)idx0 * 4u;
+      switch (bw) {                                              // wave-uniform
+        case 1: roi_row_steps<C, 1>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 2: roi_row_steps<C, 2>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 3: roi_row_steps<C, 3>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 4: roi_row_steps<C, 4>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 5: roi_row_steps<C, 5>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 6: roi_row_steps<C, 6>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 7: roi_row_steps<C, 7>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        case 8: roi_row_steps<C, 8>(rsrc, voff, idx0, rows, row_bytes, row_idx, mv, mi); break;
+        default: {
+          // wide windows: the reference's order is h, then w -- so row by row, eight columns per step, the last step of a row
+          // shifted left to end at the row's end (its leading pixels were seen already: a repeated value never wins a strict >)
+          unsigned vo = voff; int ix = idx0;
+          for (int h = 0; h < rows; ++h, vo += row_bytes, ix += row_idx) {
+            for (int w0 = 0; w0 < bw; w0 += 8) {
+              const int ws = min(w0, bw - 8);
+              roi_row_steps<C, 8>(rsrc, vo + (unsigned)ws * (C * 4u), ix + ws * C, 1, 0u, 0, mv, mi);
+            }
+          }
+        }
+      }
+      mi.x = mi.x < 0 ? -1 : mi.x + cbase; mi.y = mi.y < 0 ? -1 : mi.y + cbase + 1;
+      mi.z = mi.z < 0 ? -1 : mi.z + cbase + 2; mi.w = mi.w < 0 ? -1 : mi.w + cbase + 3;
+    }
+    if ((ROI_X & 4) && mv.x != 12345.f) continue;
     *reinterpret_cast<float4*>(top + out) = mv;
     *reinterpret_cast<int4*>(argmax + out) = mi;
   }
@@ -568,7 +684,9 @@ extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, 
     const int nrows = R * pooled_h;
     const int xps = 8 / (C / 256);                             // a workgroup = 4 rows of one slice; 8 workgroups = 4 xps rows of every slice
     const unsigned g = (unsigned)(8 * ((nrows + 4 * xps - 1) / (4 * xps)));
-#define GNET_ROWS(C_) roi_pool_fwd_rows<C_><<<g, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax)
+    static const bool rows1 = getenv("GNET_ROI_FWD_ROWS1") != nullptr;     // measurement only: round 3's kernel (scalar walkers)
+#define GNET_ROWS(C_) do { if (rows1) roi_pool_fwd_rows<C_><<<g, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax); \
+                           else roi_pool_fwd_rows2<C_><<<g, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax); } while (0)
     if (C == 256) GNET_ROWS(256); else if (C == 512) GNET_ROWS(512); else if (C == 1024) GNET_ROWS(1024); else GNET_ROWS(2048);
 #undef GNET_ROWS
   }
