@@ -58,6 +58,7 @@ def _defaults():
     g.pwfeat_narrow_dim = 64
     g.weight_init = "xavier"
     g.bias_const_init = 0.0
+    g.freeze_n_imfeat_layers = 3            # (config.py:78: trunk layers whose variables are not trained; the trunk is the caller's here)
     g.pw_feat_multiplyer = 1.0
     return cfg
 

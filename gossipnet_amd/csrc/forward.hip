@@ -842,7 +842,10 @@ constexpr size_t kEdgeFwdWSmem = (size_t)(3 * EFW_T1 + 3 * EFW_T2 + EFW_WAVES * 
 // (backward_edge.hip) -- storing them cost 0.37 GB of HBM writes per launch (2.8 TB/s on an MFMA-bound kernel)
 // and 5.9 GB of workspace for the bench batch.  KEEP (tests / debugging) stores them after all.
 template <bool TRAIN, bool KEEP>
-__global__ void __launch_bounds__(64 * EFW_WAVES, 3) edge_fwd_w(const EdgeFwdArgs a) {
+#ifndef EFW_OCC
+#define EFW_OCC 3     /* workgroups per CU (measurement builds: 4 = 128 registers per wave) */
+#endif
+__global__ void __launch_bounds__(64 * EFW_WAVES, EFW_OCC) edge_fwd_w(const EdgeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* sWpT = reinterpret_cast<unsigned*>(smem);      // Wp^T as three bf16 terms (layout above)
   unsigned* sW2T = sWpT + 3 * EFW_T1;                      // W2^T likewise
@@ -1504,7 +1507,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
     g.w1 = params + L.pw1; g.b1 = params + L.pb1; g.tc = buf->pw_tc; g.tn = buf->pw_tn;
     g.raw = L.raw; g.pw = buf->pw_feats;
     g.row_ptr = buf->row_ptr; g.straddle = buf->scratch_i;
-    g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
+    g.ef_tiles = (E + 31) / 32; g.ef_waves = max(1, min(EFW_OCC * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES)) * EFW_WAVES;
     GNET_LAUNCH(prof, GNET_K_GEOMETRY, s, edge_geometry<<<(E + 64 + 255) / 256, 256, 0, s>>>(g));
   }
   if (E > 0 && !L.raw) {
@@ -1542,7 +1545,7 @@ extern "C" int gnet_forward(const gnet_config* cfg, const gnet_shape* shape, con
 
   const int ntile_n = (N + 31) / 32;
   // edge_fwd_w partition (2 workgroups per CU): wave-owned contiguous tile ranges
-  const int ef_wg = max(1, min(3 * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
+  const int ef_wg = max(1, min(EFW_OCC * 256, ((E + 31) / 32 + EFW_WAVES - 1) / EFW_WAVES));
   const bool keep_h1 = training == 2;
   if (E > 0) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)edge_fwd_w<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEdgeFwdWSmem));

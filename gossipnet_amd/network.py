@@ -243,7 +243,11 @@ class Gnet(object):
             if nm.endswith("weights") and "/predict/" not in nm:
                 reg[off:off + k] = 1.0
         self._reg_mask = reg.to(self.device)
-        self.trainable_variables = [self.variables[nm] for nm, _ in self._spec]   # network.py:317-322
+        # network.py:317-322: the gnet / resnet variables minus the frozen trunk layers' prefixes (get_resnet, network.py:52-75).  The trunk
+        # is the caller's here (no resnet variables live in this object), so the list starts empty; a caller that keeps trunk variables of
+        # its own under the reference's names adds the first cfg.gnet.freeze_n_imfeat_layers layer prefixes and calls _filter_trainable().
+        self._ignore_prefixes = []
+        self._filter_trainable()
         self.weight_reg = weight_reg                       # l2 scale (tf l2_regularizer(scale): scale*sum(w^2)/2)
         if class_weights is None:
             class_weights = np.ones((num_classes + 1), dtype=np.float32)           # network.py:282-284
@@ -452,6 +456,13 @@ class Gnet(object):
             _lib.check(self._lib.gnet_backward_prepare(C.byref(self._cfg), C.byref(shape), C.byref(inp), _vp(self.params),
                                                        C.byref(buf), 3, ss), "gnet_backward_prepare")
             self._bpos_done.record(self._side)
+
+    def _filter_trainable(self):
+        """`trainable_variables` / `trainable_names` by the reference's rule (network.py:317-322)."""
+        self.trainable_names = [nm for nm, _ in self._spec
+                                if (nm.startswith("gnet") or nm.startswith("resnet"))
+                                and not any(nm.startswith(pref) for pref in self._ignore_prefixes)]
+        self.trainable_variables = [self.variables[nm] for nm in self.trainable_names]
 
     def _mode(self, training):
         """`training` argument of the C ABI: 0 inference, 1 training, 2 training + per-block pw_fc1 activations kept."""

@@ -149,3 +149,20 @@ def test_stale_library_is_detected_and_unhashed_library_is_loaded(tmp_path, monk
         warnings.simplefilter("always")
         _lib.load()
     assert calls == [1] and any("no source hash" in str(x.message) for x in w)    # ... without a record: loaded, not rebuilt
+
+
+
+@pytest.mark.gpu
+def test_trainable_variables_follow_the_reference_rule():
+    """network.py:317-322: gnet / resnet variables minus the ignored prefixes (the frozen trunk layers of get_resnet)."""
+    import torch
+    from gossipnet_amd.config import experiment_cfg
+    from gossipnet_amd.network import Gnet
+    experiment_cfg()
+    net = Gnet(3, device=torch.device("cuda", 0))
+    names = [nm for nm, _ in net._spec]
+    assert net.trainable_names == names and len(net.trainable_variables) == len(names)
+    net._ignore_prefixes = ["gnet/block01/"]
+    net._filter_trainable()
+    assert net.trainable_names == [nm for nm in names if not nm.startswith("gnet/block01/")]
+    assert all(v is net.variables[nm] for v, nm in zip(net.trainable_variables, net.trainable_names))
