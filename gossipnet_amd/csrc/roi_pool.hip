@@ -309,6 +309,150 @@ __global__ void __launch_bounds__(256) roi_pool_fwd_rows2(const float* __restric
   }
 }
 
+// roi_pool_fwd_cols: the same walk TRANSPOSED -- one wave = a COLUMN of bins (roi, all ph, one pw) of one 256-channel slice.  What bounds
+// roi_pool_fwd_rows2 is the 8 GB its windows pull through the L1s (64 bytes per clock and CU: ~230 us; tools/roi_ablate.sh), 1.6 times
+// the ROIs' area because neighbouring bins overlap by a pixel row / column (floor / ceil of fractional bin edges).  A column of bins has
+// ONE width (a single compile-time dispatch per wave instead of one per bin), and its bins follow each other down the image: the row a
+// bin shares with the next one is loaded ONCE and compared into both (two running (max, arg-max) sets in registers, rotated at a bin's
+// last row) -- a fifth fewer loads.  Needs bin_h >= 1 (then a row belongs to at most two consecutive bins, the earlier bin first: the
+// reference's order h, then w inside every bin is kept; strict >) and a window of at most 8 columns; other ROIs take the plain per-bin
+// walk below in the same wave.  top / argmax bit-exact.
+#ifndef ROI_NT
+#define ROI_NT 1      /* the pooled outputs (0.8 GB against a 2.4 MB feature-map slice that should stay in the L2) leave as non-temporal stores: -2..3 %; 0 = plain stores */
+#endif
+typedef float roi_f4 __attribute__((ext_vector_type(4)));
+typedef int roi_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void roi_st4(float* p, float x, float y, float z, float w) {
+  const roi_f4 v = {x, y, z, w};
+  if (ROI_NT) __builtin_nontemporal_store(v, reinterpret_cast<roi_f4*>(p)); else *reinterpret_cast<roi_f4*>(p) = v;
+}
+__device__ __forceinline__ void roi_st4(int* p, int x, int y, int z, int w) {
+  const roi_i4 v = {x, y, z, w};
+  if (ROI_NT) __builtin_nontemporal_store(v, reinterpret_cast<roi_i4*>(p)); else *reinterpret_cast<roi_i4*>(p) = v;
+}
+#define ROI_ST4(p_, x_, y_, z_, w_) roi_st4((p_), (x_), (y_), (z_), (w_))
+template <int C, int BW>
+__device__ __forceinline__ void roi_col_shared(const __amdgpu_buffer_rsrc_t rsrc, const RoiBox& b, const int PH, const int PW, const int H, const int W,
+                                               const int wstart, const unsigned lane_b, const int cbase, float* __restrict__ top,
+                                               int* __restrict__ argmax, size_t out) {
+  const float NEG = -3.402823466e+38f;
+  int hs0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(0 * b.bin_h) + b.start_h, 0), H));
+  int he0 = __builtin_amdgcn_readfirstlane(min(max((int)ceilf(1 * b.bin_h) + b.start_h, 0), H));
+  float4 mv = make_float4(0.f, 0.f, 0.f, 0.f); int4 mi = make_int4(-1, -1, -1, -1);
+  { const float i0 = he0 > hs0 ? NEG : 0.f; mv = make_float4(i0, i0, i0, i0); }
+  int h = hs0;
+  for (int ph = 0; ph < PH; ++ph, out += (size_t)PW * C) {
+    int hs1 = 0x7fffffff, he1 = 0x7fffffff;
+    if (ph + 1 < PH) {
+      hs1 = __builtin_amdgcn_readfirstlane(min(max((int)floorf((ph + 1) * b.bin_h) + b.start_h, 0), H));
+      he1 = __builtin_amdgcn_readfirstlane(min(max((int)ceilf((ph + 2) * b.bin_h) + b.start_h, 0), H));
+    }
+    const float i1 = (ph + 1 < PH && he1 > hs1) ? NEG : 0.f;
+    float4 nv = make_float4(i1, i1, i1, i1); int4 ni = make_int4(-1, -1, -1, -1);
+    h = max(h, hs0);
+    unsigned voff = lane_b + (unsigned)((h * W + wstart) * C) * 4u;
+    int idx = (h * W + wstart) * C;
+    for (; h < he0; ++h, voff += (unsigned)W * C * 4u, idx += W * C) {
+      float4 v[BW];
+#pragma unroll
+      for (int k = 0; k < BW; ++k) v[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, k * C * 4, 0));
+#pragma unroll
+      for (int k = 0; k < BW; ++k) {
+        const int cand = idx + k * C;
+        if (v[k].x > mv.x) { mv.x = v[k].x; mi.x = cand; }
+        if (v[k].y > mv.y) { mv.y = v[k].y; mi.y = cand; }
+        if (v[k].z > mv.z) { mv.z = v[k].z; mi.z = cand; }
+        if (v[k].w > mv.w) { mv.w = v[k].w; mi.w = cand; }
+      }
+      if (h >= hs1) {                                         // (uniform) the row the next bin shares: the same registers, its own maxima
+#pragma unroll
+        for (int k = 0; k < BW; ++k) {
+          const int cand = idx + k * C;
+          if (v[k].x > nv.x) { nv.x = v[k].x; ni.x = cand; }
+          if (v[k].y > nv.y) { nv.y = v[k].y; ni.y = cand; }
+          if (v[k].z > nv.z) { nv.z = v[k].z; ni.z = cand; }
+          if (v[k].w > nv.w) { nv.w = v[k].w; ni.w = cand; }
+        }
+      }
+    }
+    asm volatile("" : "+v"(mv.x), "+v"(mv.y), "+v"(mv.z), "+v"(mv.w));     // (see roi_row_steps)
+    mi.x = mi.x < 0 ? -1 : mi.x + cbase; mi.y = mi.y < 0 ? -1 : mi.y + cbase + 1;
+    mi.z = mi.z < 0 ? -1 : mi.z + cbase + 2; mi.w = mi.w < 0 ? -1 : mi.w + cbase + 3;
+    ROI_ST4(top + out, mv.x, mv.y, mv.z, mv.w);
+    ROI_ST4(argmax + out, mi.x, mi.y, mi.z, mi.w);
+    mv = nv; mi = ni; hs0 = hs1; he0 = he1;
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) roi_pool_fwd_cols(const float* __restrict__ data, int B, int H, int W,
+                                                         const float* __restrict__ rois, int ncols, int PH, int PW,
+                                                         float scale, float* __restrict__ top, int* __restrict__ argmax) {
+  constexpr int XPS = 8 / (C / 256);                          // XCDs per slice
+  static_assert(C % 256 == 0 && XPS >= 1 && XPS * (C / 256) == 8, "1, 2, 4 or 8 slices");
+  const int lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, slice = xcd / XPS;
+  const int colid = ((int)(blockIdx.x >> 3) * XPS + (xcd % XPS)) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (colid >= ncols) return;
+  const int pw = colid % PW, r = colid / PW;
+  const RoiBox b = roi_decode(rois + (size_t)r * 5, scale, PH, PW);
+  const bool no_image = b.batch < 0 || b.batch >= B;     // (undefined in the reference; here such a ROI pools nothing)
+  int wstart = (int)floorf(pw * b.bin_w), wend = (int)ceilf((pw + 1) * b.bin_w);
+  wstart = min(max(wstart + b.start_w, 0), W); wend = min(max(wend + b.start_w, 0), W);
+  wstart = __builtin_amdgcn_readfirstlane(wstart); wend = __builtin_amdgcn_readfirstlane(wend);
+  const int bw = no_image ? 0 : wend - wstart;
+  const float* img = data + (size_t)(no_image ? 0 : b.batch) * C * H * W + 256 * slice;
+  const unsigned long long ib = reinterpret_cast<unsigned long long>(img);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ib), hi = __builtin_amdgcn_readfirstlane((unsigned)(ib >> 32));
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                                        (int)(((unsigned)H * W * C - 256u * slice) * 4u), 0x00020000);
+  const unsigned lane_b = 16u * lane;
+  const int cbase = 256 * slice + 4 * lane;
+  size_t out = (((size_t)r * PH) * PW + pw) * C + cbase;
+  const bool shared = __builtin_amdgcn_readfirstlane((int)(b.bin_h >= 1.f)) != 0 && bw >= 1 && bw <= 8;
+  if (shared) {
+    switch (bw) {
+      case 1: roi_col_shared<C, 1>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      case 2: roi_col_shared<C, 2>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      case 3: roi_col_shared<C, 3>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      case 4: roi_col_shared<C, 4>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      case 5: roi_col_shared<C, 5>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      case 6: roi_col_shared<C, 6>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      case 7: roi_col_shared<C, 7>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+      default: roi_col_shared<C, 8>(rsrc, b, PH, PW, H, W, wstart, lane_b, cbase, top, argmax, out); break;
+    }
+    return;
+  }
+  // small bins (a row may belong to three or more of them), wide windows, empty columns: bin by bin, eight columns per step, the last
+  // step of a row shifted left to end at the row's end (its leading pixels were seen already: a repeated value never wins a strict >)
+  for (int ph = 0; ph < PH; ++ph, out += (size_t)PW * C) {
+    int hstart = (int)floorf(ph * b.bin_h), hend = (int)ceilf((ph + 1) * b.bin_h);
+    hstart = min(max(hstart + b.start_h, 0), H); hend = min(max(hend + b.start_h, 0), H);
+    hstart = __builtin_amdgcn_readfirstlane(hstart); hend = __builtin_amdgcn_readfirstlane(hend);
+    const int rows = hend - hstart;
+    const bool is_empty = rows <= 0 || bw <= 0;
+    const float init = is_empty ? 0.f : -3.402823466e+38f;
+    float4 mv = make_float4(init, init, init, init); int4 mi = make_int4(-1, -1, -1, -1);
+    if (!is_empty) {
+      unsigned vo = lane_b + (unsigned)((hstart * W + wstart) * C) * 4u; int ix = (hstart * W + wstart) * C;
+      for (int h = 0; h < rows; ++h, vo += (unsigned)W * C * 4u, ix += W * C) {
+        if (bw >= 8) {
+          for (int w0 = 0; w0 < bw; w0 += 8) {
+            const int ws = min(w0, bw - 8);
+            roi_row_steps<C, 8>(rsrc, vo + (unsigned)ws * (C * 4u), ix + ws * C, 1, 0u, 0, mv, mi);
+          }
+        } else {
+          for (int w0 = 0; w0 < bw; ++w0) roi_row_steps<C, 1>(rsrc, vo + (unsigned)w0 * (C * 4u), ix + w0 * C, 1, 0u, 0, mv, mi);
+        }
+      }
+      mi.x = mi.x < 0 ? -1 : mi.x + cbase; mi.y = mi.y < 0 ? -1 : mi.y + cbase + 1;
+      mi.z = mi.z < 0 ? -1 : mi.z + cbase + 2; mi.w = mi.w < 0 ? -1 : mi.w + cbase + 3;
+    }
+    ROI_ST4(top + out, mv.x, mv.y, mv.z, mv.w);
+    ROI_ST4(argmax + out, mi.x, mi.y, mi.z, mi.w);
+  }
+}
+
 // deterministic backward: one wave per input pixel (n, h, w), the four waves of a workgroup = a 2 x 2 block of pixels.
 // A pooled element's (argmax, top_diff) vector is re-read by every pixel of its bin's window (2-3 wide after the floor /
 // ceil overlap): neighbouring pixels walk the same ROIs and bins in the same order at the same time, so three of the four
@@ -685,6 +829,15 @@ extern "C" int roi_pool_fwd_f32(const float* bottom_data, int32_t B, int32_t H, 
     const int xps = 8 / (C / 256);                             // a workgroup = 4 rows of one slice; 8 workgroups = 4 xps rows of every slice
     const unsigned g = (unsigned)(8 * ((nrows + 4 * xps - 1) / (4 * xps)));
     static const bool rows1 = getenv("GNET_ROI_FWD_ROWS1") != nullptr;     // measurement only: round 3's kernel (scalar walkers)
+    static const bool rows2 = getenv("GNET_ROI_FWD_ROWS2") != nullptr;     // measurement only: rows of bins (no shared loads)
+    if (!rows1 && !rows2 && (long long)R * pooled_w <= 0x0fffffffLL) {
+      const int ncols = R * pooled_w;
+      const unsigned gc = (unsigned)(8 * ((ncols + 4 * xps - 1) / (4 * xps)));
+#define GNET_COLS(C_) roi_pool_fwd_cols<C_><<<gc, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, ncols, pooled_h, pooled_w, spatial_scale, top_data, argmax)
+      if (C == 256) GNET_COLS(256); else if (C == 512) GNET_COLS(512); else if (C == 1024) GNET_COLS(1024); else GNET_COLS(2048);
+#undef GNET_COLS
+      return launch_status();
+    }
 #define GNET_ROWS(C_) do { if (rows1) roi_pool_fwd_rows<C_><<<g, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax); \
                            else roi_pool_fwd_rows2<C_><<<g, 256, 0, (hipStream_t)stream>>>(bottom_data, B, H, W, bottom_rois, nrows, pooled_h, pooled_w, spatial_scale, top_data, argmax); } while (0)
     if (C == 256) GNET_ROWS(256); else if (C == 512) GNET_ROWS(512); else if (C == 1024) GNET_ROWS(1024); else GNET_ROWS(2048);
