@@ -594,6 +594,9 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_pixel(const float* __restric
 // (roi, ph, pw) order), and every wave then walks the list for its own channels as ONE stream: the load pipeline is filled and
 // drained once per round, not once per 64 bins.  (A round with more than RPB_CAP bins -- many tiny ROIs on one block -- is
 // redone step by step by each wave: correct, just not shared.)
+#ifndef ROI_BX
+#define ROI_BX 0   /* ablation mask of measurement builds (WRONG results, durations only): 1 = no compare-adds, 2 = no loads of the pooled vectors */
+#endif
 constexpr int RPB_CAP = 512;        // bins of a round that go through LDS (more: every wave redoes the round's steps itself)
 // CPL channels per lane (4: 16-byte loads, 256-channel slices; 2: 8-byte loads, 128-channel slices), NW waves = slices per workgroup
 template <int D, int CPL, int NW>
@@ -702,6 +705,7 @@ __global__ void __launch_bounds__(64 * NW) roi_pool_bwd_block(const float* __res
   // of the wave is live here) -- two vector instructions per (pixel, component) instead of three; pixels the reference's window
   // test excludes for this bin (v) are skipped by uniform branches
   auto add_bin = [&](const ivec& a_, const fvec& g_, const int v) {
+    if (ROI_BX & 1) { asm volatile("" :: "v"(a_), "v"(g_)); return; }
     int ax[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) ax[i] = a_[i] - c - i;      // = pixel * C where it is this lane's channel
@@ -729,7 +733,8 @@ __global__ void __launch_bounds__(64 * NW) roi_pool_bwd_block(const float* __res
         const int pq = e + q < T ? __builtin_amdgcn_readfirstlane(pk[q]) : 0;
         v_[q] = pq & 15;
         const size_t o = (size_t)(pq >> 4) * C;
-        a_[q] = *reinterpret_cast<const ivec*>(am_lane + o); g_[q] = *reinterpret_cast<const fvec*>(g_lane + o);
+        if (ROI_BX & 2) { for (int i_ = 0; i_ < CPL; ++i_) { a_[q][i_] = (int)o + i_; g_[q][i_] = 1.f; } }
+        else { a_[q] = *reinterpret_cast<const ivec*>(am_lane + o); g_[q] = *reinterpret_cast<const fvec*>(g_lane + o); }
       }
     };
     issue(0, amA, gA, vA);
