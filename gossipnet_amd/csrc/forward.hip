@@ -700,7 +700,14 @@ __global__ void __launch_bounds__(512) pw_fwd3(const PwFwd3Args aa) {
         pw2_st2(a.pw + (size_t)ep * D_E, pw_lo, make_float2(fmaxf(r_.x + b3a, 0.f), fmaxf(r_.y + b3b, 0.f)));
       }
       if (s_ == PW3_S_FC1 && it == 5) { GSTAMP(aa, 2); GSTAMP_W(aa, 9, 256); }
+#ifdef PW3_STAGGER
+      // (measurement: the two waves of a SIMD -- w and w + 4 -- form the next tile's fc1 and issue its h1 stores at DIFFERENT k-steps,
+      //  so that one's wait for the stores' acknowledgement falls into the other's MFMA stream)
+      if (s_ == PW3_STAGGER_A && wave < 4) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
+      if (s_ == PW3_STAGGER_B && wave >= 4) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
+#else
       if (s_ == PW3_S_FC1) PW3_FC1(Hn, min(t + 1, nt - 1) * PW2_T);
+#endif
       if (s_ == PW3_S_FC1 + 1 && it == 5) { GSTAMP(aa, 3); GSTAMP_W(aa, 10, 256); }
       if (s_ == PW3_S_W3 && it == 5) { GSTAMP(aa, 4); GSTAMP_W(aa, 11, 256); }
       if (s_ == PW3_S_W3) {
