@@ -362,3 +362,39 @@ def test_a_rank_without_images_contributes_zero():
     empty = {k: v[:0] for k, v in make_image(5, 80, seed=4).items()}
     net.run(DeviceBatch([empty], dev)); torch.cuda.synchronize()
     assert float(net.loss) == 0.0 and net.grads.abs().max().item() == 0.0
+
+
+@pytest.mark.gpu
+def test_backward_without_a_prepared_half_gives_the_same_bits():
+    """gnet_backward(prepared = 0) builds the winner lists itself (gnet_backward_prepare phase 0 = 1 + 2 + 3 on its own stream); the
+    product path runs the three phases on a side stream with two events (prepared = 1, prepared_event, positions_event).  Same
+    gradients, bit for bit -- also with prepared = 1 and NO events after the caller has ordered the streams itself."""
+    import ctypes as C
+    import torch
+    from gossipnet_amd import _lib
+    from gossipnet_amd.config import experiment_cfg
+    from gossipnet_amd.network import Gnet, DeviceBatch
+    from gossipnet_amd.synthetic import make_image
+    experiment_cfg()
+    dev = torch.device("cuda", 0)
+    net = Gnet(80, device=dev)
+    batch = DeviceBatch([make_image(300, 80, seed=3), make_image(200, 80, seed=4)], dev)
+    net.run(batch)
+    torch.cuda.synchronize()
+    ref = net.grads.clone()
+    lib = net._lib
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for prepared in (0, 1):
+        g2 = torch.full_like(ref, float("nan"))
+        if prepared:      # the caller's own ordering: every phase on the launch stream, no events
+            for phase in (1, 2, 3):
+                _lib.check(lib.gnet_backward_prepare(C.byref(net._cfg), C.byref(net._shape), C.byref(net._inputs), vp(net.params),
+                                                     C.byref(net._buf), phase, s), "gnet_backward_prepare")
+        _lib.check(lib.gnet_backward(C.byref(net._cfg), C.byref(net._shape), C.byref(net._inputs), vp(net.params), C.byref(net._buf),
+                                     vp(g2), prepared, None, None, s), "gnet_backward")
+        torch.cuda.synchronize()
+        assert torch.equal(g2, ref), "prepared = %d" % prepared
+    # an unknown phase is refused
+    assert lib.gnet_backward_prepare(C.byref(net._cfg), C.byref(net._shape), C.byref(net._inputs), vp(net.params),
+                                     C.byref(net._buf), 7, s) != 0
