@@ -426,7 +426,15 @@ __device__ __forceinline__ void ebw_stage_h1(float* sH, int* sE, const float* sW
 constexpr int EBW_WAVES = 4;
 constexpr int EBW_SLOTS = 3;                                    // detections of a tile handled between two LDS hand-offs
 constexpr int EBW_WAVE_FLOATS = 32 * LD64 + 32 + EBW_SLOTS * 128;   // h1/g1 tile, edge ids [32], RJ/DV [slots][64]
-constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + D_P * LD64 + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);   // 68 KB: two workgroups per CU
+// g1 = d h2 . W2^T on the bf16 pipe (round 6): W2 as three bf16 terms in the k-slot order of its MFMA operand, [term][f 64][EBW_LDW] words --
+// word h * 16 + q * 4 + w = slots 2 w, 2 w + 1 of k-step q, half h: column j = 16 q + 8 (s >> 2) + 4 h + (s & 3), the order of the lane's d h2
+// registers (edge_fwd_w's layout for its second layer; 36-word rows: eight lanes' 16-byte reads cover the banks once)
+#ifndef EBW_G1_BF16
+#define EBW_G1_BF16 1
+#endif
+constexpr int EBW_LDW = 36;
+constexpr int EBW_W2_WORDS = EBW_G1_BF16 ? 3 * D_P * EBW_LDW : D_P * LD64;
+constexpr size_t kEdgeBwdWSmem = (size_t)(D_P * LD32 + EBW_W2_WORDS + EBW_WAVES * EBW_WAVE_FLOATS) * sizeof(float);   // 78 KB (68 with the fp32 g1): two workgroups per CU
 
 // Every wave owns whole 32-winner tiles of the block's winner list (rows sorted by centre), no workgroup barrier
 // in the tile loop.  Per tile:
@@ -449,7 +457,7 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
   float* sW2 = sWpT + D_P * LD32;              // [64][68]  W2[f][j]:    B operand of g1 (16-byte reads along j)
   GSTAMP(a, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* sH = sW2 + D_P * LD64 + wave * EBW_WAVE_FLOATS;   // [32][68] bias -> h1 -> g1 of this wave's tile
+  float* sH = sW2 + EBW_W2_WORDS + wave * EBW_WAVE_FLOATS;   // [32][68] bias -> h1 -> g1 of this wave's tile
   int* sE = reinterpret_cast<int*>(sH + 32 * LD64);        // [32] edge of every tile row
   int* sRJ = sE + 32;                          // [slots][64] tile row of column j's winner (-1: not in this tile)
   float* sDV = reinterpret_cast<float*>(sRJ + EBW_SLOTS * 64);   // [slots][64] d_pc[c][j]
@@ -537,7 +545,22 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
 #pragma unroll
   for (int j = 0; j < 2; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sWpT + (i >> 3) * LD32 + 4 * (i & 7)) = wst[j]; }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; *reinterpret_cast<f32x4*>(sW2 + (i >> 4) * LD64 + 4 * (i & 15)) = wst[2 + j]; }
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j;
+    if (EBW_G1_BF16) {
+      // W2[f][4 g .. 4 g + 3] -> slots 4 ((g & 3) >> 1) .. + 3 of (half g & 1, k-step g >> 2): two words per term
+      const int f = i >> 4, g = i & 15;
+      unsigned ph0, pm0, pl0, ph1, pm1, pl1;
+      split3_pk(wst[2 + j].x, wst[2 + j].y, ph0, pm0, pl0);
+      split3_pk(wst[2 + j].z, wst[2 + j].w, ph1, pm1, pl1);
+      unsigned* dst = reinterpret_cast<unsigned*>(sW2) + f * EBW_LDW + (g & 1) * 16 + (g >> 2) * 4 + 2 * ((g & 3) >> 1);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(ph0, ph1);
+      *reinterpret_cast<uint2*>(dst + D_P * EBW_LDW) = make_uint2(pm0, pm1);
+      *reinterpret_cast<uint2*>(dst + 2 * D_P * EBW_LDW) = make_uint2(pl0, pl1);
+    } else {
+      *reinterpret_cast<f32x4*>(sW2 + (i >> 4) * LD64 + 4 * (i & 15)) = wst[2 + j];
+    }
+  }
   __syncthreads();
   GSTAMP(a, 1);
   if (have_tiles) ebw_stage_h1(sH, sE, sWpT, fx, fy, fpa, first_e, lane);
@@ -700,10 +723,26 @@ __global__ void __launch_bounds__(64 * EBW_WAVES, 2) edge_bwd_w(const EdgeBwdWAr
       float4 hm[8];
 #pragma unroll
       for (int g = 0; g < 4; ++g) { hm[g] = *reinterpret_cast<const float4*>(hp + 8 * g); hm[4 + g] = *reinterpret_cast<const float4*>(hp + 32 + 8 * g); }
+      if (EBW_G1_BF16) {
+        // six bf16 products of exact three-term splits per fp32 product (common.hpp: mma6): 48 MFMAs of 32 cycles for the 64 of 64 cycles
+        // below; the lane's d h2 registers are split here (176 vector instructions on the wave's own path, lesson 76: the balance is
+        // +1700 pipe cycles per tile)
+        const unsigned* a0 = reinterpret_cast<const unsigned*>(sW2) + col * EBW_LDW + half * 16;
+        const unsigned* a1 = a0 + 32 * EBW_LDW;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const Bf3 db = split3_8(f32x4{dA[8 * q], dA[8 * q + 1], dA[8 * q + 2], dA[8 * q + 3]}, f32x4{dA[8 * q + 4], dA[8 * q + 5], dA[8 * q + 6], dA[8 * q + 7]});
+          Bf3 w0, w1;
+          w0.h = *reinterpret_cast<const u32x4*>(a0 + 4 * q); w0.m = *reinterpret_cast<const u32x4*>(a0 + 4 * q + D_P * EBW_LDW); w0.l = *reinterpret_cast<const u32x4*>(a0 + 4 * q + 2 * D_P * EBW_LDW);
+          w1.h = *reinterpret_cast<const u32x4*>(a1 + 4 * q); w1.m = *reinterpret_cast<const u32x4*>(a1 + 4 * q + D_P * EBW_LDW); w1.l = *reinterpret_cast<const u32x4*>(a1 + 4 * q + 2 * D_P * EBW_LDW);
+          g1a = mma6(g1a, w0, db);
+          g1b = mma6(g1b, w1, db);
+        }
+      }
       const float* b0 = sW2 + col * LD64 + 4 * half;
       const float* b1 = b0 + 32 * LD64;
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
+      for (int s8 = 0; s8 < (EBW_G1_BF16 ? 0 : 8); ++s8) {
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b0 + 8 * s8);
         const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1 + 8 * s8);
         g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0.x, dA[4 * s8 + 0], g1a, 0, 0, 0);
