@@ -83,13 +83,13 @@ def executed_mfma_flops(cls, E, N, winners_per_block, pw_rows):
     """MFMA FLOPs one launch really issues, per pipe: (fp32 FLOPs: 4096 per v_mfma_f32_32x32x2_f32, bf16 FLOPs: 32768 per
     v_mfma_f32_32x32x16_bf16), from the kernels' tile loops:
     edge_fwd_w forms its fp32 products as six bf16 products of three-term splits: 72 bf16 MFMAs per 32 edges (the fp32 formulation
-    it replaces: 96 fp32 MFMAs, see `fp32_equivalent_flops`); edge_bwd_w 24 bf16 MFMAs (h1, the forward's sequence) + 128 fp32 MFMAs
-    per 32 winner rows; pw_fwd3 (round 6) per 32 edges and wave 96 (fc2) + 12 (fc3) + 1 (fc2's bias) bf16 MFMAs and 4 fp32 MFMAs
+    it replaces: 96 fp32 MFMAs, see `fp32_equivalent_flops`); edge_bwd_w 24 (h1, the forward's sequence) + 48 (g1 = d h2 . W2^T, round 6) bf16
+    MFMAs + 64 fp32 MFMAs (d P, d Wp) per 32 winner rows; pw_fwd3 (round 6) per 32 edges and wave 96 (fc2) + 12 (fc3) + 1 (fc2's bias) bf16 MFMAs and 4 fp32 MFMAs
     (fc1's K = 8 geometry product; the 2C score columns are two table rows per edge), eight waves; pw_bwd_bf (round 6) per 32
     listed rows and wave 216 bf16 MFMAs (d2 12, dW3 12, dW2 96, d h1 96), eight waves.  (GNET_PW_FP32_PIPE: round 5's fp32 kernels.)"""
     table = {
         "edge_fwd": (0.0, 72 * 32768.0 * E / 32),
-        "edge_bwd": (128 * 4096.0 * winners_per_block / 32, 24 * 32768.0 * winners_per_block / 32),
+        "edge_bwd": (64 * 4096.0 * winners_per_block / 32, 72 * 32768.0 * winners_per_block / 32),
         "pw_fwd": (2.0 * E * (8 * 256 + 256 * 256 + 256 * 32), 0.0) if PW_FP32_PIPE else
                   (8 * 4 * 4096.0 * E / 32, 8 * 109 * 32768.0 * E / 32),
         "pw_bwd_main": (2.0 * pw_rows * (2 * 256 * 256 + 2 * 256 * 32), 0.0) if PW_FP32_PIPE else (0.0, 8 * 216 * 32768.0 * pw_rows / 32),
@@ -626,7 +626,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_note": ("fp32 operands, accumulators and results throughout; the four edge-sized FC kernels (edge_fwd_w, pw_fwd3, pw_bwd_bf, and "
-                           "edge_bwd_w's h1 recomputation) form each fp32 product as six bf16 products of exact three-term splits with fp32 "
+                           "edge_bwd_w's h1 recomputation and g1 product) form each fp32 product as six bf16 products of exact three-term splits with fp32 "
                            "accumulation -- error against fp64 at the fp32 MFMA's level, measured on the kernels' own operands by "
                            "tests/test_gpu_bf16x3.py (gnet_debug_gemm) and profiles/r05_bf16x3_probe.txt; parity bars unchanged"),
             "data": "synthetic",

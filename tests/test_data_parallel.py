@@ -97,7 +97,7 @@ def test_bench_prices_the_two_mfma_pipes():
     assert f32 == 0.0 and bf16 == 72 * 32768.0 * 1000
     assert bench.fp32_equivalent_flops("edge_fwd", E, N, W, R) == 96 * 4096.0 * 1000 == 12288.0 * E
     f32, bf16 = bench.executed_mfma_flops("edge_bwd", E, N, W, R)
-    assert (f32, bf16) == (128 * 4096.0 * 200, 24 * 32768.0 * 200)
+    assert (f32, bf16) == (64 * 4096.0 * 200, 72 * 32768.0 * 200)
     assert bench.fp32_equivalent_flops("edge_bwd", E, N, W, R) == 160 * 4096.0 * 200
     # round 6: the pw-MLP kernels on the bf16 pipe -- pw_bwd_bf 216 bf16 MFMAs per wave and 32 listed rows (8 waves) for the 294 912
     # FLOPs per row of its four fp32 GEMMs; pw_fwd3 109 bf16 + 4 fp32 MFMAs per wave and 32 edges for 151 552 FLOPs per edge
