@@ -145,6 +145,43 @@ def test_roi_pool_random_vs_oracle(B, H, W, C, R, ph, pw, scale, seed):
     assert np.abs(ga - _scatter_by_argmax(ram, gtop, rois, (B, H, W, C))).max() <= 1e-5 * max(1.0, np.abs(rgrad).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [256, 512, 1024, 2048])
+def test_roi_pool_forward_column_kernel_paths(C):
+    """roi_pool_fwd_cols (C a multiple of 256): one wave = a column of bins.  Its three paths against the C oracle, bit for bit:
+    the shared walk (bin_h >= 1, windows of at most 8 columns: the row two consecutive bins share is loaded once), small ROIs (bin_h < 1:
+    a map row belongs to three or more bins -- bin by bin), wide windows (more than 8 columns per bin: steps of eight, the last one
+    shifted left), with ROIs hanging over every edge of the map, an empty ROI and one whose image index is outside the batch."""
+    from gossipnet_amd.roi_pooling_layer.roi_pooling_op import roi_pool
+    rng = np.random.default_rng(C)
+    B, H, W = 2, 23, 41
+    data = rng.normal(size=(B, H, W, C)).astype(np.float32)
+    data[0, 3:6, 4:9] = data[0, 3, 4]                     # ties inside windows: the FIRST maximum in (h, w) order must win
+    def box(x0, y0, w, h, b=None):
+        return [float(rng.integers(0, B) if b is None else b), x0, y0, x0 + w, y0 + h]
+    rois = []
+    for _ in range(12): rois.append(box(rng.uniform(-5, 30), rng.uniform(-5, 15), rng.uniform(8, 28), rng.uniform(8, 20)))      # shared walk
+    for _ in range(8): rois.append(box(rng.uniform(0, 38), rng.uniform(0, 20), rng.uniform(0.2, 5), rng.uniform(0.2, 5)))       # bin_h < 1
+    for _ in range(6): rois.append(box(rng.uniform(-70, -10), rng.uniform(0, 10), rng.uniform(70, 110), rng.uniform(9, 14)))     # wide windows (PW = 3 below too)
+    rois.append(box(500, 500, 10, 10)); rois.append(box(2, 2, 20, 12, b=7)); rois.append(box(10, 5, 0, 0))
+    rois = np.asarray(rois, np.float32)
+    for ph, pw, scale in ((7, 7, 1.0), (7, 3, 1.0), (2, 9, 0.5), (16, 1, 1.0)):
+        rtop, ram = native.roi_pool(data, _valid_batch(rois, B), ph, pw, scale)
+        top, am = roi_pool(torch.tensor(data, device="cuda:0"), torch.tensor(rois, device="cuda:0"), ph, pw, scale)
+        am, top = am.cpu().numpy(), top.cpu().numpy()
+        ok = rois[:, 0] < B                                # (an image index outside the batch reads out of bounds in the reference; here: zeros, -1)
+        assert np.array_equal(am[ok], ram[ok]) and np.array_equal(top[ok], rtop[ok]), (C, ph, pw)
+        assert (am[~ok] == -1).all() and (top[~ok] == 0).all()
+
+
+def _valid_batch(rois, B):
+    """The oracle (like the reference) indexes the image by the ROI's first column unchecked: give it a valid image for the rows the
+    device treats as 'no image' (their outputs are compared separately)."""
+    r = rois.copy()
+    r[r[:, 0] >= B, 0] = 0
+    return r
+
+
 def _scatter_by_argmax(argmax, grad, rois, shape):
     """The plain arg-max scatter (what roi_pool_bwd_atomic_f32 computes).  The reference's RoiPoolGrad is NOT always this
     sum: its feasible-bin / in-ROI tests (roi_pooling_op.cc:405-431) drop a pooled element whose arg-max pixel lies one
