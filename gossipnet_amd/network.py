@@ -260,11 +260,6 @@ class Gnet(object):
         self._row_ptr_tmp = [None, None]
         self._scratch_tmp = [None, None]
         self._side = None
-        # pass 2 of the graph build (the fill) on the side stream too, into edge arrays of the count slot's own (measurement switch; see
-        # _build_graph): it then runs beside the previous step's tail instead of at the head of this step's main-stream queue
-        self.fill_on_side = os.environ.get("GNET_FILL_ON_SIDE", "0") == "1"
-        self._edge_tmp = [None, None]
-        self._edges_free = [None, None]
         self.grad_scale = 1.0      # scale of the data-loss gradient (1 / images of the global step: mean over images)
         self.reg_scale = 1.0       # scale of the l2-regulariser gradient (1 / world size under a SUM all-reduce)
         # tests / debugging: keep the per-block pw_fc1 activations [E,64] in HBM (Gnet.debug_view("blk_h1", ...));
@@ -407,30 +402,8 @@ class Gnet(object):
         self._view(buf.row_ptr, N + 1, torch.int32).copy_(self._row_ptr_tmp[k][:N + 1])
         self._rp_free[k] = torch.cuda.Event()
         self._rp_free[k].record(torch.cuda.current_stream(self.device))
-        if self.fill_on_side and E > 0:
-            # edge arrays of this count slot (the plan's own stay unused): the fill is ordered behind the count on the side stream and
-            # behind the main-stream readers of the slot's previous use (two steps ago); the main stream waits for it
-            ne = E + 64
-            if self._edge_tmp[k] is None or self._edge_tmp[k][0].numel() < ne:
-                cap = int(ne * 1.1) + 1024
-                self._edge_tmp[k] = (torch.empty(cap, dtype=torch.int32, device=self.device), torch.empty(cap, dtype=torch.int32, device=self.device),
-                                     torch.empty(cap, dtype=torch.float32, device=self.device))
-            ec, en, ei = self._edge_tmp[k]
-            if self._edges_free[k] is not None:
-                self._side.wait_event(self._edges_free[k])
-            with torch.cuda.stream(self._side):
-                ss = C.c_void_p(self._side.cuda_stream)
-                _lib.check(self._scoped("graph", ss, lib.gnet_graph_fill, _vp(db.dets), N, _vp(db.det_off), db.n_img, thr,
-                                        _vp(self._row_ptr_tmp[k]), _vp(ec), _vp(en), _vp(ei), ss), "gnet_graph_fill")
-                fill_done = torch.cuda.Event()
-                fill_done.record(self._side)
-            torch.cuda.current_stream(self.device).wait_event(fill_done)
-            buf.edge_c, buf.edge_n, buf.edge_iou = _vp(ec), _vp(en), _vp(ei)
-            self._edge_slot = k
-        else:
-            self._edge_slot = None
-            _lib.check(self._scoped("graph", s, lib.gnet_graph_fill, _vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr,
-                                    buf.edge_c, buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
+        _lib.check(self._scoped("graph", s, lib.gnet_graph_fill, _vp(db.dets), N, _vp(db.det_off), db.n_img, thr, buf.row_ptr,
+                                buf.edge_c, buf.edge_n, buf.edge_iou, s), "gnet_graph_fill")
         self.num_edges = E
         return shape, buf
 
@@ -573,11 +546,6 @@ class Gnet(object):
                     # ONCE per optimisation step whatever the number of images in it: not scaled by grad_scale.
                     # Under data parallelism every rank adds reg_scale = 1 / world of it (the all-reduce sums).
                     self.grads.addcmul_(self.params, self._reg_mask, value=float(self.weight_reg) * float(self.reg_scale))
-        if getattr(self, "_edge_slot", None) is not None:
-            # every main-stream reader of this slot's edge arrays is queued: the slot's next fill (two steps on, side stream) waits here
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self._edges_free[self._edge_slot] = ev
         return self
 
     # ------------------------------------------------------------------ image-feature start features
